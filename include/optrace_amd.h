@@ -1,0 +1,345 @@
+/*
+ * optrace_amd.h -- C-ABI of the MI355X-native sequential ray-tracing core.
+ *
+ * The upstream reference (drocheam/optrace, pure NumPy) has no FFI boundary of its own
+ * (SURVEY.md section 8b); the drop-in boundary is the Python surface of
+ * optrace/tracer/__init__.py:3-63.  This header is the C-ABI that our Python mirror of that
+ * surface (package optrace_amd) binds with ctypes.  Every entry point names the reference
+ * function(s) it replaces as file:line relative to the reference checkout.
+ *
+ * Conventions
+ *   - All ray buffers are DEVICE pointers (HIP), caller-owned, struct-of-arrays.  Multi-component
+ *     quantities use the reference's Fortran-ordered layout (ray_storage.py:80-90): element
+ *     (ray r, section i, component c) of an (N, nt, 3) array lives at  r + N*(i + nt*c).
+ *   - dtypes follow ray_storage.py:77-90: positions/directions/refractive indices f64,
+ *     weights / wavelengths / polarisation f32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
+ *     with respect to the host unless stated otherwise.
+ *   - Return value: 0 on success, negative OT_ERR_* otherwise; ot_last_error() gives the text.
+ *   - Nothing here allocates or frees caller buffers.  Handles (ot_scene) own small device tables only.
+ */
+#ifndef OPTRACE_AMD_H
+#define OPTRACE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OT_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------------- */
+#define OT_OK 0
+#define OT_ERR_INVALID (-1)     /* bad argument / descriptor                                     */
+#define OT_ERR_HIP (-2)         /* HIP runtime error (text in ot_last_error)                     */
+#define OT_ERR_UNSUPPORTED (-3) /* feature not representable on the device                       */
+#define OT_ERR_NO_DEVICE (-4)   /* no HIP device available                                       */
+
+/* ---- numeric contract (reference class constants) ------------------------------------------ */
+#define OT_C_EPS 1e-6        /* Surface.C_EPS   surface.py:17        */
+#define OT_N_EPS_SURF 1e-10  /* Surface.N_EPS   surface.py:20        */
+#define OT_N_EPS_TRACE 1e-11 /* Raytracer.N_EPS raytracer.py:30      */
+#define OT_MAX_HIT_ITER 200  /* regula-falsi timeout surface.py:403  */
+
+/* counter rows, Raytracer.INFOS raytracer.py:43-48 */
+#define OT_INFO_ABSORB_MISSING 0
+#define OT_INFO_TIR 1
+#define OT_INFO_ILL_COND 2
+#define OT_INFO_OUTLINE_INTERSECTION 3
+#define OT_INFO_HURB_NEG_DIR 4
+#define OT_N_INFOS 5
+
+/* ---- surfaces (optrace/tracer/geometry/surface/) -------------------------------------------- */
+#define OT_SURF_CIRCLE 0  /* CircularSurface    circular_surface.py:9     flat disc               */
+#define OT_SURF_RING 1    /* RingSurface        ring_surface.py:10        flat annulus            */
+#define OT_SURF_RECT 2    /* RectangularSurface rectangular_surface.py:10 flat, rotated by angle  */
+#define OT_SURF_SLIT 3    /* SlitSurface        slit_surface.py:12        rect minus inner rect   */
+#define OT_SURF_CONIC 4   /* ConicSurface / SphericalSurface (k = 0) conic_surface.py:10          */
+#define OT_SURF_ASPHERE 5 /* AsphericSurface    aspheric_surface.py:9     conic + even polynomial */
+
+#define OT_MAX_ASPH 12 /* even-order coefficients a2 .. a24 */
+
+typedef struct ot_surface {
+    int32_t kind;   /* OT_SURF_*                                                                 */
+    int32_t ncoeff; /* ASPHERE: number of even polynomial coefficients                           */
+    double pos[3];  /* centre position                                                           */
+    double r;       /* outer radius (CIRCLE/RING/CONIC/ASPHERE); RECT/SLIT keep the reference's 1 */
+    double ri;      /* RING: inner radius                                                        */
+    double dim[2];  /* RECT/SLIT: outer side lengths                                             */
+    double dimi[2]; /* SLIT: inner (open) side lengths                                           */
+    double angle;   /* RECT/SLIT: rotation about z [rad] (RectangularSurface._angle)             */
+    double R;       /* CONIC/ASPHERE: vertex radius of curvature                                 */
+    double k;       /* CONIC/ASPHERE: conic constant                                             */
+    double z_min;   /* absolute z range of the surface (Surface.z_min / z_max)                   */
+    double z_max;
+    double coeff[OT_MAX_ASPH]; /* ASPHERE: a2, a4, ... [mm^-1, mm^-3, ...]                         */
+} ot_surface;
+
+/* ---- media: RefractionIndex.__call__ refraction_index.py:62-169 ----------------------------- */
+#define OT_N_CONSTANT 0    /* c[0] = n                                                            */
+#define OT_N_ABBE 1        /* c = {A, B, d}: n = A + B/(wl2 - d)  (A, B solved on the host exactly
+                              as refraction_index.py:85-100 does, including its float32 line table) */
+#define OT_N_CAUCHY 2      /* :105 */
+#define OT_N_CONRADY 3     /* :101 */
+#define OT_N_SELLMEIER1 4  /* :108 */
+#define OT_N_SELLMEIER2 5  /* :111 */
+#define OT_N_SELLMEIER3 6  /* :114 */
+#define OT_N_SELLMEIER4 7  /* :117 */
+#define OT_N_SELLMEIER5 8  /* :120 */
+#define OT_N_SCHOTT 9      /* :124 */
+#define OT_N_HERZBERGER 10 /* :127 */
+#define OT_N_HOO1 11       /* "Handbook of Optics 1" :131 */
+#define OT_N_HOO2 12       /* "Handbook of Optics 2" :134 */
+#define OT_N_EXTENDED 13   /* :137 */
+#define OT_N_EXTENDED2 14  /* :141 */
+#define OT_N_EXTENDED3 15  /* :145 */
+#define OT_N_DATA 16       /* np.interp over an equally spaced table (spectrum.py:103-106), table
+                              = tab_len (wl, n) pairs at table_pool[tab_off ...]: first the tab_len
+                              wavelengths, then the tab_len values.  Also carries host-tabulated
+                              "Function" media.                                                     */
+#define OT_N_LINES 17      /* exact per-line values for discrete spectra: n = value[j] where
+                              wl == line[j] (same table layout as DATA); used for "Function" media
+                              under Monochromatic / Lines sources                                   */
+
+typedef struct ot_medium {
+    int32_t model; /* OT_N_* */
+    int32_t tab_len;
+    int64_t tab_off;
+    double c[10];
+} ot_medium;
+
+/* ---- filters: TransmissionSpectrum.__call__ transmission_spectrum.py:73-84 -------------------- */
+#define OT_T_CONSTANT 0  /* spectrum.py:99   */
+#define OT_T_DATA 1      /* spectrum.py:103  np.interp, 0 outside                                  */
+#define OT_T_RECTANGLE 2 /* spectrum.py:108  */
+#define OT_T_GAUSSIAN 3  /* spectrum.py:113  evaluated in float32 like the reference does for f32 wl */
+#define OT_T_LINES 4     /* host-tabulated per-line values ("Function" spectra, discrete sources)   */
+
+typedef struct ot_filter {
+    int32_t type;    /* OT_T_* */
+    int32_t inverse; /* TransmissionSpectrum.inverse: T -> 1 - T */
+    int32_t tab_len;
+    int32_t _pad;
+    int64_t tab_off;
+    double val, wl0, wl1, mu, sig;
+} ot_filter;
+
+/* ---- tracing elements: Raytracer.__tracing_elements raytracer.py:492-508 ----------------------- */
+#define OT_EL_LENS 0       /* Lens        raytracer.py:314-370 (two refracting surfaces)            */
+#define OT_EL_IDEAL_LENS 1 /* IdealLens   raytracer.py:360-363, 720-759                             */
+#define OT_EL_FILTER 2     /* Filter      raytracer.py:372-391                                      */
+#define OT_EL_APERTURE 3   /* Aperture    raytracer.py:372-391 (the invisible end aperture as well) */
+
+typedef struct ot_element {
+    int32_t kind;    /* OT_EL_*                                                                    */
+    int32_t front;   /* surface index                                                              */
+    int32_t back;    /* surface index (LENS) or -1                                                 */
+    int32_t n_lens;  /* LENS: medium index of the lens material                                    */
+    int32_t n_after; /* LENS / IDEAL_LENS: medium index behind the lens (n2 or n0, raytracer.py:326) */
+    int32_t filter;  /* FILTER: filter index                                                       */
+    int32_t hurb;    /* APERTURE: 1 = apply HURB edge bending here (raytracer.py:385)              */
+    int32_t _pad;
+    double D;        /* IDEAL_LENS: optical power [dpt]                                            */
+} ot_element;
+
+typedef struct ot_scene_desc {
+    double outline[6]; /* Raytracer.outline [x0,x1,y0,y1,z0,z1]                                      */
+    int32_t n_surfaces, n_elements, n_media, n_filters;
+    const ot_surface* surfaces;
+    const ot_element* elements; /* z-sorted; the last one must be the end aperture (raytracer.py:501) */
+    const ot_medium* media;
+    const ot_filter* filters;
+    const double* table_pool; /* shared table storage for DATA/LINES media and filters               */
+    int64_t table_pool_len;
+    int32_t n0;       /* ambient medium index (Raytracer.n0)                                         */
+    int32_t no_pol;   /* Raytracer.no_pol                                                            */
+    int32_t use_hurb; /* Raytracer.use_hurb                                                          */
+    int32_t _pad;
+    double hurb_factor; /* Raytracer.HURB_FACTOR raytracer.py:33                                     */
+} ot_scene_desc;
+
+typedef struct ot_scene ot_scene; /* opaque: device copy of the tables */
+
+/* ---- ray sources: RaySource.create_rays ray_source.py:204-437 --------------------------------- */
+#define OT_SRC_POINT 0  /* Point  point.py:62                                                       */
+#define OT_SRC_LINE 1   /* Line   line.py:81                                                        */
+#define OT_SRC_CIRCLE 2 /* CircularSurface.random_positions circular_surface.py:33                  */
+#define OT_SRC_RING 3   /* RingSurface.random_positions     ring_surface.py:135                     */
+#define OT_SRC_RECT 4   /* RectangularSurface.random_positions rectangular_surface.py:142           */
+#define OT_SRC_IMAGE_RGB 5  /* RGBImage: pixel pdf + sRGB primaries ray_source.py:233-258           */
+#define OT_SRC_IMAGE_GRAY 6 /* GrayscaleImage: pixel pdf, spectrum from `spectrum`                  */
+
+#define OT_DIV_NONE 0
+#define OT_DIV_LAMBERTIAN 1 /* ray_source.py:300-309 */
+#define OT_DIV_ISOTROPIC 2  /* ray_source.py:311-318 */
+#define OT_DIV_TABLE 3      /* "Function": host-tabulated pdf(theta), ray_source.py:320-333           */
+
+#define OT_OR_CONSTANT 0   /* ray_source.py:266 */
+#define OT_OR_CONVERGING 1 /* ray_source.py:269 */
+
+#define OT_POL_CONSTANT 0 /* also "x" (0) and "y" (pi/2), ray_source.py:366-376 */
+#define OT_POL_UNIFORM 1  /* :378 */
+#define OT_POL_LIST 2     /* "List" and "xy": discrete angles with probabilities :372, :381-385       */
+#define OT_POL_TABLE 3    /* "Function": host-tabulated pdf(angle) :387-392                          */
+
+#define OT_SPEC_MONO 0     /* light_spectrum.py:91  */
+#define OT_SPEC_UNIFORM 1  /* Constant / Rectangle: uniform in [wl0, wl1] :94-98                     */
+#define OT_SPEC_LINES 2    /* :100-103 discrete inverse CDF                                          */
+#define OT_SPEC_GAUSSIAN 3 /* :110-122 truncated normal via erfinv                                   */
+#define OT_SPEC_TABLE 4    /* Data / Blackbody / Function / Histogram: linear inverse CDF :105,:129   */
+
+typedef struct ot_source {
+    int32_t shape;       /* OT_SRC_*                                                                */
+    int32_t divergence;  /* OT_DIV_*                                                                */
+    int32_t div_2d;      /* RaySource.div_2d                                                        */
+    int32_t orientation; /* OT_OR_*                                                                 */
+    int32_t polarization; /* OT_POL_*                                                               */
+    int32_t spectrum;    /* OT_SPEC_*                                                               */
+    int32_t img_w, img_h; /* IMAGE_*: pixel counts                                                  */
+    double pos[3];
+    double r, ri;        /* LINE: half length r; CIRCLE/RING radii                                  */
+    double dim[2];       /* RECT / IMAGE side lengths                                               */
+    double angle;        /* RECT rotation [rad]; LINE angle [rad]                                   */
+    double div_angle;    /* [deg]                                                                   */
+    double div_axis_angle; /* [deg]                                                                 */
+    double s[3];         /* unit orientation (CONSTANT)                                             */
+    double conv_pos[3];  /* CONVERGING                                                              */
+    double pol_angle;    /* [rad] for POL_CONSTANT                                                  */
+    double wl, wl0, wl1, mu, sig;
+    double power;        /* power carried by THIS bundle of n rays (ray_storage.py:160)             */
+    /* tables (device copies made by ot_sources_create); layouts:
+     *   spec_tab : LINES: n_spec lines (as the reference's float32 values upcast) then n_spec weights;
+     *              TABLE: n_spec wavelengths then n_spec pdf values
+     *   pol_tab  : LIST: n_pol angles [rad] then n_pol probabilities; TABLE: n_pol angles then pdf
+     *   div_tab  : TABLE: n_div thetas [rad] then n_div pdf values
+     *   img_pdf  : IMAGE_*: img_w*img_h relative pixel powers (RaySource._pIf)
+     *   img_rgb  : IMAGE_RGB: img_w*img_h*3 sRGB values in [0,1], row-major (y, x, c)              */
+    const double* spec_tab; int64_t n_spec;
+    const double* pol_tab;  int64_t n_pol;
+    const double* div_tab;  int64_t n_div;
+    const double* img_pdf;
+    const double* img_rgb;
+} ot_source;
+
+/* A contiguous block of rays generated from one source: rays [first, first+count) of the launch. */
+typedef struct ot_source_range {
+    int32_t source;  /* index into the source table                                                 */
+    int32_t _pad;
+    int64_t first;   /* first ray index inside this launch                                          */
+    int64_t count;   /* number of rays (stratification domain, ray_storage.py:160-163)              */
+} ot_source_range;
+
+typedef struct ot_sources ot_sources; /* opaque: device copy of sources + tables */
+
+/* ---- ray storage: RayStorage ray_storage.py:35-90 --------------------------------------------- */
+typedef struct ot_rays {
+    int64_t N;   /* rays in this launch                                                            */
+    int32_t nt;  /* sections per ray = n tracing surfaces + 2 (raytracer.py:278)                   */
+    int32_t _pad;
+    double* p;   /* (N, nt, 3) f64 F-order  p_list                                                 */
+    double* s;   /* (N, 3)     f64 F-order  s0_list: in = initial, out = final direction           */
+    float* w;    /* (N, nt)    f32 F-order  w_list                                                 */
+    double* n;   /* (N, nt)    f64 F-order  n_list                                                 */
+    float* wl;   /* (N,)       f32          wl_list                                                */
+    float* pol;  /* (N, nt, 3) f32 F-order  pol_list; NULL when no_pol                             */
+} ot_rays;
+
+/* ---- library --------------------------------------------------------------------------------- */
+int ot_abi_version(void);
+const char* ot_last_error(void);
+/* number of HIP devices visible; negative on error */
+int ot_device_count(void);
+
+/* ---- scene ------------------------------------------------------------------------------------ */
+/* Validates and uploads the scene tables (replaces nothing 1:1 -- the reference walks Python objects,
+ * raytracer.py:274, 492-508).  Synchronous. */
+int ot_scene_create(const ot_scene_desc* desc, ot_scene** out);
+void ot_scene_destroy(ot_scene* scene);
+/* nt = number of tracing surfaces + 2 (raytracer.py:278) */
+int ot_scene_sections(const ot_scene* scene);
+
+/* ---- sources ---------------------------------------------------------------------------------- */
+int ot_sources_create(const ot_source* sources, int32_t n_sources, ot_sources** out);
+void ot_sources_destroy(ot_sources* src);
+
+/* RaySource.create_rays (ray_source.py:204) for every range, writing section 0 of `rays`
+ * (p[:,0], s, w[:,0], wl, pol[:,0]) the way RayStorage.thread_rays does (ray_storage.py:156-166).
+ * Device RNG: counter-based (Philox-4x32-10) keyed by (seed, range, ray); stratified grids use a
+ * keyed bijective index permutation instead of the reference's shuffle (random.py:39-43). */
+int ot_rays_generate(const ot_sources* src, const ot_source_range* ranges, int32_t n_ranges,
+                     uint64_t seed, int32_t no_pol, const ot_rays* rays, void* stream);
+
+/* ---- tracing ---------------------------------------------------------------------------------- */
+/* Raytracer.trace / sub_trace (raytracer.py:262-415) for rays whose section 0 is already in `rays`
+ * (injected or produced by ot_rays_generate).  Fills sections 1..nt-1 of p/w/n/pol, n[:,0], the
+ * final directions in rays->s and ADDS the per-section counters to msgs (device, int64[5*nt],
+ * row-major (info, section)).  hurb_normals: optional device array (2*n_hurb_elements*N f64:
+ * for the j-th HURB aperture, N standard-normal draws for the a axis then N for the b axis,
+ * replacing np.random.normal raytracer.py:468-469); NULL = device RNG keyed by `seed`. */
+int ot_trace(const ot_scene* scene, const ot_rays* rays, const double* hurb_normals, uint64_t seed,
+             int64_t* msgs, void* stream);
+
+/* Fused generation + trace: same result as ot_rays_generate followed by ot_trace, but the freshly
+ * generated ray never makes a round trip through HBM (one launch, ray state in registers). */
+int ot_generate_and_trace(const ot_scene* scene, const ot_sources* src,
+                          const ot_source_range* ranges, int32_t n_ranges, uint64_t seed,
+                          const ot_rays* rays, int64_t* msgs, void* stream);
+
+/* ---- leaf operators (public Surface / RefractionIndex methods) ---------------------------------- */
+/* Surface.find_hit (surface.py:307, conic_surface.py:126): p, s are (n,3) F-order device arrays;
+ * outputs p_hit (n,3) F-order, is_hit (n) uint8, ill (n) uint8 (all zero for analytic surfaces). */
+int ot_surface_find_hit(const ot_surface* surf, int64_t n, const double* p, const double* s,
+                        double* p_hit, uint8_t* is_hit, uint8_t* ill, void* stream);
+/* Surface.normals (surface.py:247, conic_surface.py:70, function_surface_2d.py:202): out (n,3) F-order */
+int ot_surface_normals(const ot_surface* surf, int64_t n, const double* x, const double* y,
+                       double* normals, void* stream);
+/* Surface.mask (surface.py:235, ring_surface.py:123, rectangular_surface.py:100, slit_surface.py:89) */
+int ot_surface_mask(const ot_surface* surf, int64_t n, const double* x, const double* y,
+                    uint8_t* mask, void* stream);
+/* Surface.values (surface.py:137) */
+int ot_surface_values(const ot_surface* surf, int64_t n, const double* x, const double* y,
+                      double* z, void* stream);
+/* RingSurface.hurb_props / SlitSurface.hurb_props (ring_surface.py:88, slit_surface.py:65):
+ * a_, b_ (n), b (n,3) F-order, inside (n) uint8 */
+int ot_surface_hurb_props(const ot_surface* surf, int64_t n, const double* x, const double* y,
+                          double* a_, double* b_, double* b, uint8_t* inside, void* stream);
+/* RefractionIndex.__call__ (refraction_index.py:62): wl f32 device array as stored in RayStorage */
+int ot_refraction_index(const ot_medium* medium, const double* table_pool, int64_t table_pool_len,
+                        int64_t n, const float* wl, double* out, void* stream);
+
+/* ---- detector --------------------------------------------------------------------------------- */
+#define OT_PROJ_NONE 0          /* flat detector or projection_method=None                           */
+#define OT_PROJ_EQUIDISTANT 1   /* spherical_surface.py:64                                          */
+#define OT_PROJ_ORTHOGRAPHIC 2  /* :50                                                              */
+#define OT_PROJ_EQUAL_AREA 3    /* :87                                                              */
+#define OT_PROJ_STEREOGRAPHIC 4 /* :75                                                              */
+
+/* Raytracer._hit_detector (raytracer.py:881-1051) over rays [first, first+count): for every ray
+ * the section straddling the detector is searched, the detector surface is intersected with the
+ * direction re-derived from stored positions (ray_storage.py:274-279), hits beyond the section end
+ * are retried on the next section, and the optional sphere projection is applied.
+ * Outputs are dense per-ray arrays (count entries): ph (count,3) F-order projected hit, hw f32 weight
+ * (0 = no valid hit; the reference drops those rows, raytracer.py:1023), and ill_count (device
+ * int64, ADDED to).  extent4 (device f64[4], may be NULL): running xmin,xmax,ymin,ymax of valid hits
+ * (raytracer.py:1044-1046), must be initialised by the caller to +inf,-inf,+inf,-inf. */
+int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
+                     int32_t projection, double* ph, float* hw, double* extent4, int64_t* ill_count,
+                     void* stream);
+
+/* SphericalSurface.sphere_projection (spherical_surface.py:36-97): p (n,3) F-order -> out (n,3) F-order */
+int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, const double* p, double* out,
+                         void* stream);
+
+/* RenderImage.render inner part (render_image.py:396-418 + misc.binning_indices_2d misc.py:59-91 +
+ * color.x/y/z_observer observers.py:14-41): bins n hits into hist (Ny, Nx, 4) f64 device array,
+ * ADDING w*[xbar(wl), ybar(wl), zbar(wl), 1].  extent = [x0,x1,y0,y1] after RenderImage.__fix_extent.
+ * Rays with w == 0 are skipped (they add nothing in the reference either). */
+int ot_render_accumulate(int64_t n, const double* px, const double* py, const float* w,
+                         const float* wl, const double extent[4], int32_t Nx, int32_t Ny,
+                         double* hist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPTRACE_AMD_H */

@@ -1,0 +1,40 @@
+"""Device plumbing: torch owns HBM allocations and streams, the C-ABI gets raw pointers."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+def require_device() -> torch.device:
+    """cuda:<current> or a loud failure -- the product path has no CPU fallback."""
+    if not torch.cuda.is_available():
+        raise _capi.BackendError("No HIP device available (torch.cuda.is_available() is False); "
+                                 "optrace_amd has no CPU fallback.")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def to_dev(a: np.ndarray, dtype) -> torch.Tensor:
+    """Copy a host array to the device as a flat contiguous tensor."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype).reshape(-1)).to(require_device())
+
+
+def f_order_flat(a: np.ndarray, dtype=np.float64) -> np.ndarray:
+    """(n, 3) array -> flat component-major buffer (the reference's Fortran order)."""
+    return np.ascontiguousarray(np.asarray(a, dtype=dtype).T).reshape(-1)
+
+
+def from_f_order(t: torch.Tensor, n: int, ncomp: int) -> np.ndarray:
+    """flat component-major device buffer -> (n, ncomp) F-ordered host array."""
+    return t.cpu().numpy().reshape(ncomp, n).T

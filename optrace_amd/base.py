@@ -1,0 +1,94 @@
+"""Common parent of all geometry / spectrum classes (mirrors optrace/tracer/base_class.py:11-114)."""
+from __future__ import annotations
+
+import copy
+from typing import Any
+
+import numpy as np
+
+
+def check_type(key: str, val: Any, types) -> None:
+    """TypeError in the reference's wording (property_checker.py:2-14) if `val` has the wrong type."""
+    if isinstance(val, bool) and types in (float, int, (int, float), (float, int)):
+        raise TypeError(f"Property '{key}' needs to be of type(s) {types}, but is bool.")
+    if not isinstance(val, types):
+        raise TypeError(f"Property '{key}' needs to be of type(s) {types}, but is {type(val).__name__}.")
+
+
+def check_above(key: str, val, bound) -> None:
+    if val <= bound:
+        raise ValueError(f"Property '{key}' needs to be above {bound}, but is {val}.")
+
+
+def check_not_below(key: str, val, bound) -> None:
+    if val < bound:
+        raise ValueError(f"Property '{key}' needs to be at least {bound}, but is {val}.")
+
+
+def check_not_above(key: str, val, bound) -> None:
+    if val > bound:
+        raise ValueError(f"Property '{key}' needs to be at most {bound}, but is {val}.")
+
+
+def check_in(key: str, val, choices) -> None:
+    if val not in choices:
+        raise ValueError(f"Property '{key}' needs to be one of {choices}, but is '{val}'.")
+
+
+class BaseClass:
+    """Description strings, copy, read-only locking and a compact state representation."""
+
+    def __init__(self, desc: str = "", long_desc: str = "") -> None:
+        self._lock = False
+        self._new_lock = False
+        self.desc = desc
+        self.long_desc = long_desc
+
+    def crepr(self) -> list:
+        """State as nested tuples; used to detect geometry changes since the last trace."""
+        out = []
+        for val in self.__dict__.values():
+            if isinstance(val, BaseClass):
+                out.append(val.crepr())
+            elif isinstance(val, np.ndarray):
+                out.append(tuple(val.flat) if val.size < 20 else id(val))
+            elif callable(val):
+                out.append(id(val))
+            elif isinstance(val, list):
+                out.append(tuple(val))
+            else:
+                out.append(val)
+        return out
+
+    def get_desc(self, fallback: str = "") -> str:
+        return self.desc if self.desc != "" else fallback
+
+    def get_long_desc(self, fallback: str = "") -> str:
+        return self.long_desc if self.long_desc != "" else self.get_desc(fallback)
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def lock(self) -> None:
+        """Make the object (and its arrays) read-only."""
+        for val in self.__dict__.values():
+            if isinstance(val, np.ndarray):
+                val.flags.writeable = False
+        self._lock = True
+        self._new_lock = True
+
+    def __str__(self) -> str:
+        d = {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
+        return f"{type(self).__name__} at {hex(id(self))} with {d}"
+
+    def __setattr__(self, key: str, val: Any) -> None:
+        if key not in ("_lock", "_new_lock"):
+            d = self.__dict__
+            if d.get("_new_lock", False) and not (key in d or hasattr(type(self), key)):
+                raise AttributeError(f"Failed to set invalid/unknown property {key}.")
+            if d.get("_lock", False) and key not in ("desc", "long_desc"):
+                raise RuntimeError("Object is currently read-only. Create a new object with new properties "
+                                   "or use class methods to change its properties.")
+        if key in ("desc", "long_desc"):
+            check_type(key, val, str)
+        self.__dict__[key] = val

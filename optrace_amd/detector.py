@@ -1,0 +1,40 @@
+"""Detector stage on the GPU: section search, detector intersection, sphere projection.
+
+Device implementation of Raytracer._hit_detector (raytracer.py:881-1051) through `ot_detector_hits`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._device import require_device, stream_ptr, ptr, to_dev, f_order_flat, from_f_order
+
+
+def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projection: int, want_extent: bool):
+    """-> (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count)."""
+    lib = _capi.load_library()
+    dev = require_device()
+    ph = torch.empty(3 * count, dtype=torch.float64, device=dev)
+    hw = torch.empty(count, dtype=torch.float32, device=dev)
+    ill = torch.zeros(1, dtype=torch.int64, device=dev)
+    ext = None
+    if want_extent:
+        ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float64, device=dev)
+    rs = rays._rays_struct()
+    _capi.check(lib.ot_detector_hits(C.byref(rs), int(first), int(count), C.byref(surf_desc), int(projection),
+                                     ptr(ph), ptr(hw), ptr(ext), ptr(ill), stream_ptr()))
+    return ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill.item())
+
+
+def project_points(surf_desc: _capi.Surface, p: np.ndarray, projection: int) -> np.ndarray:
+    """SphericalSurface.sphere_projection (spherical_surface.py:36-97) via `ot_sphere_projection`."""
+    lib = _capi.load_library()
+    dev = require_device()
+    n = int(np.shape(p)[0])
+    dp = to_dev(f_order_flat(p), np.float64)
+    out = torch.empty(3 * n, dtype=torch.float64, device=dev)
+    _capi.check(lib.ot_sphere_projection(C.byref(surf_desc), int(projection), n, ptr(dp), ptr(out), stream_ptr()))
+    return from_f_order(out, n, 3).copy()

@@ -1,0 +1,129 @@
+"""Image containers used as light sources, and the sRGB helpers the image source needs.
+
+Mirror of the parts of optrace/tracer/image/{base_image,rgb_image,grayscale_image}.py and
+optrace/tracer/color/srgb.py that feed `RaySource.create_rays` (ray_source.py:120-146, 233-258).
+Only array input is supported (file decoding needs OpenCV, which is not part of this stack).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .base import BaseClass, check_type, check_above
+
+# relative powers of the three sRGB primary spectra (color/srgb.py:24-26)
+SRGB_PRIMARY_POWER_FACTORS = [0.885651229244, 1.000000000000, 0.775993481741]
+
+_WL_MIN0, _WL_MAX0 = 380., 780.
+
+
+def srgb_to_srgb_linear(rgb: np.ndarray) -> np.ndarray:
+    """Remove the sRGB gamma (color/srgb.py:30-47)."""
+    a = 0.055
+    below = np.abs(rgb) <= 0.04045
+    lin = np.sign(rgb) * (1 / (1 + a) * (np.abs(rgb) + a)) ** 2.4
+    lin[below] = 1 / 12.92 * rgb[below]
+    return lin
+
+
+def power_from_srgb_linear(rgbl: np.ndarray) -> np.ndarray:
+    """Relative pixel power under the primary spectra below (color/srgb.py:556-565)."""
+    f = SRGB_PRIMARY_POWER_FACTORS
+    return f[0] * rgbl[:, :, 0] + f[1] * rgbl[:, :, 1] + f[2] * rgbl[:, :, 2]
+
+
+def _gauss(x, mu, sig):
+    return 1 / (sig * np.sqrt(2 * np.pi)) * np.exp(-0.5 / sig ** 2 * (x - mu) ** 2)
+
+
+def srgb_r_primary(wl: np.ndarray) -> np.ndarray:
+    """Spectrum with the chromaticity of the sRGB red primary (color/srgb.py:469-481)."""
+    r = 75.1660756583 * 0.951190393 * (_gauss(wl, 639.854491, 30.0) + 0.0500907584 * _gauss(wl, 418.905848, 80.6220465))
+    r[~((wl >= _WL_MIN0) & (wl <= _WL_MAX0))] = 0
+    return r
+
+
+def srgb_g_primary(wl: np.ndarray) -> np.ndarray:
+    """color/srgb.py:484-495"""
+    g = 83.4999222966 * 1 * _gauss(wl, 539.13108974, 33.31164968)
+    g[~((wl >= _WL_MIN0) & (wl <= _WL_MAX0))] = 0
+    return g
+
+
+def srgb_b_primary(wl: np.ndarray) -> np.ndarray:
+    """color/srgb.py:498-509"""
+    b = 47.99521746361 * 1.16364585503 * (_gauss(wl, 454.833119, 20.1460206) + 0.184484176 * _gauss(wl, 459.658190, 71.0927568))
+    b[~((wl >= _WL_MIN0) & (wl <= _WL_MAX0))] = 0
+    return b
+
+
+class _BaseImage(BaseClass):
+    """Array plus geometric extent; element [0, 0] is the lower left corner (base_image.py:14-140)."""
+
+    _channels = 3
+
+    def __init__(self, data: np.ndarray, s=None, extent=None, quantity: str = "", projection: str = None,
+                 limit: float = None, **kwargs) -> None:
+        self._new_lock = False
+        if isinstance(data, str):
+            raise NotImplementedError("Loading image files needs OpenCV; pass a numpy array instead.")
+        self._data = data
+        if extent is None and s is None:
+            raise ValueError("Either s or extent need to be provided for Images")
+        if extent is None:
+            check_type("s", s, (list, tuple, np.ndarray))
+            s2 = np.asarray_chkfinite(s, dtype=np.float64)
+            if s2.shape[0] != 2:
+                raise ValueError("s needs to have 2 elements.")
+            check_above("s[0]", s2[0], 0)
+            check_above("s[1]", s2[1], 0)
+            self.extent = [-s2[0] / 2, s2[0] / 2, -s2[1] / 2, s2[1] / 2]
+        else:
+            self.extent = extent
+        self.quantity = quantity
+        self.projection = projection
+        self.limit = limit
+        super().__init__(**kwargs)
+        self._new_lock = True
+
+    @property
+    def shape(self):
+        return self._data.shape
+
+    @property
+    def data(self) -> np.ndarray:
+        return self._data.copy()
+
+    @property
+    def s(self) -> list:
+        return [float(self.extent[1] - self.extent[0]), float(self.extent[3] - self.extent[2])]
+
+    @property
+    def Apx(self) -> float:
+        return float(self.s[0] * self.s[1] / (self.shape[1] * self.shape[0]))
+
+    def __setattr__(self, key, val):
+        if key == "_data":
+            check_type(key, val, np.ndarray)
+            val = np.asarray_chkfinite(val, dtype=np.float64)
+            if self._channels == 3 and (val.ndim != 3 or val.shape[2] != 3):
+                raise TypeError("Image data needs to have three dimensions with three channels")
+            if self._channels == 1 and val.ndim != 2:
+                raise TypeError("Image data needs to have two dimensions")
+            if val.min() < 0 or val.max() > 1:
+                raise ValueError("Image values need to be inside range [0, 1]")
+        elif key == "extent":
+            check_type(key, val, (list, np.ndarray))
+            val = np.asarray_chkfinite(val, dtype=np.float64)
+            if val.shape[0] != 4 or val[0] >= val[1] or val[2] >= val[3]:
+                raise ValueError("extent needs to be [x0, x1, y0, y1] with x1 > x0, y1 > y0")
+        super().__setattr__(key, val)
+
+
+class RGBImage(_BaseImage):
+    """sRGB image with values in [0, 1] (rgb_image.py:12-75)."""
+    _channels = 3
+
+
+class GrayscaleImage(_BaseImage):
+    """sRGB-gamma grayscale image with values in [0, 1] (grayscale_image.py:10-60)."""
+    _channels = 1

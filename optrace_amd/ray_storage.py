@@ -1,0 +1,252 @@
+"""RayStorage: all ray sections of a trace, resident in HBM.
+
+Mirror of optrace/tracer/ray_storage.py:11-293.  The arrays keep the reference's shapes, dtypes and
+Fortran (struct-of-arrays) order -- p_list (N, nt, 3) f64, s0_list (N, 3) f64, w_list (N, nt) f32,
+n_list (N, nt) f64, wl_list (N,) f32, pol_list (N, nt, 3) f32 -- but live in device memory
+(torch tensors); the NumPy attributes of the reference API are read-only host copies made on first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .base import BaseClass
+from ._device import require_device, stream_ptr, ptr
+from ._warn import warning
+from . import misc
+
+
+class SourceTable:
+    """Device copy of the `ot_source` table of a list of RaySources (handle from ot_sources_create)."""
+
+    _ptr_fields = ("spec_tab", "pol_tab", "div_tab", "img_pdf", "img_rgb")
+
+    def __init__(self, sources: list, powers: list) -> None:
+        lib = _capi.load_library()
+        require_device()
+        self._keep = []
+        arr = (_capi.Source * len(sources))()
+        for j, (rs, power) in enumerate(zip(sources, powers)):
+            f = rs._source_fields()
+            s = arr[j]
+            for key, val in f.items():
+                if key in self._ptr_fields:
+                    a = np.ascontiguousarray(val, dtype=np.float64)
+                    self._keep.append(a)
+                    setattr(s, key, a.ctypes.data_as(C.POINTER(C.c_double)))
+                elif isinstance(val, list):
+                    getattr(s, key)[:] = val
+                else:
+                    setattr(s, key, val)
+            s.power = float(power)
+        self.handle = C.c_void_p()
+        _capi.check(lib.ot_sources_create(arr, len(sources), C.byref(self.handle)))
+        self._lib = lib
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self._lib.ot_sources_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class RayStorage(BaseClass):
+
+    def __init__(self, **kwargs) -> None:
+        self._lock = False
+        self.N_list = np.array([], dtype=int)
+        self.B_list = np.array([], dtype=int)
+        self.no_pol = False
+        self.ray_source_list = []
+        self._N = 0
+        self._nt = 0
+        self._dev = {}    # name -> torch tensor (flat, component-major)
+        self._host = {}   # name -> cached read-only numpy view
+        self._powers = []
+        super().__init__(**kwargs)
+
+    # ---- allocation (ray_storage.py:35-90) ---------------------------------------------------------
+    def init(self, ray_source_list: list, N: int, nt: int, no_pol: bool, _single_power: float = None) -> None:
+        self._lock = False
+        self.no_pol = no_pol
+        assert N >= 0 and nt >= 0 and len(ray_source_list)
+        dev = require_device()
+
+        # rays per source proportional to power, remainder drawn with the powers as probabilities
+        P_list = np.array([RS.power for RS in ray_source_list])
+        P_all = np.sum(P_list)
+        self.N_list = (N * P_list / P_all).astype(int)
+        dN = N - np.sum(self.N_list)
+        index_add = np.random.choice(self.N_list.shape[0], size=dN, p=P_list / P_all)
+        np.add.at(self.N_list, index_add, np.ones(index_add.shape))
+        if np.any(self.N_list == 0):
+            warning("There are RaySources that have no rays assigned. "
+                    "Change the power ratio or raise the overall ray number")
+        self.B_list = np.concatenate(([0], np.cumsum(self.N_list))).astype(int)
+        self.ray_source_list = ray_source_list
+        self._powers = [float(_single_power or RS.power) for RS in ray_source_list]
+
+        self._N, self._nt = int(N), int(nt)
+        self._host = {}
+        self._dev = {
+            "p": torch.empty(3 * nt * N, dtype=torch.float64, device=dev),
+            "s": torch.empty(3 * N, dtype=torch.float64, device=dev),
+            "w": torch.empty(nt * N, dtype=torch.float32, device=dev),
+            "n": torch.empty(nt * N, dtype=torch.float64, device=dev),
+            "wl": torch.empty(N, dtype=torch.float32, device=dev),
+            "pol": None if no_pol else torch.empty(3 * nt * N, dtype=torch.float32, device=dev),
+        }
+
+    @staticmethod
+    def storage_size(N: int, nt: int, no_pol: bool) -> int:
+        """Bytes needed for N rays with nt sections (ray_storage.py:92-104)."""
+        f32, f64 = 4, 8
+        fpol = f32 * N * nt * 3 if not no_pol else f64
+        return N * nt * 3 * f64 + N * 3 * f64 + fpol + N * nt * f32 + N * nt * f64 + N * f32
+
+    @staticmethod
+    def max_rays_for_size(size: int, nt: int, no_pol: bool) -> int:
+        f32, f64 = 4, 8
+        if no_pol:
+            return (size - f64) // (nt * 3 * f64 + 3 * f64 + nt * f32 + nt * f64 + f32)
+        return size // (nt * 3 * f64 + 3 * f64 + f32 * nt * 3 + nt * f32 + nt * f64 + f32)
+
+    @property
+    def N(self) -> int:
+        return self._N if self.N_list.shape[0] else 0
+
+    @property
+    def Nt(self) -> int:
+        return self._nt if self.N_list.shape[0] else 0
+
+    # ---- device side --------------------------------------------------------------------------------
+    def _rays_struct(self) -> _capi.Rays:
+        d = self._dev
+        r = _capi.Rays()
+        r.N, r.nt = self._N, self._nt
+        r.p, r.s, r.w, r.n, r.wl = (d["p"].data_ptr(), d["s"].data_ptr(), d["w"].data_ptr(),
+                                    d["n"].data_ptr(), d["wl"].data_ptr())
+        r.pol = d["pol"].data_ptr() if d["pol"] is not None else None
+        return r
+
+    def _source_ranges(self):
+        """One stratification range per source (what RayStorage.thread_rays does for one thread,
+        ray_storage.py:147-166)."""
+        rng = (_capi.SourceRange * len(self.N_list))()
+        for i in range(len(self.N_list)):
+            rng[i].source = i
+            rng[i].first = int(self.B_list[i])
+            rng[i].count = int(self.N_list[i])
+        return rng
+
+    def _source_table(self) -> SourceTable:
+        return SourceTable(self.ray_source_list, self._powers)
+
+    def generate(self, seed: int | None) -> None:
+        """Fill section 0 from the sources (RaySource.create_rays on the device)."""
+        lib = _capi.load_library()
+        seed = int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
+        tab = self._source_table()
+        rng = self._source_ranges()
+        rays = self._rays_struct()
+        _capi.check(lib.ot_rays_generate(tab.handle, rng, len(rng), seed, int(self.no_pol), C.byref(rays),
+                                         stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+        self._host.clear()
+
+    def set_initial_rays(self, p, s, pols, w, wl) -> None:
+        """Inject section 0 from host arrays (used for parity runs against recorded reference rays)."""
+        N, nt, dev = self._N, self._nt, require_device()
+        d = self._dev
+        p = np.asarray(p, dtype=np.float64)
+        for c in range(3):
+            d["p"][c * nt * N: c * nt * N + N] = torch.from_numpy(np.ascontiguousarray(p[:, c])).to(dev)
+            d["s"][c * N:(c + 1) * N] = torch.from_numpy(np.ascontiguousarray(np.asarray(s, dtype=np.float64)[:, c])).to(dev)
+            if d["pol"] is not None:
+                d["pol"][c * nt * N: c * nt * N + N] = torch.from_numpy(
+                    np.ascontiguousarray(np.asarray(pols)[:, c], dtype=np.float32)).to(dev)
+        d["w"][:N] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(dev)
+        d["wl"][:] = torch.from_numpy(np.ascontiguousarray(wl, dtype=np.float32)).to(dev)
+        self._host.clear()
+
+    # ---- host views (reference attribute API) --------------------------------------------------------
+    def _view(self, name: str) -> np.ndarray:
+        if name not in self._host:
+            N, nt = self._N, self._nt
+            t = self._dev.get(name)
+            if name == "pol" and t is None:
+                a = np.broadcast_to(np.nan, (N, nt, 3))
+            elif t is None:
+                a = np.array([])
+            else:
+                h = t.cpu().numpy()
+                shape = {"p": (3, nt, N), "pol": (3, nt, N), "s": (3, N), "w": (nt, N), "n": (nt, N), "wl": (N,)}[name]
+                a = h.reshape(shape).transpose(*reversed(range(len(shape))))  # F-ordered (N, nt, 3) view
+                a.flags.writeable = False
+            self._host[name] = a
+        return self._host[name]
+
+    p_list = property(lambda self: self._view("p"))
+    s0_list = property(lambda self: self._view("s"))
+    w_list = property(lambda self: self._view("w"))
+    n_list = property(lambda self: self._view("n"))
+    wl_list = property(lambda self: self._view("wl"))
+    pol_list = property(lambda self: self._view("pol"))
+
+    def lock(self) -> None:
+        self._lock = True
+        self._new_lock = True
+
+    def source_sections(self, index: int = None):
+        assert self.N, "ray_source_list has no rays stored."
+        assert index is None or 0 <= index < len(self.N_list)
+        Ns, Ne = self.B_list[index:index + 2] if index is not None else (0, self.N)
+        return (self.p_list[Ns:Ne, 0], self.s0_list[Ns:Ne], self.pol_list[Ns:Ne, 0],
+                self.w_list[Ns:Ne, 0], self.wl_list[Ns:Ne])
+
+    def ray_lengths(self, ch=None, ch2=None) -> np.ndarray:
+        _, s, _, _, _, _, _ = self.rays_by_mask(ch, ch2, ret=[0, 1, 0, 0, 0, 0, 0], normalize=False)
+        return np.linalg.norm(s, axis=s.ndim - 1)
+
+    def optical_lengths(self, ch=None, ch2=None) -> np.ndarray:
+        _, s, _, _, _, _, n = self.rays_by_mask(ch, ch2, ret=[0, 1, 0, 0, 0, 0, 1], normalize=False)
+        return np.linalg.norm(s, axis=s.ndim - 1) * n
+
+    def source_numbers(self) -> np.ndarray:
+        return self.rays_by_mask(ret=[0, 0, 0, 0, 0, 1, 0])[5]
+
+    def direction_vectors(self, normalize: bool = True) -> np.ndarray:
+        return self.rays_by_mask(ret=[0, 1, 0, 0, 0, 0, 0], normalize=normalize)[1]
+
+    def rays_by_mask(self, ch=None, ch2=None, ret=None, normalize: bool = True):
+        """Properties of selected rays / sections (ray_storage.py:235-293): (p, s, pol, w, wl, snum, n).
+        Post-processing helper on the host copies; the tracing and detector kernels never call it."""
+        assert self.N, "ray_source_list has no rays stored."
+        ret = [1, 1, 1, 1, 1, 1, 1] if ret is None else ret
+        ch = np.ones(self.N, dtype=bool) if ch is None else ch
+        ch2 = slice(None) if ch2 is None else ch2
+        assert ch.shape[0] == self.N
+
+        snums = s = None
+        if ret[5]:
+            ind = np.nonzero(ch)[0]
+            snums = np.zeros_like(ind, dtype=int)
+            for i, _ in enumerate(self.N_list):
+                Ns, Ne = self.B_list[i:i + 2]
+                snums[(Ns <= ind) & (ind < Ne)] = i
+        if ret[1]:
+            if not isinstance(ch2, slice):
+                ch21 = np.where(ch2 < self.Nt - 1, ch2 + 1, ch2)
+                s = self.p_list[ch, ch21] - self.p_list[ch, ch2]
+                if normalize:
+                    s = misc.normalize(s)
+            else:
+                s = self.p_list[ch, 1:] - self.p_list[ch, :-1]
+                s = np.hstack((s, np.zeros((s.shape[0], 1, 3), order='F', dtype=np.float64)))
+                if normalize:
+                    s = misc.normalize(s.reshape((s.shape[0] * s.shape[1], 3))).reshape(s.shape)
+        return (self.p_list[ch, ch2] if ret[0] else None, s if ret[1] else None,
+                self.pol_list[ch, ch2] if ret[2] else None, self.w_list[ch, ch2] if ret[3] else None,
+                self.wl_list[ch] if ret[4] else None, snums, self.n_list[ch, ch2] if ret[6] else None)

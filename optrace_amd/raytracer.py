@@ -1,0 +1,462 @@
+"""Raytracer: sequential tracing of a scene on one MI355X (or one per rank).
+
+Mirror of optrace/tracer/raytracer.py:28-1279 for the hot path named in BASELINE.json:
+`trace` (ray generation, all surface interactions, section stores, counters), `detector_image`
+(detector hit search + binning) and `iterative_render`.  The object keeps the reference's API; the work
+happens in HIP kernels reached through the C-ABI (include/optrace_amd.h):
+
+    trace(N)          -> ot_generate_and_trace   (one fused launch: generation + every surface)
+    detector_image()  -> ot_detector_hits + ot_render_accumulate
+
+Geometry validation (element order, collisions) is one-off host work per trace and stays in NumPy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from enum import IntEnum
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import _capi
+from .base import check_type
+from .geometry.elements import Group, Lens, Filter, Aperture, Detector
+from .geometry.surfaces import (Surface, Point, Line, RectangularSurface, SphericalSurface, RingSurface,
+                                SlitSurface)
+from .options import global_options
+from .ray_storage import RayStorage
+from .refraction_index import RefractionIndex
+from .render_image import RenderImage
+from .scene import CompiledScene, tracing_elements
+from ._device import require_device, stream_ptr, ptr
+from ._warn import warning
+from . import detector as _detector
+
+
+class Raytracer(Group):
+
+    N_EPS: float = 1e-11
+    HURB_FACTOR: float = 2 ** 0.5
+    MAX_RAY_STORAGE_RAM: int = 200_000_000_000
+    """Upper bound for the ray storage of one trace.  The reference guards host RAM with 6 GB
+    (raytracer.py:37); here the storage lives in the 288 GB of HBM3E of one MI355X."""
+    ITER_RAYS_STEP: int = 1000000
+
+    class INFOS(IntEnum):
+        ABSORB_MISSING = 0
+        TIR = 1
+        ILL_COND = 2
+        OUTLINE_INTERSECTION = 3
+        HURB_NEG_DIR = 4
+
+    def __init__(self, outline, n0: RefractionIndex = None, no_pol: bool = False, use_hurb: bool = False,
+                 seed: int = None, **kwargs) -> None:
+        self.outline = outline
+        self.no_pol = no_pol
+        self.use_hurb = use_hurb
+        self.seed = seed  #: base seed of the device RNG (None: drawn from numpy's global RNG per trace)
+        self.rays = RayStorage()
+        self._msgs = np.array([])
+        self._ignore_geometry_error = False
+        self.geometry_error = False
+        self._last_trace_snapshot = None
+        self.fault_pos = np.array([])
+        self._scene = None
+        self._scene_handle = None
+        super().__init__(None, n0, **kwargs)
+        self._new_lock = True
+
+    def __setattr__(self, key: str, val: Any) -> None:
+        if key == "outline":
+            check_type(key, val, (list, np.ndarray))
+            o = np.asarray_chkfinite(val, dtype=np.float64)
+            if o.shape[0] != 6 or o[0] >= o[1] or o[2] >= o[3] or o[4] >= o[5]:
+                raise ValueError("Outline needs to be specified as [x1, x2, y1, y2, z1, z2] "
+                                 "with x2 > x1, y2 > y1, z2 > z1.")
+            val = o
+        elif key in ("no_pol", "use_hurb"):
+            check_type(key, val, bool)
+        super().__setattr__(key, val)
+
+    @property
+    def extent(self):
+        return tuple(self.outline)
+
+    @property
+    def pos(self):
+        return np.mean(self.outline[:2]), np.mean(self.outline[2:4]), self.outline[4]
+
+    def clear(self) -> None:
+        super().clear()
+        self.rays.__init__()
+
+    # ---- change detection (raytracer.py:129-179) ------------------------------------------------------
+    def tracing_snapshot(self) -> dict:
+        return dict(Rays=[self.rays.N, self.rays.Nt, self.rays.no_pol],
+                    Ambient=[tuple(self.outline), self.n0.crepr()],
+                    TraceSettings=[self.no_pol, self.use_hurb, self.HURB_FACTOR],
+                    Lenses=[D.crepr() for D in self.lenses],
+                    Filters=[D.crepr() for D in self.filters],
+                    Apertures=[D.crepr() for D in self.apertures],
+                    RaySources=[D.crepr() for D in self.ray_sources])
+
+    def property_snapshot(self) -> dict:
+        return self.tracing_snapshot() | dict(Detectors=[D.crepr() for D in self.detectors])
+
+    def compare_property_snapshot(self, h1: dict, h2: dict) -> dict:
+        diff = {key: h1[key] != h2[key] for key in h1.keys()}
+        diff["Ambient"] = diff["Ambient"] or diff["Lenses"]
+        diff["Any"] = any(diff.values())
+        return diff
+
+    def check_if_rays_are_current(self) -> bool:
+        if self._last_trace_snapshot is None:
+            return False
+        return not self.compare_property_snapshot(self._last_trace_snapshot, self.tracing_snapshot())["Any"]
+
+    # ---- messages (raytracer.py:181-244) ----------------------------------------------------------------
+    def _surface_names(self) -> list:
+        names = dict()
+        for type_, els in zip(["Lens", "Aperture", "Filter"], [self.lenses, self.apertures, self.filters]):
+            for i, el in enumerate(els):
+                if not el.has_back():
+                    names[f"surface of {type_} {el.abbr}{i}"] = el.pos[2]
+                else:
+                    names[f"front surface of {type_} {el.abbr}{i}"] = el.front.pos[2]
+                    names[f"back surface of {type_} {el.abbr}{i}"] = el.back.pos[2]
+        return ["RaySource"] + sorted(names, key=lambda k: names[k]) + ["Outline"]
+
+    def _show_messages(self, N) -> None:
+        names = self._surface_names()
+        texts = {
+            self.INFOS.TIR: "with total inner reflection at surface {s} ({n}), treating as absorbed.",
+            self.INFOS.ABSORB_MISSING: "missing lens surface {s} ({n}), set to absorbed",
+            self.INFOS.ILL_COND: "are ill-conditioned for numerical hit finding at surface {s} ({n}). "
+                                 "Where and whether they intersect might be wrong.",
+            self.INFOS.OUTLINE_INTERSECTION: "hitting outline after surface {s} ({n}), set to absorbed.",
+            self.INFOS.HURB_NEG_DIR: "have negative z-direction after ray bending at surface {s} ({n}), "
+                                     "set to absorbed.",
+        }
+        for type_ in range(self._msgs.shape[0]):
+            for surf in range(self._msgs.shape[1]):
+                if count := self._msgs[type_, surf]:
+                    name = names[surf] if surf < len(names) else "?"
+                    warning(f"{count} rays ({100*count/N:.3g}% of all rays) "
+                            + texts[self.INFOS(type_)].format(s=surf, n=name))
+
+    # ---- geometry checks (raytracer.py:510-664) ---------------------------------------------------------
+    def _pretrace_check(self, N: int) -> bool:
+        check_type("N", N, int)
+        if N < 1:
+            raise ValueError(f"Ray number N needs to be at least 1, but is {N}.")
+        self._geometry_checks()
+        if self.geometry_error and not self._ignore_geometry_error:
+            warning("ABORTED TRACING")
+            return True
+        return False
+
+    def _geometry_checks(self) -> None:
+        elements = tracing_elements(self)
+
+        def is_inside(e) -> bool:
+            o = self.outline + self.N_EPS * np.array([-1, 1, -1, 1, -1, 1])
+            return o[0] <= e[0] and e[1] <= o[1] and o[2] <= e[2] and e[3] <= o[3] and o[4] <= e[4] and e[5] <= o[5]
+
+        if not self.ray_sources:
+            warning("RaySource Missing.")
+            self.geometry_error = True
+            return
+
+        coll = False
+        xc = yc = zc = np.array([])
+        for i, el in enumerate(elements):
+            if not is_inside(el.extent):
+                warning(f"Element{i} {el} with extent {el.extent} outside outline {self.outline}.")
+                self.geometry_error = True
+                return
+            if i + 1 < len(elements):
+                coll, xc, yc, zc = self.check_collision(el.front, elements[i + 1].front)
+            if not coll and el.has_back():
+                coll, xc, yc, zc = self.check_collision(el.front, el.back)
+            if not coll and el.has_back():
+                coll, xc, yc, zc = self.check_collision(el.back, elements[i + 1].front)
+            if self.use_hurb and i < len(elements) - 1 and isinstance(el, Aperture):
+                if not isinstance(el.front, (RingSurface, SlitSurface)):
+                    warning(f"Ray bending for surface type {type(el.front).__name__} not implemented.")
+                    self.geometry_error = True
+                    return
+            if coll:
+                break
+
+        if not coll:
+            for rs in self.ray_sources:
+                if not is_inside(rs.extent):
+                    warning(f"RaySource {rs} with extent {rs.extent} outside outline {self.outline}.")
+                    self.geometry_error = True
+                    return
+                if rs.pos[2] >= elements[0].extent[4]:
+                    coll, xc, yc, zc = self.check_collision(rs.surface, elements[0].front)
+                if coll:
+                    break
+
+        if coll:
+            warning(f"Detected collision between two Surfaces at {xc[0], yc[0], zc[0]}"
+                    f" and at least {xc.shape[0]} other positions.")
+            self.geometry_error = True
+            self.fault_pos = np.column_stack((xc, yc, zc))
+            return
+        self.geometry_error = False
+
+    @staticmethod
+    def check_collision(front, back, res: int = 100):
+        """Is `front` anywhere behind `back` where both are defined?  Sampled on a res x res grid
+        (raytracer.py:580-664).  Host NumPy: one-off validation, not part of the per-ray path."""
+        empty = np.array([])
+        if not (isinstance(front, Surface) or isinstance(back, Surface)):
+            raise TypeError("At least one object needs to be a Surface for collision detection")
+
+        if isinstance(front, Point) or isinstance(back, Point):
+            rev, pt, surf = (False, front, back) if isinstance(front, Point) else (True, back, front)
+            x, y = np.array([pt.pos[0]]), np.array([pt.pos[1]])
+            z = surf._values_host(x, y)
+            hit = ((z < pt.pos[2]) if not rev else (z > pt.pos[2])) & surf._mask_host(x, y)
+            where = np.where(hit)[0]
+            return bool(np.any(hit)), x[where], y[where], z[where]
+
+        if isinstance(front, Line) or isinstance(back, Line):
+            rev, line, surf = (False, front, back) if isinstance(front, Line) else (True, back, front)
+            t = np.linspace(-line.r, line.r, 10 * res)
+            ang = np.deg2rad(line.angle)
+            x = line.pos[0] + np.cos(ang) * t
+            y = line.pos[1] + np.sin(ang) * t
+            z = surf._values_host(x, y)
+            hit = ((z < line.pos[2]) if not rev else (z > line.pos[2])) & surf._mask_host(x, y)
+            where = np.where(hit)[0]
+            return bool(np.any(hit)), x[where], y[where], z[where]
+
+        xsf, xef, ysf, yef, zsf, zef = front.extent
+        xsb, xeb, ysb, yeb, zsb, zeb = back.extent
+        if zef < zsb:
+            return False, empty, empty, empty
+        xs, xe, ys, ye = max(xsf, xsb), min(xef, xeb), max(ysf, ysb), min(yef, yeb)
+        if xs > xe or ys > ye:
+            return False, empty, empty, empty
+        Y, X = np.mgrid[ys:ye:res * 1j, xs:xe:res * 1j]
+        x2, y2 = X.flatten(), Y.flatten()
+        valid = front._mask_host(x2, y2) & back._mask_host(x2, y2)
+        x2v, y2v = x2[valid], y2[valid]
+        zfv = front._values_host(x2v, y2v)
+        zbv = back._values_host(x2v, y2v)
+        coll = zfv > zbv
+        where = np.where(coll)[0]
+        return bool(np.any(coll)), x2v[where], y2v[where], zfv[where]
+
+    # ---- scene upload --------------------------------------------------------------------------------------
+    def _compile(self) -> CompiledScene:
+        lib = _capi.load_library()
+        self._release_scene()
+        self._scene = CompiledScene(self)
+        handle = C.c_void_p()
+        _capi.check(lib.ot_scene_create(C.byref(self._scene.desc), C.byref(handle)))
+        self._scene_handle = handle
+        return self._scene
+
+    def _release_scene(self) -> None:
+        if self._scene_handle is not None and self._scene_handle.value:
+            _capi.load_library().ot_scene_destroy(self._scene_handle)
+        self._scene_handle = None
+
+    def __del__(self):
+        try:
+            self._release_scene()
+        except Exception:
+            pass
+
+    # ---- tracing (raytracer.py:262-415) -----------------------------------------------------------------
+    def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None) -> None:
+        """Trace N rays through the current geometry.
+
+        Geometry errors are reported as warnings and set `geometry_error` instead of raising, like the
+        reference.  `_initial_rays` = (p, s, pols, w, wl) and `_hurb_normals` (2*n_hurb, N) inject
+        recorded inputs for parity tests; normally rays are generated inside the tracing kernel.
+        """
+        if self._pretrace_check(N):
+            return
+        lib = _capi.load_library()
+        dev = require_device()
+
+        nt = len(self.tracing_surfaces) + 2
+        if self.rays.storage_size(N, nt, self.no_pol) > self.MAX_RAY_STORAGE_RAM:
+            raise RuntimeError(f"More than {self.MAX_RAY_STORAGE_RAM*1e-9:.1f} GB RAM requested. Either decrease"
+                               " the number of rays, surfaces or do an iterative render. If your system can handle"
+                               " more RAM usage, increase the Raytracer.MAX_RAY_STORAGE_RAM parameter.")
+
+        scene = self._compile()
+        assert scene.nt == nt
+        self.rays.init(self.ray_sources, N, nt, self.no_pol)
+        rays = self.rays._rays_struct()
+        msgs = torch.zeros(len(self.INFOS) * nt, dtype=torch.int64, device=dev)
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed)
+
+        if _initial_rays is None:
+            tab = self.rays._source_table()
+            rng = self.rays._source_ranges()
+            _capi.check(lib.ot_generate_and_trace(self._scene_handle, tab.handle, rng, len(rng), seed,
+                                                  C.byref(rays), ptr(msgs), stream_ptr()))
+        else:
+            self.rays.set_initial_rays(*_initial_rays)
+            hn = None
+            if _hurb_normals is not None:
+                hn = torch.from_numpy(np.ascontiguousarray(_hurb_normals, dtype=np.float64).reshape(-1)).to(dev)
+            _capi.check(lib.ot_trace(self._scene_handle, C.byref(rays), ptr(hn), seed, ptr(msgs), stream_ptr()))
+
+        torch.cuda.current_stream().synchronize()
+        self.rays.lock()
+        self._msgs = msgs.cpu().numpy().reshape(len(self.INFOS), nt).astype(int)
+        self._show_messages(N)
+        self._last_trace_snapshot = self.tracing_snapshot()
+
+    # ---- detector (raytracer.py:881-1098) ----------------------------------------------------------------
+    def _hit_detector(self, info: str, detector_index: int = 0, source_index: int = None, extent=None,
+                      projection_method: str = "Equidistant"):
+        """Device hit search -> (ph, hw, wl) device tensors of the selected ray range (dense: rays without a
+        valid hit carry weight 0), the extent actually used, the projection name and the ill-conditioned count."""
+        if not self.detectors:
+            raise RuntimeError("Detector Missing")
+        if not self.rays.N:
+            raise RuntimeError("No rays traced.")
+        if source_index is not None and (source_index > len(self.ray_sources) - 1 or source_index < 0):
+            raise IndexError("Invalid source_index.")
+        if detector_index > len(self.detectors) - 1 or detector_index < 0:
+            raise IndexError("Invalid detector_index.")
+        if not self.check_if_rays_are_current():
+            raise RuntimeError("Tracing geometry/properties changed. Please retrace first.")
+
+        Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
+        Ns, Ne = int(Ns), int(Ne)
+        dsurf = self.detectors[detector_index].surface
+
+        if isinstance(dsurf, SphericalSurface) and projection_method is not None:
+            if projection_method not in SphericalSurface.sphere_projection_methods:
+                raise ValueError(f"Invalid projection_method {projection_method}, "
+                                 f"must be one of {SphericalSurface.sphere_projection_methods}.")
+            projection = projection_method
+        else:
+            projection = None
+
+        if not (extent is None or isinstance(extent, (list, np.ndarray))):
+            raise ValueError(f"Invalid extent '{extent}'.")
+
+        ph, hw, ext4, ill_count = _detector.detector_hits(self.rays, Ns, Ne - Ns, dsurf._desc(),
+                                                          _capi.PROJECTIONS[projection], extent is None)
+        wl = self.rays._dev["wl"][Ns:Ne]
+
+        if extent is not None:
+            extent_out = np.asarray_chkfinite(np.array(extent, dtype=np.float64).copy(), dtype=np.float64)
+            # rays outside a user extent are dropped (raytracer.py:1036-1040); binning gives them weight 0
+            n = Ne - Ns
+            x, y = ph[:n], ph[n:2 * n]
+            inside = (extent_out[0] <= x) & (x <= extent_out[1]) & (extent_out[2] <= y) & (y <= extent_out[3])
+            hw = torch.where(inside, hw, torch.zeros_like(hw))
+        else:
+            extent_out = self.detectors[detector_index].pos[:2].repeat(2)
+            if np.all(np.isfinite(ext4)):
+                extent_out = ext4.copy()
+        return ph, hw, wl, extent_out, projection, ill_count
+
+    def detector_image(self, detector_index: int = 0, source_index: int = None, extent=None,
+                       limit: float = None, projection_method: str = "Equidistant", **kwargs) -> RenderImage:
+        """Render the image on a detector for the traced rays (raytracer.py:1053-1098)."""
+        if limit is not None and extent is not None and "_dont_filter" not in kwargs:
+            warning("Using the limit parameter in combination with a user defined extent"
+                    " will produce an incorrect detector image, as the rays outside the extent"
+                    " are not included in the convolution calculation.")
+        p, w, wl, extent_out, projection, ill_count = self._hit_detector(
+            "Detector Image", detector_index, source_index, extent, projection_method)
+
+        det = self.detectors[detector_index]
+        pname = f": {det.desc}" if det.desc != "" else ""
+        desc = f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm"
+        if source_index is not None:
+            desc = f"Rays from RS{source_index} at " + desc
+
+        img = RenderImage(long_desc=desc, extent=extent_out, projection=projection)
+        img.render(p, w, wl, limit=limit, **kwargs)
+        if ill_count:
+            warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
+                    f"numerical hit finding at detector {detector_index}. "
+                    "Where and whether they intersect might be wrong.")
+        return img
+
+    # ---- iterative rendering (raytracer.py:1134-1279) -------------------------------------------------------
+    def iterative_render(self, N, detector_index=0, limit=None, projection_method="Equidistant", pos=None,
+                         extent=None) -> list:
+        """Render detector images from N rays traced in chunks of ITER_RAYS_STEP; images of all chunks
+        are summed (the extent of the first chunk fixes later ones)."""
+        if not self.ray_sources:
+            raise RuntimeError("Ray Source(s) Missing.")
+        if not self.detectors:
+            raise RuntimeError("Detector(s) Missing.")
+        if (N := int(N)) <= 0:
+            raise ValueError(f"Ray number N_rays needs to be a positive int, but is {N}.")
+
+        if pos is None:
+            if isinstance(detector_index, list):
+                raise ValueError("detector_index list needs to have the same length as pos list")
+            pos = [self.detectors[detector_index].pos]
+        elif isinstance(pos, list) and not isinstance(pos[0], (list, np.ndarray)):
+            pos = [pos]
+
+        def as_list(v, name):
+            if not isinstance(v, list):
+                return [v] * len(pos)
+            if len(v) != len(pos):
+                raise ValueError(f"{name} list needs to have the same length as pos list")
+            return v
+
+        detector_index = as_list(detector_index, "detector_index")
+        limit = as_list(limit, "limit")
+        projection_method = as_list(projection_method, "projection_method")
+        if not isinstance(extent, list) or isinstance(extent[0], (int, float)):
+            extent = [extent] * len(pos)
+        elif len(extent) != len(pos):
+            raise ValueError("extent list needs to have the same length as pos list")
+        extentc = extent.copy()
+
+        rays_step = self.ITER_RAYS_STEP
+        iterations = max(1, int(N / rays_step))
+        images: list = []
+
+        if self._pretrace_check(rays_step):
+            raise RuntimeError("Geometry checks failed. Tracing aborted. Check the warnings.")
+
+        nt = len(self.tracing_surfaces) + 2
+        msgs_cum = np.zeros((len(self.INFOS), nt), dtype=int)
+
+        for i in range(iterations):
+            if i == iterations - 1:
+                rays_step += int(N - iterations * rays_step)
+            with global_options.no_warnings():
+                self.trace(N=rays_step)
+                msgs_cum += self._msgs
+            for j in range(len(pos)):
+                self.detectors[detector_index[j]].move_to(pos[j])
+                img = self.detector_image(detector_index=detector_index[j], extent=extentc[j], limit=limit[j],
+                                          _dont_filter=True, _keep_on_device=True,
+                                          projection_method=projection_method[j])
+                img._dev *= rays_step / N
+                if i == 0:
+                    images.append(img)
+                    extentc[j] = img._extent0
+                else:
+                    images[j]._dev += img._dev
+
+        for i, img in enumerate(images):
+            img._sync_host()
+            if limit[i] is not None:
+                img._apply_rayleigh_filter()
+
+        self._msgs = msgs_cum
+        self._show_messages(N)
+        return images

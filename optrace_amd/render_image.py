@@ -1,0 +1,158 @@
+"""RenderImage: XYZ + power histogram of detector hits.
+
+Mirror of optrace/tracer/image/render_image.py:29-421 for the rendering path: `render` bins hits on
+the GPU (`ot_render_accumulate`: binning_indices_2d + CIE observer interpolation + f64 atomics) into an
+(Ny, Nx, 4) float64 image.  `_data` is the host copy the reference API exposes; the device histogram is
+kept alongside so that iterative rendering and the multi-GPU reduction never leave HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import _capi
+from .base import BaseClass, check_type, check_above
+from ._device import require_device, stream_ptr, ptr, to_dev
+
+
+class RenderImage(BaseClass):
+
+    EPS: float = 1e-9
+    K: float = 683.002  # luminous efficacy [lm/W] (scipy.constants "luminous efficacy", render_image.py:35)
+    SIZES = [1, 3, 5, 7, 9, 15, 21, 27, 35, 45, 63, 105, 135, 189, 315, 945]
+    MAX_IMAGE_SIDE: int = SIZES[-1]
+    MAX_IMAGE_RATIO: int = SIZES[2]
+    image_modes = ["sRGB (Absolute RI)", "sRGB (Perceptual RI)", "Outside sRGB Gamut", "Irradiance",
+                   "Illuminance", "Lightness (CIELUV)", "Hue (CIELUV)", "Chroma (CIELUV)", "Saturation (CIELUV)"]
+
+    def __init__(self, extent, projection: str = None, **kwargs) -> None:
+        self._new_lock = False
+        self.extent = extent
+        self._extent0 = self.extent.copy()
+        self._data = None
+        self._dev = None
+        self._limit = None
+        self.projection = projection
+        super().__init__(**kwargs)
+        self._new_lock = True
+
+    def has_image(self) -> bool:
+        return self._data is not None
+
+    def _check_for_image(self) -> None:
+        if not self.has_image():
+            raise RuntimeError("Image was not calculated/rendered yet.")
+
+    @property
+    def s(self) -> list:
+        return [float(self.extent[1] - self.extent[0]), float(self.extent[3] - self.extent[2])]
+
+    @property
+    def shape(self) -> tuple:
+        self._check_for_image()
+        return self._data.shape
+
+    @property
+    def data(self) -> np.ndarray:
+        self._check_for_image()
+        return self._data.copy()
+
+    @property
+    def Apx(self) -> float:
+        self._check_for_image()
+        return self.s[0] * self.s[1] / (self.shape[1] * self.shape[0])
+
+    def power(self) -> float:
+        self._check_for_image()
+        return float(np.sum(self._data[:, :, 3]))
+
+    def luminous_power(self) -> float:
+        self._check_for_image()
+        return float(self.K * np.sum(self._data[:, :, 1]))
+
+    @property
+    def limit(self) -> float:
+        return self._limit
+
+    def _fix_extent(self) -> None:
+        """Give point / line / extreme-ratio images a valid 2D extent (render_image.py:224-255)."""
+        sx, sy = self.s
+        MR = self.MAX_IMAGE_RATIO
+        self.extent = self._extent0.copy()
+        if sx < 2 * self.EPS and sy < 2 * self.EPS:
+            self.extent += self.EPS * np.array([-1, 1, -1, 1])
+        elif not sx or sy / sx > MR:
+            xm = (self._extent0[0] + self._extent0[1]) / 2
+            self.extent[0] = xm - sy / MR / 2
+            self.extent[1] = xm + sy / MR / 2
+        elif not sy or sx / sy > MR:
+            ym = (self._extent0[2] + self._extent0[3]) / 2
+            self.extent[2] = ym - sx / MR / 2
+            self.extent[3] = ym + sx / MR / 2
+        if self._limit is not None:
+            self.extent += np.array([-1.0, 1.0, -1.0, 1.0]) * 2.7 * self._limit / 1000.0
+
+    def _pixel_counts(self) -> tuple[int, int]:
+        """Nx, Ny: the smaller side has 945 px, the ratio snaps to 1, 3 or 5 (render_image.py:383-387)."""
+        Nrs = self.MAX_IMAGE_SIDE
+        nf = lambda a: min(self.MAX_IMAGE_RATIO, 1 + 2 * int(a / 2))  # noqa: E731
+        Nx = Nrs if self.s[0] <= self.s[1] else Nrs * nf(self.s[0] / self.s[1])
+        Ny = Nrs if self.s[0] > self.s[1] else Nrs * nf(self.s[1] / self.s[0])
+        return Nx, Ny
+
+    def render(self, p=None, w=None, wl=None, limit: float = None, _dont_filter: bool = False,
+               _keep_on_device: bool = False) -> None:
+        """Bin hit positions into the XYZW image (render_image.py:361-421).
+
+        p (n, 3) positions, w (n,) powers, wl (n,) wavelengths: NumPy arrays, or device tensors in the
+        layout `ot_detector_hits` produces (p flat component-major).  Hits with w == 0 add nothing.
+        """
+        self._limit = limit
+        self._fix_extent()
+        Nx, Ny = self._pixel_counts()
+        lib = _capi.load_library()
+        dev = require_device()
+        hist = torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=dev)
+
+        n = 0 if p is None else (int(w.shape[0]))
+        if n:
+            if isinstance(p, torch.Tensor):
+                px, py = p[:n], p[n:2 * n]
+                dw, dwl = w, wl
+            else:
+                p = np.asarray(p, dtype=np.float64)
+                px, py = to_dev(p[:, 0], np.float64), to_dev(p[:, 1], np.float64)
+                dw, dwl = to_dev(w, np.float32), to_dev(wl, np.float32)
+            ext = (C.c_double * 4)(*[float(v) for v in self.extent])
+            _capi.check(lib.ot_render_accumulate(n, ptr(px), ptr(py), ptr(dw), ptr(dwl), ext, Nx, Ny,
+                                                 ptr(hist), stream_ptr()))
+        self._dev = hist.view(Ny, Nx, 4)
+        if not _keep_on_device:
+            self._data = self._dev.cpu().numpy()
+        if not _dont_filter and self._limit is not None:
+            self._apply_rayleigh_filter()
+
+    def _sync_host(self) -> None:
+        self._data = self._dev.cpu().numpy()
+
+    def _apply_rayleigh_filter(self) -> None:
+        """Airy-disc resolution filter (render_image.py:257-296) -- next-row feature."""
+        raise NotImplementedError("The Rayleigh resolution filter (limit=...) is not part of the tracing hot "
+                                  "path and is not implemented yet.")
+
+    def __setattr__(self, key: str, val: Any) -> None:
+        if key == "extent" and val is not None:
+            check_type(key, val, (list, np.ndarray))
+            val = np.asarray_chkfinite(val, dtype=np.float64)
+            if val.shape[0] != 4 or val[0] > val[1] or val[2] > val[3]:
+                raise ValueError("extent needs to be [x0, x1, y0, y1] with x1 >= x0, y1 >= y0")
+        elif key == "_limit" and val is not None:
+            check_type(key, val, (float, int))
+            check_above(key, val, 0)
+            val = float(val)
+        elif key == "projection":
+            check_type(key, val, (str, type(None)))
+        super().__setattr__(key, val)

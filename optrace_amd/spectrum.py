@@ -1,0 +1,298 @@
+"""Spectra: base class, light spectra of sources, transmission spectra of filters.
+
+Host-side mirror of optrace/tracer/spectrum/{spectrum,light_spectrum,transmission_spectrum}.py.
+The objects hold parameters and describe themselves to the device: a LightSpectrum becomes the
+`spectrum` part of an `ot_source` (wavelength sampling happens inside the ray-generation kernel),
+a TransmissionSpectrum becomes an `ot_filter`.
+"""
+from __future__ import annotations
+
+import copy
+import pathlib
+from typing import Any, Callable
+
+import numpy as np
+
+from . import _capi
+from .base import BaseClass, check_type, check_in, check_not_above
+from .options import global_options as go
+
+_tables = np.load(pathlib.Path(__file__).resolve().parent / "data" / "cie_tables.npz")
+_illuminants = _tables["illuminants"]
+_ill_names = [str(s) for s in _tables["illuminant_names"]]
+
+
+def wavelengths(N: int) -> np.ndarray:
+    """N equally spaced wavelengths over global_options.wavelength_range (color/tools.py:13-21)."""
+    return np.linspace(*go.wavelength_range, N)
+
+
+def illuminant(name: str) -> Callable[[np.ndarray], np.ndarray]:
+    """Linear interpolation of a CIE standard illuminant table (color/illuminants.py:16-...)."""
+    col = _ill_names.index(name)
+
+    def f(wl):
+        return np.interp(wl, _illuminants[:, 0], _illuminants[:, col], left=0, right=0)
+    f.__name__ = f"{name.lower()}_illuminant"
+    return f
+
+
+d65_illuminant = illuminant("D65")
+
+
+def blackbody(wl: np.ndarray, T: float = 6504.) -> np.ndarray:
+    """Planck spectral radiance (color/tools.py:24-44)."""
+    c, h, k_B = 299792458.0, 6.62607015e-34, 1.380649e-23
+    wlm = 1e-9 * wl
+    return 2 * h * c ** 2 / wlm ** 5 / (np.exp(h * c / (wlm * k_B * T)) - 1)
+
+
+def normalized_blackbody(wl: np.ndarray, T: float = 6504.) -> np.ndarray:
+    """Blackbody curve with its maximum inside the visible range scaled to 1 (color/tools.py:46-61)."""
+    l_w = 2897.771955 * 1e3 / T
+    p_w, p_l, p_r = blackbody(np.array([l_w, *go.wavelength_range]), T)
+    p_max = p_w if go.wavelength_range[0] <= l_w <= go.wavelength_range[1] else max(p_l, p_r)
+    return blackbody(wl, T) / p_max
+
+
+class Spectrum(BaseClass):
+    """Parametrised spectrum (spectrum.py:12-260)."""
+
+    spectrum_types = ["Monochromatic", "Constant", "Data", "Lines", "Rectangle", "Gaussian", "Function"]
+    unit = ""
+    quantity = ""
+
+    def __init__(self, spectrum_type: str = "Gaussian", val: float = 1., lines=None, line_vals=None,
+                 wl: float = 550., wl0: float = 400., wl1: float = 600., wls=None, vals=None,
+                 func: Callable = None, mu: float = 550., sig: float = 50., unit: str = None,
+                 quantity: str = None, func_args: dict = {}, **kwargs) -> None:
+        self.spectrum_type = spectrum_type
+        self.lines = lines
+        self.line_vals = line_vals
+        self.func_args = func_args
+        self.func = func
+        self.wl, self.wl0, self.wl1 = wl, wl0, wl1
+        self.val, self.mu, self.sig = val, mu, sig
+        self._wls, self._vals = wls, vals
+        self.unit = unit if unit is not None else self.unit
+        self.quantity = quantity if quantity is not None else self.quantity
+        super().__init__(**kwargs)
+        self._new_lock = True
+
+    def is_continuous(self) -> bool:
+        return self.spectrum_type not in ["Lines", "Monochromatic"]
+
+    def _eval_host(self, wl) -> np.ndarray:
+        """Spectrum values on the host -- scene set-up (tabulating callables) only (spectrum.py:81-120)."""
+        if not self.is_continuous():
+            raise RuntimeError(f"Can't call discontinuous spectrum_type '{self.spectrum_type}'")
+        wl_ = np.asarray_chkfinite(wl, dtype=np.float64)
+        st = self.spectrum_type
+        if st == "Constant":
+            return np.broadcast_to(self.val, wl_.shape)
+        if st == "Data":
+            return np.interp(wl_, self._wls, self._vals, left=0, right=0)
+        if st == "Rectangle":
+            res = np.zeros_like(wl_, dtype=np.float64)
+            res[(self.wl0 <= wl_) & (wl_ <= self.wl1)] = self.val
+            return res
+        if st == "Gaussian":
+            return self.val * np.exp(-(wl_ - self.mu) ** 2 / (2 * self.sig ** 2))
+        if st == "Function":
+            return self.func(wl_, **self.func_args)
+        raise AssertionError(st)
+
+    def __call__(self, wl) -> np.ndarray:
+        return self._eval_host(wl)
+
+    def get_desc(self, fallback: str = None) -> str:
+        fallback = str(self.val) if self.spectrum_type == "Constant" else self.spectrum_type
+        return super().get_desc(fallback=fallback)
+
+    def __setattr__(self, key: str, val: Any) -> None:
+        if key == "spectrum_type":
+            check_type(key, val, str)
+            check_in(key, val, self.spectrum_types)
+        elif key in ("lines", "line_vals") and val is not None:
+            check_type(key, val, (list, np.ndarray))
+            val2 = np.asarray_chkfinite(val, dtype=np.float32)  # float32 like the reference (spectrum.py:168)
+            if val2.shape[0] == 0:
+                raise ValueError(f"'{key}' can't be empty.")
+            if key == "lines" and (val2.min() < go.wavelength_range[0] or val2.max() > go.wavelength_range[1]):
+                raise ValueError(f"'lines' need to be inside visible range {go.wavelength_range}.")
+            if key == "line_vals" and val2.min() < 0:
+                raise ValueError("line_vals must be all positive.")
+            if key == "lines" and len(np.unique(val)) != len(val):
+                raise ValueError("All elements inside of 'lines' must be unique.")
+            val = val2
+        elif key == "func_args":
+            check_type(key, val, dict)
+            val = copy.deepcopy(val)
+        elif key in ("quantity", "unit"):
+            check_type(key, val, str)
+        elif key == "func":
+            if val is not None and not callable(val):
+                raise TypeError("func needs to be callable or None")
+            if val is not None and type(self).__name__ != "RefractionIndex":
+                T = val(wavelengths(10000), **self.func_args)
+                if np.min(T) < 0 or np.max(T) <= 0:
+                    raise RuntimeError("Function func needs to return positive values over the visible range.")
+        elif key in ("_wls", "_vals") and val is not None:
+            check_type(key, val, (list, np.ndarray))
+            val2 = np.asarray_chkfinite(val, dtype=np.float64)
+            if key == "_wls":
+                if val2[0] < go.wavelength_range[0] or val2[-1] > go.wavelength_range[1]:
+                    raise ValueError("wls needs to be inside the visible range")
+                if np.std(np.diff(val2)) > 1e-4 or np.any(np.diff(val2) <= 0) or (val2[1] - val2[0] < 1e-6):
+                    raise ValueError("wls needs to be monotonically increasing with the same step size.")
+            elif val2.min() < 0:
+                raise ValueError("vals must be all positive")
+            val = val2
+        elif key in ("wl", "wl0", "wl1", "mu"):
+            check_type(key, val, (int, float))
+            val = float(val)
+            if val < go.wavelength_range[0] or val > go.wavelength_range[1]:
+                raise ValueError(f"Property '{key}' needs to be inside {go.wavelength_range}, but is {val}.")
+        elif key == "sig":
+            check_type(key, val, (int, float))
+            val = float(val)
+            if val <= 0:
+                raise ValueError("sig needs to be above 0")
+        elif key == "val" and type(self).__name__ != "RefractionIndex":
+            check_type(key, val, (int, float))
+            val = float(val)
+            if val < 0:
+                raise ValueError("val needs to be at least 0")
+        super().__setattr__(key, val)
+
+
+class LightSpectrum(Spectrum):
+    """Spectrum of a light source (light_spectrum.py:13-300); sampling runs in the generation kernel."""
+
+    spectrum_types = [*Spectrum.spectrum_types, "Blackbody", "Histogram"]
+
+    def __init__(self, spectrum_type: str = "Blackbody", T: float = 5500, **sargs) -> None:
+        self.T = T
+        line_spec = spectrum_type in ["Monochromatic", "Lines"]
+        unit = "W" if line_spec else "W/nm"
+        quantity = "Spectral Power" if line_spec else "Spectral Power Density"
+        super().__init__(spectrum_type, unit=unit, quantity=quantity, **sargs)
+
+    def _eval_host(self, wl) -> np.ndarray:
+        if self.spectrum_type == "Blackbody":
+            return self.val * normalized_blackbody(np.asarray_chkfinite(wl, dtype=np.float64), T=self.T)
+        if self.spectrum_type == "Histogram":
+            wl_ = np.asarray_chkfinite(wl, dtype=np.float64)
+            ind = np.digitize(wl_, self._wls)
+            ins = (ind > 0) & (ind < self._wls.shape[0])
+            res = np.zeros_like(wl_)
+            res[ins] = self._vals[ind[ins] - 1]
+            return res
+        return super()._eval_host(wl)
+
+    def _source_fields(self) -> dict:
+        """Spectrum part of an `ot_source` for LightSpectrum.random_wavelengths (light_spectrum.py:81-138)."""
+        st = self.spectrum_type
+        if st == "Monochromatic":
+            return dict(spectrum=_capi.SPEC_MONO, wl=float(self.wl))
+        if st in ("Constant", "Rectangle"):
+            wl0 = go.wavelength_range[0] if st == "Constant" else self.wl0
+            wl1 = go.wavelength_range[1] if st == "Constant" else self.wl1
+            return dict(spectrum=_capi.SPEC_UNIFORM, wl0=float(wl0), wl1=float(wl1))
+        if st == "Lines":
+            check_type("LightSpectrum.lines", self.lines, (np.ndarray, list))
+            check_type("LightSpectrum.line_vals", self.line_vals, (np.ndarray, list))
+            if not self.line_vals.sum():
+                raise RuntimeError("Cumulated probability is zero.")
+            keep = self.line_vals > 0
+            # discrete inverse CDF: cumulative sums are taken in float32 like the reference does
+            # (random.py:133-136 on the float32 line_vals)
+            F = np.cumsum(self.line_vals[keep])
+            tab = np.concatenate((self.lines[keep].astype(np.float64), F.astype(np.float64)))
+            return dict(spectrum=_capi.SPEC_LINES, spec_tab=tab, n_spec=int(keep.sum()))
+        if st == "Gaussian":
+            return dict(spectrum=_capi.SPEC_GAUSSIAN, mu=float(self.mu), sig=float(self.sig),
+                        wl0=float(go.wavelength_range[0]), wl1=float(go.wavelength_range[1]))
+        # Data / Blackbody / Function / Histogram: linear inverse CDF of a tabulated pdf
+        if st == "Data":
+            x, f = self._wls, self._vals
+        else:
+            x = wavelengths(4000 if st == "Blackbody" else 10000)
+            f = self._eval_host(x)
+        f = np.asarray(f, dtype=np.float64)
+        if not f.sum():
+            raise RuntimeError("Cumulated probability is zero.")
+        if f.min() < 0:
+            raise RuntimeError("Got negative value in pdf.")
+        # cumulative trapezoid with unit spacing (random.py:150: scipy cumulative_trapezoid(f, initial=0))
+        F = np.concatenate(([0.], np.cumsum((f[1:] + f[:-1]) / 2)))
+        return dict(spectrum=_capi.SPEC_TABLE, spec_tab=np.concatenate((np.asarray(x, dtype=np.float64), F)),
+                    n_spec=len(x))
+
+    def __setattr__(self, key, val):
+        if key == "T":
+            check_type(key, val, (int, float))
+            val = float(val)
+            if val <= 0:
+                raise ValueError("T needs to be above 0")
+        super().__setattr__(key, val)
+
+
+class TransmissionSpectrum(Spectrum):
+    """Transmittance of a filter, range [0, 1] (transmission_spectrum.py:11-110)."""
+
+    spectrum_types = ["Constant", "Data", "Rectangle", "Gaussian", "Function"]
+    quantity = "Transmission T"
+
+    def __init__(self, spectrum_type: str = "Gaussian", inverse: bool = False, **sargs) -> None:
+        self.inverse = inverse
+        super().__init__(spectrum_type, **sargs)
+
+    def _eval_host(self, wl):
+        v = super()._eval_host(wl)
+        return v if not self.inverse else 1.0 - v
+
+    def _desc(self, pool: list, lines: np.ndarray | None) -> _capi.Filter:
+        """`ot_filter` for this spectrum; tables are appended to `pool`.  `lines` = the distinct f32
+        wavelengths of all sources if every source is discrete (needed for "Function" spectra)."""
+        f = _capi.Filter()
+        f.inverse = int(self.inverse)
+        st = self.spectrum_type
+        f.val, f.wl0, f.wl1, f.mu, f.sig = float(self.val), float(self.wl0), float(self.wl1), float(self.mu), float(self.sig)
+        if st == "Constant":
+            f.type = _capi.T_CONSTANT
+        elif st == "Rectangle":
+            f.type = _capi.T_RECTANGLE
+        elif st == "Gaussian":
+            f.type = _capi.T_GAUSSIAN
+        elif st == "Data":
+            f.type = _capi.T_DATA
+            f.tab_off, f.tab_len = len(pool), len(self._wls)
+            pool.extend(self._wls.tolist())
+            pool.extend(self._vals.tolist())
+        else:  # Function: exact per line for discrete sources, fine table otherwise
+            f.inverse = 0  # folded into the table
+            if lines is not None:
+                f.type = _capi.T_LINES
+                x = lines.astype(np.float64)
+            else:
+                f.type = _capi.T_DATA
+                x = wavelengths(65537)
+            v = np.asarray(self._eval_host(x), dtype=np.float64)
+            f.tab_off, f.tab_len = len(pool), len(x)
+            pool.extend(x.tolist())
+            pool.extend(v.tolist())
+        return f
+
+    def __setattr__(self, key, val):
+        if key == "val" and isinstance(val, (int, float)):
+            check_not_above(key, val, 1)
+        if key == "_vals" and isinstance(val, (list, np.ndarray)):
+            if np.max(val) > 1:
+                raise ValueError("all elements in vals need to be in range [0, 1].")
+        if key == "inverse":
+            check_type(key, val, bool)
+        if key == "func" and callable(val):
+            if np.any(val(wavelengths(1000)) > 1):
+                raise RuntimeError("Function func needs to return values in range [0, 1] over the visible range.")
+        super().__setattr__(key, val)

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the upstream NumPy reference.
+
+Runs ONLY in the build container (needs /root/reference, imported through oracle/refload.py);
+the resulting .npz files are committed, the reference is not.  Re-run with
+    python tests/golden/generate_golden.py
+All runs are seeded and single-threaded, so the reference is bit-reproducible.
+
+Files
+  leaf_surfaces.npz   G1: find_hit / normals / mask / values / hurb_props per surface flavour
+  leaf_media.npz      G1: RefractionIndex for every model, TransmissionSpectrum, CIE observers,
+                          binning_indices_2d edge cases, sphere projections
+  trace_<scene>.npz   G3: injected initial rays + every ray section + counters + detector hits and
+                          sparse detector images, for the scenes of tests/scenes.py
+  sources.npz         G4: distribution fingerprints of RaySource.create_rays
+"""
+from __future__ import annotations
+
+import pathlib
+import sys
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import refload  # noqa: E402
+import scenes  # noqa: E402
+
+ot = refload.load(0)
+
+
+# ------------------------------------------------------------------------------------------------
+def surface_params(s) -> dict:
+    d = dict(cls=type(s).__name__, pos=np.array(s.pos), z_min=s.z_min, z_max=s.z_max)
+    for k in ("r", "ri", "R", "k"):
+        if hasattr(s, k):
+            d[k] = float(getattr(s, k))
+    for k in ("dim", "dimi", "coeff"):
+        if hasattr(s, k):
+            d[k] = np.array(getattr(s, k), dtype=np.float64)
+    if hasattr(s, "_angle"):
+        d["angle"] = float(s._angle)
+    return d
+
+
+def gen_leaf_surfaces():
+    rng = np.random.default_rng(1234)
+    out = {}
+    zoo = scenes.surface_zoo(ot)
+    for name, sf in zoo.items():
+        n = 1500
+        ext = np.array(sf.extent)
+        cx, cy = (ext[0] + ext[1]) / 2, (ext[2] + ext[3]) / 2
+        hw = max(ext[1] - ext[0], ext[3] - ext[2]) * 0.75
+        # ray starts: mostly before the surface, some inside its z range, some behind
+        p = np.zeros((n, 3), order="F")
+        p[:, 0] = cx + rng.uniform(-hw, hw, n)
+        p[:, 1] = cy + rng.uniform(-hw, hw, n)
+        p[:, 2] = sf.z_min - rng.uniform(0.2, 6.0, n)
+        p[1200:1350, 2] = rng.uniform(sf.z_min - 0.05, sf.z_max + 0.05, 150)
+        p[1350:, 2] = sf.z_max + rng.uniform(1e-3, 2.0, 150)
+        s = np.zeros((n, 3), order="F")
+        s[:, 0] = rng.uniform(-0.35, 0.35, n)
+        s[:, 1] = rng.uniform(-0.35, 0.35, n)
+        s[:100, :2] = 0.0  # straight rays
+        s[:, 2] = np.sqrt(1 - s[:, 0] ** 2 - s[:, 1] ** 2)
+        # aim a part of the rays exactly at the edge region
+        p[100:300, 0] = cx + (sf.r if hasattr(sf, "R") or type(sf).__name__ in ("CircularSurface", "RingSurface") else hw / 0.75 / 2) * np.cos(np.linspace(0, 6.2, 200))
+        p[100:300, 1] = cy + (sf.r if hasattr(sf, "R") or type(sf).__name__ in ("CircularSurface", "RingSurface") else hw / 0.75 / 2) * np.sin(np.linspace(0, 6.2, 200))
+        s[100:300, :2] *= 0.02
+        s[100:300, 2] = np.sqrt(1 - s[100:300, 0] ** 2 - s[100:300, 1] ** 2)
+
+        with ot.global_options.no_warnings():
+            ph, hit, ill = sf.find_hit(p, s)
+        x = cx + rng.uniform(-hw, hw, n)
+        y = cy + rng.uniform(-hw, hw, n)
+        x[:5] = [cx, cx + 1e-9, cx, cx - 0.3, cx + 0.2]
+        y[:5] = [cy, cy, cy + 1e-9, cy + 0.1, cy - 0.4]
+        out[f"{name}/p"], out[f"{name}/s"] = p, s
+        out[f"{name}/p_hit"], out[f"{name}/is_hit"] = np.array(ph), np.array(hit)
+        out[f"{name}/ill"] = np.array(ill, dtype=bool) if len(ill) else np.zeros(n, dtype=bool)
+        out[f"{name}/x"], out[f"{name}/y"] = x, y
+        out[f"{name}/normals"] = np.array(sf.normals(x, y))
+        out[f"{name}/mask"] = np.array(sf.mask(x, y))
+        out[f"{name}/values"] = np.array(sf.values(x, y))
+        if hasattr(sf, "hurb_props"):
+            a_, b_, b, inside = sf.hurb_props(x, y)
+            out[f"{name}/hurb_a"], out[f"{name}/hurb_b"], out[f"{name}/hurb_bvec"], out[f"{name}/hurb_inside"] = a_, b_, b, inside
+        for k, v in surface_params(sf).items():
+            out[f"{name}/param/{k}"] = v
+    out["names"] = np.array(list(zoo.keys()))
+    np.savez_compressed(HERE / "leaf_surfaces.npz", **out)
+    print("leaf_surfaces.npz", len(out))
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_leaf_media():
+    rng = np.random.default_rng(99)
+    out = {}
+    wl = np.concatenate(([380., 780., 486.1327, 589.2938, 656.272], rng.uniform(380, 780, 59))).astype(np.float32)
+    out["wl"] = wl
+    for name, kw in scenes.MEDIA.items():
+        n_type = name.split("_")[0]
+        ri = ot.RefractionIndex(n_type, **kw)
+        out[f"n/{name}"] = np.array(ri(wl), dtype=np.float64)
+    # Abbe coefficients as the reference computes them (refraction_index.py:85-98)
+    # transmission spectra, called with the float32 wavelengths like the tracer does (raytracer.py:380)
+    T = scenes.transmission_zoo(ot)
+    for name, t in T.items():
+        out[f"T/{name}"] = np.array(t(wl), dtype=np.float64)
+    # CIE observers
+    wlo = np.concatenate(([359.9, 360., 360.5, 555., 830., 830.01], rng.uniform(350, 840, 58))).astype(np.float32)
+    out["obs/wl"] = wlo
+    out["obs/xyz"] = np.column_stack((ot.color.x_observer(wlo), ot.color.y_observer(wlo), ot.color.z_observer(wlo)))
+    # binning_indices_2d (tests/test_misc.py:139-169 style edge cases)
+    from optrace.tracer import misc
+    ext = np.array([-1.0, 2.0, 0.5, 1.5])
+    x = np.concatenate(([-1.0, 2.0, 2.0000001, -1.0000001, 0.5, 0.5, 0.5], rng.uniform(-1.2, 2.2, 200)))
+    y = np.concatenate(([0.5, 1.5, 1.0, 1.0, 0.49999, 1.5, 1.50001], rng.uniform(0.4, 1.6, 200)))
+    w = rng.uniform(0.1, 1, x.shape[0]).astype(np.float32)
+    xi, yi, wm = misc.binning_indices_2d(x, y, w, 945, 315, ext)
+    out["bin/x"], out["bin/y"], out["bin/w"], out["bin/extent"] = x, y, w, ext
+    out["bin/xi"], out["bin/yi"], out["bin/wm"] = xi, yi, wm
+    # sphere projections
+    for R in (-13.4, 7.0):
+        sf = ot.SphericalSurface(r=abs(R) * 0.6, R=R)
+        sf.move_to([0.3, -0.2, 5.0])
+        xs = rng.uniform(-abs(R) * 0.55, abs(R) * 0.55, 300) / np.sqrt(2)
+        ys = rng.uniform(-abs(R) * 0.55, abs(R) * 0.55, 300) / np.sqrt(2)
+        p = np.column_stack((xs + 0.3, ys - 0.2, sf.values(xs + 0.3, ys - 0.2)))
+        out[f"proj/{R}/p"] = p
+        for m in sf.sphere_projection_methods:
+            out[f"proj/{R}/{m}"] = sf.sphere_projection(p, m)
+    np.savez_compressed(HERE / "leaf_media.npz", **out)
+    print("leaf_media.npz", len(out))
+
+
+# ------------------------------------------------------------------------------------------------
+def sparse(img: np.ndarray) -> dict:
+    nz = np.nonzero(img[:, :, 3])
+    return dict(shape=np.array(img.shape), iy=nz[0].astype(np.int32), ix=nz[1].astype(np.int32),
+                val=img[nz[0], nz[1], :])
+
+
+def gen_trace(name: str, builder, N: int, seed: int, **rt_args):
+    import optrace.tracer.geometry.ray_source as rsmod
+    refload.reseed(ot, seed)
+    RT = builder(ot, **rt_args)
+
+    # record what create_rays hands to the tracer (initial rays) ...
+    rec = []
+    orig_create = rsmod.RaySource.create_rays
+
+    def create_rec(self, N, no_pol=False, power=None):
+        res = orig_create(self, N, no_pol=no_pol, power=power)
+        rec.append([np.array(a) for a in res])
+        return res
+
+    # ... and the standard-normal draws behind np.random.normal in __hurb (raytracer.py:468-469)
+    normals = []
+    orig_normal = np.random.normal
+
+    def normal_rec(loc=0.0, scale=1.0, size=None):
+        z = np.random.standard_normal(size)
+        normals.append(z)
+        return loc + scale * z
+
+    rsmod.RaySource.create_rays = create_rec
+    np.random.normal = normal_rec
+    try:
+        RT.trace(N)
+    finally:
+        rsmod.RaySource.create_rays = orig_create
+        np.random.normal = orig_normal
+    assert not RT.geometry_error, name
+
+    out = dict(N=N, seed=seed)
+    out["p0"] = np.vstack([r[0] for r in rec])
+    out["s0"] = np.vstack([r[1] for r in rec])
+    out["w0"] = np.concatenate([r[3] for r in rec])
+    out["wl"] = np.concatenate([r[4] for r in rec]).astype(np.float32)
+    if not RT.no_pol:
+        out["pol0"] = np.vstack([r[2] for r in rec])
+    if normals:
+        out["hurb_normals"] = np.array(normals)
+    out["N_list"] = RT.rays.N_list
+    out["p_list"], out["w_list"], out["n_list"] = np.array(RT.rays.p_list), np.array(RT.rays.w_list), np.array(RT.rays.n_list)
+    out["s_final"] = np.array(RT.rays.s0_list)
+    assert np.array_equal(out["wl"], RT.rays.wl_list)
+    if not RT.no_pol:
+        out["pol_list"] = np.array(RT.rays.pol_list)
+    out["msgs"] = np.array(RT._msgs)
+
+    # detector stage
+    with ot.global_options.no_warnings():
+        for di, det in enumerate(RT.detectors):
+            projs = [None]
+            if isinstance(det.surface, ot.SphericalSurface):
+                projs = ["Equidistant", "Orthographic", "Equal-Area", "Stereographic"]
+            for proj in projs:
+                key = f"det{di}/{proj}"
+                ph, w, wl, ext, _, _, ill = RT._hit_detector("x", di, None, None, proj)
+                out[f"{key}/ph"], out[f"{key}/w"], out[f"{key}/wl"] = ph, w, wl
+                out[f"{key}/extent"], out[f"{key}/ill"] = ext, ill
+                img = RT.detector_image(detector_index=di, projection_method=proj)
+                for k, v in sparse(img._data).items():
+                    out[f"{key}/img/{k}"] = v
+                out[f"{key}/img/extent"] = np.array(img.extent)
+                out[f"{key}/img/power"] = img.power()
+            # fixed user extent + single source selection on the first projection
+            e0 = np.array(det.extent[:4])
+            cx, cy = (e0[0] + e0[1]) / 2, (e0[2] + e0[3]) / 2
+            uext = [cx - (e0[1] - e0[0]) / 5, cx + (e0[1] - e0[0]) / 4, cy - (e0[3] - e0[2]) / 4, cy + (e0[3] - e0[2]) / 6]
+            img = RT.detector_image(detector_index=di, extent=uext, projection_method=projs[0],
+                                    source_index=len(RT.ray_sources) - 1)
+            key = f"det{di}/user"
+            out[f"{key}/uext"] = np.array(uext)
+            for k, v in sparse(img._data).items():
+                out[f"{key}/img/{k}"] = v
+            out[f"{key}/img/extent"] = np.array(img.extent)
+            out[f"{key}/img/power"] = img.power()
+    np.savez_compressed(HERE / f"trace_{name}.npz", **out)
+    print(f"trace_{name}.npz N={N} msgs={RT._msgs.sum(axis=1)}")
+
+
+def gen_sources():
+    """Distribution fingerprints of RaySource.create_rays for the statistical parity tests (G4)."""
+    out = {}
+    N = 200000
+    cases = {
+        "point_iso": dict(surface=ot.Point(), divergence="Isotropic", div_angle=5., pos=[0, 0, -20]),
+        "disc_lamb": dict(surface=ot.CircularSurface(r=2.0), divergence="Lambertian", div_angle=14, pos=[0.3, -0.2, -10], s=[0.02, 0.05, 1]),
+        "ring_none": dict(surface=ot.RingSurface(r=2.0, ri=0.8), divergence="None", pos=[0, 0, 0]),
+        "rect_conv": dict(surface=ot.RectangularSurface(dim=[8.39, 4.0]), divergence="Isotropic", div_angle=0.25,
+                          orientation="Converging", conv_pos=[0, 0, 0], pos=[0, 0, -600]),
+        "line_iso2d": dict(surface=ot.Line(r=1.5, angle=30), divergence="Isotropic", div_2d=True, div_angle=10,
+                           div_axis_angle=20, pos=[0, 0, 0]),
+        "disc_lamb2d": dict(surface=ot.CircularSurface(r=0.5), divergence="Lambertian", div_2d=True, div_angle=25, pos=[0, 0, 0]),
+    }
+    specs = {
+        "mono": ot.LightSpectrum("Monochromatic", wl=550.),
+        "lines": ot.LightSpectrum("Lines", lines=[486.1327, 589.2938, 656.272], line_vals=[1, 2, 0.5]),
+        "rect": ot.LightSpectrum("Rectangle", wl0=420., wl1=680.),
+        "const": ot.LightSpectrum("Constant"),
+        "gauss": ot.LightSpectrum("Gaussian", mu=540., sig=40.),
+        "d65": ot.presets.light_spectrum.d65,
+        "blackbody": ot.LightSpectrum("Blackbody", T=4000),
+    }
+    pols = {"x": {}, "y": {}, "xy": {}, "Uniform": {}, "Constant": dict(pol_angle=25.),
+            "List": dict(pol_angles=[0., 45., 90.], pol_probs=[1., 2., 1.])}
+    refload.reseed(ot, 5)
+    for cname, kw in cases.items():
+        rs = ot.RaySource(spectrum=specs["mono"], polarization="Uniform", power=2.5, **kw)
+        p, s, pol, w, wl = rs.create_rays(N)
+        out[f"case/{cname}/p_mean"], out[f"case/{cname}/p_std"] = p.mean(axis=0), p.std(axis=0)
+        out[f"case/{cname}/s_mean"], out[f"case/{cname}/s_std"] = s.mean(axis=0), s.std(axis=0)
+        out[f"case/{cname}/p_min"], out[f"case/{cname}/p_max"] = p.min(axis=0), p.max(axis=0)
+        out[f"case/{cname}/sz_hist"] = np.histogram(s[:, 2], bins=20, range=(s[:, 2].min(), 1.0))[0]
+        out[f"case/{cname}/sz_min"] = s[:, 2].min()
+        out[f"case/{cname}/w"] = w[:3]
+        out[f"case/{cname}/pol_dot_s"] = np.abs((pol * s).sum(axis=1)).max()
+    for sname, sp in specs.items():
+        rs = ot.RaySource(ot.Point(), spectrum=sp, pos=[0, 0, 0])
+        wl = rs.create_rays(N)[4]
+        out[f"spec/{sname}/hist"] = np.histogram(wl, bins=40, range=(380, 780))[0]
+        out[f"spec/{sname}/mean"], out[f"spec/{sname}/std"] = wl.mean(), wl.std()
+    for pname, kw in pols.items():
+        rs = ot.RaySource(ot.Point(), spectrum=specs["mono"], polarization=pname, pos=[0, 0, 0], **kw)
+        pol = rs.create_rays(N)[2]
+        ang = np.arctan2(pol[:, 1], pol[:, 0]) % (2 * np.pi)
+        out[f"pol/{pname}/hist"] = np.histogram(ang, bins=16, range=(0, 2 * np.pi))[0]
+    out["N"] = N
+    np.savez_compressed(HERE / "sources.npz", **out)
+    print("sources.npz", len(out))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["leaf", "media", "trace", "sources"]
+    if "leaf" in which:
+        gen_leaf_surfaces()
+    if "media" in which:
+        gen_leaf_media()
+    if "trace" in which:
+        for j, (name, (builder, N)) in enumerate(scenes.SCENES.items()):
+            gen_trace(name, builder, N, seed=100 + j)
+        gen_trace("double_gauss_nopol", scenes.double_gauss, 1200, seed=300, no_pol=True)
+        gen_trace("asphere_nopol", scenes.asphere_scene, 1500, seed=301, no_pol=True)
+    if "sources" in which:
+        gen_sources()

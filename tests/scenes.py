@@ -1,0 +1,216 @@
+"""Scene builders shared by the golden-vector generator (run with the reference package) and the tests
+(run with optrace_amd).  Every builder takes the package as `ot`, so the same script text drives both --
+which is also the drop-in check of the Python API.
+
+Geometry numbers come from the reference's example / test scenes (cited per function); they are data.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def c1_single_lens(ot, **rt_args):
+    """BASELINE.json configs[0] / SURVEY 8d C1: biconvex spherical lens, monochromatic point source."""
+    RT = ot.Raytracer(outline=[-10, 10, -10, 10, -25, 60], **rt_args)
+    RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=5, pos=[0, 0, -20],
+                        spectrum=ot.LightSpectrum("Monochromatic", wl=550.)))
+    RT.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1,
+                   n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 0]))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[4, 4]), pos=[0, 0, 20]))
+    return RT
+
+
+def double_gauss(ot, spectrum=None, **rt_args):
+    """BASELINE.json configs[1] / C2: Nikkor-Wakamiya 100 mm f/1.4 double Gauss, geometry of
+    examples/double_gauss.py:34-102 (US patent 4448497), 5 point sources, FDC line spectrum."""
+    RT = ot.Raytracer(outline=[-2000, 2000, -22000, 2000, -50000, 180], **rt_args)
+    g = 50000
+    spectrum = spectrum or ot.LightSpectrum("Lines", lines=[486.1327, 589.2938, 656.272], line_vals=[1, 1, 1])
+    for deg in [0, 5, 10, 15, 20]:
+        xp = g * np.tan(deg / 180 * np.pi)
+        RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", orientation="Converging", conv_pos=[0, 0, 0],
+                            div_angle=0.03, pos=[0, -xp, -g], spectrum=spectrum, desc=f"{deg} deg"))
+
+    def lens(r1, R1, r2, R2, n, V, z, d2):
+        L = ot.Lens(ot.SphericalSurface(r=r1, R=R1), ot.SphericalSurface(r=r2, R=R2),
+                    n=ot.RefractionIndex("Abbe", n=n, V=V), pos=[0, 0, z], d1=0, d2=d2)
+        RT.add(L)
+        return L
+
+    L0 = lens(76 / 2, 78.36, 76 / 2, 469.5, 1.797, 45.3, 0, 9.8837)
+    L1 = lens(64 / 2, 50.3, 62 / 2, 74.38, 1.773, 49.4, L0.back.pos[2] + 0.1938, 9.1085)
+    L2 = lens(59 / 2, 138.1, 51 / 2, 34.33, 1.673, 32.20, L1.back.pos[2] + 2.9457, 2.3256)
+    RT.add(ot.Aperture(ot.RingSurface(ri=49.6 / 2, r=76 / 2), pos=[0, 0, L2.back.pos[2] + 16.07]))
+    L3 = lens(48.8 / 2, -34.41, 57 / 2, -2907, 1.740, 28.30, L2.back.pos[2] + 16.07 + 13, 1.938)
+    L4 = lens(57 / 2, -2907, 60 / 2, -59.05, 1.773, 49.40, L3.back.pos[2] + 1e-6, 12.403)
+    L5 = lens(66.8 / 2, -150.9, 67.8 / 2, -57.89, 1.788, 47.50, L4.back.pos[2] + 0.3876, 8.333)
+    L6 = lens(66 / 2, 284.6, 66 / 2, -253.2, 1.788, 47.50, L5.back.pos[2] + 0.1938, 5.0388)
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[86.53, 86.53]), pos=[0, 0, L6.back.pos[2] + 73.839]))
+    return RT
+
+
+def mixed_geometry(ot, **rt_args):
+    """Scene of tests/tracing_geometry.py:9-92 without its plot-only markers/volumes: two area sources
+    (line + tabulated spectrum), flat lens, conic lenses (k != 0), ring aperture, Function-index lens with a
+    different medium behind, Function filter, ideal lens, flat and spherical detectors."""
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -5, 60], **rt_args)
+    RT.add(ot.RaySource(ot.CircularSurface(r=1), divergence="None", spectrum=ot.presets.light_spectrum.FDC,
+                        pos=[0, 0, 0], s=[0, 0, 1], polarization="y"))
+    RT.add(ot.RaySource(ot.CircularSurface(r=1), divergence="None", s=[0, 0, 1],
+                        spectrum=ot.presets.light_spectrum.d65, pos=[0, 1, -3], polarization="Constant",
+                        pol_angle=25, power=2))
+    RT.add(ot.Lens(ot.CircularSurface(r=3), ot.CircularSurface(r=3), de=0.1, pos=[0, 0, 2],
+                   n=ot.RefractionIndex("Constant", n=1.8)))
+    RT.add(ot.Lens(ot.ConicSurface(r=3, R=10, k=-0.444), ot.ConicSurface(r=3, R=-10, k=-7.25), de=0.1,
+                   pos=[0, 0, 10], n=ot.RefractionIndex("Cauchy", coeff=[1.49, 0.00354, 0, 0])))
+    RT.add(ot.Lens(ot.ConicSurface(r=3, R=5, k=-0.31), ot.ConicSurface(r=3, R=-5, k=-3.04), de=0.6,
+                   pos=[0, 0, 25], n=ot.RefractionIndex("Constant", n=1.8)))
+    RT.add(ot.Aperture(ot.RingSurface(r=1, ri=0.01), pos=[0, 0, 20.3]))
+    nL3 = ot.RefractionIndex("Function", func=lambda l: 1.8 - 0.007 * (l - 380) / 400)
+    RT.add(ot.Lens(ot.SphericalSurface(r=1, R=2.2), ot.SphericalSurface(r=1, R=-5), de=0.1, pos=[0, 0, 47],
+                   n=nL3, n2=ot.RefractionIndex("Constant", n=1.1)))
+    fspec = ot.TransmissionSpectrum("Function", func=lambda l: np.exp(-0.5 * (l - 460) ** 2 / 20 ** 2))
+    RT.add(ot.Filter(ot.CircularSurface(r=1), pos=[0, 0, 45.2], spectrum=fspec))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[2, 2]), pos=[0, 0, 0]))
+    RT.add(ot.Detector(ot.SphericalSurface(R=-1.1, r=1), pos=[0, 0, 40]))
+    RT.add(ot.IdealLens(r=3, D=1, pos=[0, 0, RT.outline[5] - 1]))
+    return RT
+
+
+def arizona_eye_scene(ot, **rt_args):
+    """BASELINE.json configs[2] / C3 geometry: presets.geometry.arizona_eye(adaptation=1/0.6, pupil=4)
+    (examples/arizona_eye_model.py:15-57) lit by a rectangular area source converging onto the eye."""
+    RT = ot.Raytracer(outline=[-10, 10, -10, 10, -610, 28], **rt_args)
+    RT.add(ot.RaySource(ot.RectangularSurface(dim=[8.39, 8.39]), divergence="Isotropic", div_angle=0.25,
+                        orientation="Converging", conv_pos=[0, 0, 0], pos=[0, 0, -600],
+                        spectrum=ot.LightSpectrum("Rectangle", wl0=420., wl1=680.)))
+    RT.add(ot.presets.geometry.arizona_eye(adaptation=1 / 0.6, pupil=4))
+    return RT
+
+
+def hurb_slit_lens(ot, **rt_args):
+    """BASELINE.json configs[4] / C5: slit aperture (examples/hurb_apertures.py:30-36) in water followed by a
+    biconvex lens, HURB edge bending on, polarisation tracked."""
+    RT = ot.Raytracer(outline=[-3, 3, -3, 3, -5, 40], n0=ot.RefractionIndex("Constant", n=1.33),
+                      use_hurb=True, **rt_args)
+    RT.add(ot.RaySource(ot.RectangularSurface(dim=[0.05, 2]), divergence="None", s=[0, 0, 1], pos=[0, 0, -4],
+                        spectrum=ot.LightSpectrum("Monochromatic", wl=550.)))
+    RT.add(ot.Aperture(ot.SlitSurface(dim=[2.5, 2.5], dimi=[0.05, 2]), pos=[0, 0, 0]))
+    RT.add(ot.Lens(ot.SphericalSurface(r=1.2, R=18), ot.SphericalSurface(r=1.2, R=-18), de=0.1,
+                   n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 12]))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[1.5, 1.5]), pos=[0, 0, 30]))
+    return RT
+
+
+def hurb_ring_ideal(ot, **rt_args):
+    """Ring aperture in front of an ideal lens with HURB (tests/hurb_geometry.py:10-82, n=1.2, ri=0.5, 580 nm)."""
+    zd = 100.
+    RT = ot.Raytracer(outline=[-15, 15, -15, 15, -6, zd + 10], use_hurb=True,
+                      n0=ot.RefractionIndex("Constant", n=1.2), **rt_args)
+    RT.add(ot.RaySource(ot.CircularSurface(r=0.5), s=[0, 0, 1], pos=[0, 0, -5],
+                        spectrum=ot.LightSpectrum("Monochromatic", wl=580.)))
+    RT.add(ot.Aperture(ot.RingSurface(r=1.5, ri=0.5), pos=[0, 0, -0.001]))
+    RT.add(ot.IdealLens(1.5, 1 / zd * 1000, pos=[0, 0, 0]))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[0.5, 0.5]), pos=[0, 0, zd]))
+    return RT
+
+
+def asphere_scene(ot, **rt_args):
+    """Synthetic scene for the numeric (Illinois) hit search: an aspheric singlet, a conic (k != 0) lens, a
+    rectangular filter and a rotated rectangular aperture; tilted Lambertian disc source so that some rays
+    miss, hit the outline or are totally reflected."""
+    RT = ot.Raytracer(outline=[-8, 8, -8, 8, -12, 50], **rt_args)
+    RT.add(ot.RaySource(ot.CircularSurface(r=2.0), divergence="Lambertian", div_angle=14, pos=[0.3, -0.2, -10],
+                        s=[0.02, 0.05, 1], spectrum=ot.LightSpectrum("Gaussian", mu=540., sig=40.),
+                        polarization="Uniform"))
+    with ot.global_options.no_warnings():
+        front = ot.AsphericSurface(r=4, R=12, k=-0.8, coeff=[2e-3, -4e-5, 3e-7])
+        back = ot.AsphericSurface(r=4, R=-15, k=0.3, coeff=[-1e-3, 2e-5])
+    RT.add(ot.Lens(front, back, de=0.4, pos=[0, 0, 0],
+                   n=ot.RefractionIndex("Sellmeier1", coeff=[1.03961212, 0.00600069867, 0.231792344,
+                                                             0.0200179144, 1.01046945, 103.560653])))
+    filt = ot.RectangularSurface(dim=[5, 4])
+    RT.add(ot.Filter(filt, pos=[0, 0, 6], spectrum=ot.TransmissionSpectrum("Gaussian", mu=550., sig=60., val=0.9)))
+    RT.add(ot.Lens(ot.ConicSurface(r=3.5, R=9, k=-2.1), ot.ConicSurface(r=3.5, R=-30, k=1.5), de=0.3,
+                   pos=[0, 0.1, 12], n=ot.RefractionIndex("Schott", coeff=[2.7, -0.01, 0.03, 1e-3, -1e-4, 1e-5]),
+                   n2=ot.RefractionIndex("Constant", n=1.2)))
+    ap = ot.RectangularSurface(dim=[6, 6])
+    ap.rotate(20)
+    slit = ot.SlitSurface(dim=[7, 7], dimi=[3, 2])
+    slit.rotate(-12)
+    RT.add(ot.Aperture(slit, pos=[0, 0, 20]))
+    RT.add(ot.Filter(ap, pos=[0, 0, 24], spectrum=ot.TransmissionSpectrum("Rectangle", wl0=450., wl1=640.,
+                                                                            val=0.8, inverse=True)))
+    RT.add(ot.Detector(ot.SphericalSurface(r=5, R=-20), pos=[0, 0, 35]))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[8, 8]), pos=[0, 0, 30]))
+    return RT
+
+
+SCENES = {
+    "c1_single_lens": (c1_single_lens, 2000),
+    "double_gauss": (double_gauss, 1500),
+    "mixed_geometry": (mixed_geometry, 2500),
+    "arizona_eye": (arizona_eye_scene, 2000),
+    "hurb_slit_lens": (hurb_slit_lens, 2000),
+    "hurb_ring_ideal": (hurb_ring_ideal, 2000),
+    "asphere": (asphere_scene, 2500),
+}
+
+
+def surface_zoo(ot):
+    """name -> surface, covering every flavour the device kernels implement."""
+    z = {}
+    z["circle"] = ot.CircularSurface(r=2.5)
+    z["ring"] = ot.RingSurface(r=3.0, ri=0.7)
+    z["rect"] = ot.RectangularSurface(dim=[3.0, 2.0])
+    r2 = ot.RectangularSurface(dim=[4.0, 1.5])
+    r2.rotate(33.0)
+    z["rect_rot"] = r2
+    z["slit"] = ot.SlitSurface(dim=[4.0, 4.0], dimi=[0.2, 2.5])
+    s2 = ot.SlitSurface(dim=[5.0, 3.0], dimi=[1.0, 0.3])
+    s2.rotate(-20.0)
+    z["slit_rot"] = s2
+    z["sphere_pos"] = ot.SphericalSurface(r=3.0, R=8.0)
+    z["sphere_neg"] = ot.SphericalSurface(r=2.0, R=-5.0)
+    z["conic_m025"] = ot.ConicSurface(r=3.0, R=7.8, k=-0.25)
+    z["conic_m75"] = ot.ConicSurface(r=3.0, R=12.0, k=-7.5)
+    z["conic_p3"] = ot.ConicSurface(r=2.0, R=-9.0, k=3.0)
+    z["conic_parab"] = ot.ConicSurface(r=3.0, R=6.0, k=-1.0)
+    z["asphere_a"] = ot.AsphericSurface(r=4, R=12, k=-0.8, coeff=[2e-3, -4e-5, 3e-7])
+    z["asphere_b"] = ot.AsphericSurface(r=3, R=-15, k=0.3, coeff=[-1e-3, 2e-5])
+    for j, (name, s) in enumerate(z.items()):
+        s.move_to([0.1 * j - 0.5, 0.3 - 0.07 * j, 2.0 + 0.5 * j])
+    return z
+
+
+MEDIA = {
+    "Constant": dict(n=1.5),
+    "Abbe": dict(n=1.797, V=45.3),
+    "Abbe_lines": dict(n=1.6, V=30.0, lines=[479.9914, 546.0740, 643.8469]),
+    "Cauchy": dict(coeff=[1.49, 0.00354, 1e-5, 2e-7]),
+    "Conrady": dict(coeff=[1.5, 0.01, 0.0005]),
+    "Sellmeier1": dict(coeff=[1.03961212, 0.00600069867, 0.231792344, 0.0200179144, 1.01046945, 103.560653]),
+    "Sellmeier2": dict(coeff=[1.2, 0.9, 0.1, 0.002, 0.12]),
+    "Sellmeier3": dict(coeff=[0.7, 0.005, 0.4, 0.014, 0.9, 97.9, 0.01, 0.02]),
+    "Sellmeier4": dict(coeff=[1.9, 0.4, 0.02, 1.0, 100.0]),
+    "Sellmeier5": dict(coeff=[0.6, 0.004, 0.4, 0.013, 0.8, 95.0, 0.01, 0.02, 0.002, 0.03]),
+    "Schott": dict(coeff=[2.27, -0.01, 0.01, 1e-4, -1e-6, 1e-7]),
+    "Herzberger": dict(coeff=[1.5, 0.005, 1e-4, -0.002, 1e-4, -1e-5]),
+    "Handbook of Optics 1": dict(coeff=[2.2, 0.01, 0.02, 0.01]),
+    "Handbook of Optics 2": dict(coeff=[1.2, 1.0, 0.01, 0.01]),
+    "Extended": dict(coeff=[2.25, -0.009, 0.012, 2e-4, -1e-5, 1e-6, -1e-8, 1e-9]),
+    "Extended2": dict(coeff=[2.25, -0.009, 0.012, 2e-4, -1e-5, 1e-6, 1e-4, -1e-5]),
+    "Extended3": dict(coeff=[2.25, -0.009, 1e-4, 0.012, 2e-4, -1e-5, 1e-6, -1e-7, 1e-9]),
+    "Data": dict(wls=np.linspace(380., 780., 41), vals=1.5 + 0.1 * np.exp(-np.linspace(0, 3, 41))),
+}
+
+
+def transmission_zoo(ot):
+    return {
+        "Constant": ot.TransmissionSpectrum("Constant", val=0.6),
+        "Constant_inv": ot.TransmissionSpectrum("Constant", val=0.6, inverse=True),
+        "Rectangle": ot.TransmissionSpectrum("Rectangle", wl0=450., wl1=640., val=0.8),
+        "Gaussian": ot.TransmissionSpectrum("Gaussian", mu=550., sig=60., val=0.9),
+        "Gaussian_inv": ot.TransmissionSpectrum("Gaussian", mu=500., sig=30., val=1.0, inverse=True),
+        "Data": ot.TransmissionSpectrum("Data", wls=np.linspace(400., 700., 31), vals=np.linspace(0.1, 0.9, 31) ** 2),
+    }
