@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ray-surface-intersections/s of Raytracer.trace() on the double-Gauss scene.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--no-pol]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one bundle of synthetic rays: on-device ray generation from
+the five point sources, all 15 tracing surfaces, all section stores (what `RT.trace(N)` covers in
+tests/benchmark.py:81-86 of the reference).  Workload = BASELINE.json configs[1]: double_gauss.py geometry,
+10 M rays per GPU, 3 wavelengths (FDC lines), polarisation on.  Ray storage is allocated once and stays
+resident in HBM; every step uses a fresh seed.  Multi-GPU: rays are sharded, every rank traces its own
+bundle (weak scaling), no data-path collective inside the step; after the timed region the detector
+histograms are all-reduced once over RCCL to exercise the exchange step.
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying `roofline` (dominant kernel:
+algorithmic bytes / HIP-event kernel time against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle,
+a scalar port of the reference, timed on a bounded sample on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU and step")
+    ap.add_argument("--no-pol", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(RT, scene, seconds: float) -> dict:
+    """Time the CPU oracle (kind "port": oracle/oracle.c, scalar restatement of the reference's NumPy path,
+    pinned to it by tests/test_oracle_golden.py) on a bounded sample of the same workload: rays generated
+    by the device kernel for this scene, traced through all 15 surfaces on ONE host core."""
+    import oracle_bridge as ob  # checker / baseline only
+    M = scene.nt - 2
+    r = RT.rays
+    n_avail = r.N
+
+    def run(n):
+        rays = ob.HostRays(n, scene.nt, RT.no_pol)
+        p0 = r.p_list[:n, 0]
+        d = r.p_list[:n, 1] - p0
+        s0 = d / np.linalg.norm(d, axis=1)[:, None]
+        rays.set_initial(p0, s0, None if RT.no_pol else r.pol_list[:n, 0], r.w_list[:n, 0], r.wl_list[:n])
+        t0 = time.perf_counter()
+        ob.trace(scene.desc, rays, None)
+        return time.perf_counter() - t0
+
+    n = min(50_000, n_avail)
+    t = run(n)
+    n2 = int(min(n_avail, max(n, n * seconds / max(t, 1e-6))))
+    if n2 > n:
+        t, n = run(n2), n2
+    return {"value": n * M / t, "unit": "ray-surface-intersections/s", "cores": 1, "kind": "port",
+            "sample": f"{n} rays x {M} surfaces of the same scene (device-generated rays), {t:.1f} s on 1 core"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import optrace_amd as ot
+    from optrace_amd import _capi
+    from optrace_amd._device import ptr, stream_ptr
+    import scenes
+
+    lib = _capi.load_library()
+    N = args.rays
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, no_pol=args.no_pol, seed=1000 + rank)
+        RT._geometry_checks()
+        assert not RT.geometry_error
+        scene = RT._compile()
+        nt = scene.nt
+        M = nt - 2
+        RT.rays.init(RT.ray_sources, N, nt, RT.no_pol)
+    rays = RT.rays._rays_struct()
+    tab = RT.rays._source_table()
+    rng = RT.rays._source_ranges()
+    msgs = torch.zeros(5 * nt + 1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step(seed):
+        _capi.check(lib.ot_generate_and_trace(RT._scene_handle, tab.handle, rng, len(rng), seed, C.byref(rays),
+                                              ptr(msgs), stream_ptr()))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(17 + i)
+    barrier()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record(stream)  # same stream the kernel is launched on
+        step(1000 + rank + 7919 * i)
+        ev1[i].record(stream)
+    barrier()
+    t_local = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    t = torch.tensor([t_local], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_max = float(t.item())
+
+    # ---- after the timed region: detector image + the one exchange step (histogram all-reduce) ----------
+    RT.rays.lock()
+    RT._last_trace_snapshot = RT.tracing_snapshot()
+    RT._msgs = msgs.cpu().numpy()[:-1].reshape(5, nt)
+    det_extent = [-45., 45., -45., 45.]
+    torch.cuda.synchronize()
+    td0 = time.perf_counter()
+    with ot.global_options.no_warnings():
+        img = RT.detector_image(extent=det_extent, _keep_on_device=True)
+    torch.cuda.synchronize()
+    t_det = time.perf_counter() - td0
+    hist = img._dev
+    t_red = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        t_red = time.perf_counter() - tr0
+    total_power = float(hist[..., 3].sum().item())
+
+    if rank == 0:
+        pol = not args.no_pol
+        bytes_per_ray = nt * (48 if pol else 36) + 28  # compulsory RayStorage traffic of trace()
+        b_trace = N * bytes_per_ray
+        achieved = b_trace / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ray-surface-intersections/s",
+            "value": world * N * M * args.steps / t_max,
+            "unit": "ray-surface-intersections/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps,
+            "ms_per_surface_per_Mray": 1e3 * t_max / args.steps / M / (N / 1e6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "double_gauss.py geometry (15 tracing surfaces, 5 point sources, FDC lines), "
+                                   f"{N} rays per GPU, polarisation {'on' if pol else 'off'}, on-device generation",
+                       "rays_per_gpu": N, "surfaces": M, "sections": nt, "parallelism": f"ray-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "trace_kernel (ot_generate_and_trace)", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": b_trace},
+            "detector": {"rays_per_s": N / t_det, "ms": 1e3 * t_det, "allreduce_ms": 1e3 * t_red,
+                         "image_power_all_ranks": total_power},
+        }
+        if not args.skip_cpu:
+            out["cpu_baseline"] = cpu_baseline(RT, scene, args.cpu_seconds)
+            out["cpu_baseline"]["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -273,8 +273,9 @@ int ot_rays_generate(const ot_sources* src, const ot_source_range* ranges, int32
 /* ---- tracing ---------------------------------------------------------------------------------- */
 /* Raytracer.trace / sub_trace (raytracer.py:262-415) for rays whose section 0 is already in `rays`
  * (injected or produced by ot_rays_generate).  Fills sections 1..nt-1 of p/w/n/pol, n[:,0], the
- * final directions in rays->s and ADDS the per-section counters to msgs (device, int64[5*nt],
- * row-major (info, section)).  hurb_normals: optional device array (2*n_hurb_elements*N f64:
+ * final directions in rays->s and ADDS the per-section counters to msgs (device, int64[5*nt + 1]:
+ * the counters row-major (info, section), then one word that is set non-zero if a numeric hit search
+ * ran into the 200-iteration timeout, where the reference raises TimeoutError surface.py:403).  hurb_normals: optional device array (2*n_hurb_elements*N f64:
  * for the j-th HURB aperture, N standard-normal draws for the a axis then N for the b axis,
  * replacing np.random.normal raytracer.py:468-469); NULL = device RNG keyed by `seed`. */
 int ot_trace(const ot_scene* scene, const ot_rays* rays, const double* hurb_normals, uint64_t seed,
@@ -288,7 +289,8 @@ int ot_generate_and_trace(const ot_scene* scene, const ot_sources* src,
 
 /* ---- leaf operators (public Surface / RefractionIndex methods) ---------------------------------- */
 /* Surface.find_hit (surface.py:307, conic_surface.py:126): p, s are (n,3) F-order device arrays;
- * outputs p_hit (n,3) F-order, is_hit (n) uint8, ill (n) uint8 (all zero for analytic surfaces). */
+ * outputs p_hit (n,3) F-order, is_hit (n) uint8, ill (n) uint8: bit 0 = ill-conditioned bracket
+ * (always 0 for analytic surfaces), bit 1 = the iteration timed out (surface.py:403). */
 int ot_surface_find_hit(const ot_surface* surf, int64_t n, const double* p, const double* s,
                         double* p_hit, uint8_t* is_hit, uint8_t* ill, void* stream);
 /* Surface.normals (surface.py:247, conic_surface.py:70, function_surface_2d.py:202): out (n,3) F-order */
@@ -321,7 +323,7 @@ int ot_refraction_index(const ot_medium* medium, const double* table_pool, int64
  * are retried on the next section, and the optional sphere projection is applied.
  * Outputs are dense per-ray arrays (count entries): ph (count,3) F-order projected hit, hw f32 weight
  * (0 = no valid hit; the reference drops those rows, raytracer.py:1023), and ill_count (device
- * int64, ADDED to).  extent4 (device f64[4], may be NULL): running xmin,xmax,ymin,ymax of valid hits
+ * int64[2], ADDED to: [0] ill-conditioned rays, [1] rays whose numeric hit search timed out).  extent4 (device f64[4], may be NULL): running xmin,xmax,ymin,ymax of valid hits
  * (raytracer.py:1044-1046), must be initialised by the caller to +inf,-inf,+inf,-inf. */
 int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
                      int32_t projection, double* ph, float* hw, double* extent4, int64_t* ill_count,

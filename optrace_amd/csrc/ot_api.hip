@@ -1,0 +1,835 @@
+// C-ABI of the MI355X tracing core (include/optrace_amd.h): host entry points + HIP kernels for gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared (see Makefile).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ot_detector.hpp"
+#include "ot_device.hpp"
+#include "ot_generate.hpp"
+#include "ot_scene.hpp"
+#include "ot_trace.hpp"
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(OT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+extern "C" int ot_abi_version(void) { return OT_ABI_VERSION; }
+extern "C" const char* ot_last_error(void) { return g_err.c_str(); }
+extern "C" int ot_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return OT_ERR_NO_DEVICE;
+    return n;
+}
+
+static int require_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(OT_ERR_NO_DEVICE, "no HIP device available; this library has no CPU fallback");
+    return OT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scene compilation (host)
+// ---------------------------------------------------------------------------------------------------------
+static double conic_sag(double rho, double k1rho2, double r2) { return rho * r2 / (1 + std::sqrt(1 - k1rho2 * r2)); }
+
+static int compile_surface(const ot_surface& s, SurfDev& d) {
+    std::memset(&d, 0, sizeof(d));
+    const double NE = OT_N_EPS_SURF;
+    d.kind = s.kind;
+    d.ncoeff = s.ncoeff;
+    d.flat = (s.z_max == s.z_min);
+    d.px = s.pos[0];
+    d.py = s.pos[1];
+    d.pz = s.pos[2];
+    d.z_min = s.z_min;
+    d.z_max = s.z_max;
+    d.z_lo = s.z_min - NE;
+    d.z_hi = s.z_max + NE;
+    d.z_beh = s.z_max + NE;
+    d.zt1 = s.z_min - OT_C_EPS / 10;
+    d.zt2 = s.z_max + OT_C_EPS / 10;
+    d.edge_val = s.z_max;
+    switch (s.kind) {
+        case OT_SURF_CIRCLE:
+            d.r_eps2 = std::pow(s.r + NE, 2.0);
+            break;
+        case OT_SURF_RING:
+            d.r_eps2 = std::pow(s.r + NE, 2.0);
+            d.ri_eps2 = std::pow(s.ri - NE, 2.0);
+            d.ri = s.ri;
+            break;
+        case OT_SURF_RECT:
+        case OT_SURF_SLIT: {
+            d.rot = (s.angle != 0.0);
+            d.cna = std::cos(-s.angle);
+            d.sna = std::sin(-s.angle);
+            d.cpa = std::cos(s.angle);
+            d.spa = std::sin(s.angle);
+            double xs = -s.dim[0] / 2, xe = s.dim[0] / 2, ys = -s.dim[1] / 2, ye = s.dim[1] / 2;
+            d.ox_lo = xs - NE;
+            d.ox_hi = xe + NE;
+            d.oy_lo = ys - NE;
+            d.oy_hi = ye + NE;
+            if (s.kind == OT_SURF_SLIT) {
+                double xsi = -s.dimi[0] / 2, xei = s.dimi[0] / 2, ysi = -s.dimi[1] / 2, yei = s.dimi[1] / 2;
+                d.ix_lo = xsi + NE;
+                d.ix_hi = xei - NE;
+                d.iy_lo = ysi + NE;
+                d.iy_hi = yei - NE;
+                d.hdx = s.dimi[0] / 2;
+                d.hdy = s.dimi[1] / 2;
+            }
+            break;
+        }
+        case OT_SURF_CONIC:
+        case OT_SURF_ASPHERE: {
+            if (s.R == 0.0 || !std::isfinite(s.R)) return fail(OT_ERR_INVALID, "surface: R must be finite and non-zero");
+            if (s.kind == OT_SURF_ASPHERE && (s.ncoeff < 1 || s.ncoeff > OT_MAX_ASPH))
+                return fail(OT_ERR_UNSUPPORTED, "asphere: ncoeff out of range");
+            d.r_eps2 = std::pow(s.r + NE, 2.0);
+            d.k = s.k;
+            d.k1 = s.k + 1;
+            d.rho = 1 / s.R;
+            d.nrho = -d.rho;
+            d.rho2 = std::pow(d.rho, 2.0);
+            d.k1rho2 = (s.k + 1) * d.rho2;
+            d.krho2 = s.k * d.rho2;
+            d.inv_rho = 1 / d.rho;
+            d.two_inv_rho = 2 / d.rho;
+            for (int j = 0; j < s.ncoeff && j < OT_MAX_ASPH; j++) {
+                d.coeff[j] = s.coeff[j];
+                d.dcoeff[j] = s.coeff[j] * (double)(2 * (j + 1));
+            }
+            // Surface.values outside the mask: pos_z + _values(r - N_EPS, 0) (surface.py:153-162)
+            if (!d.flat) {
+                double re = s.r - NE;
+                double v;
+                if (s.kind == OT_SURF_CONIC) {
+                    v = conic_sag(d.rho, d.k1rho2, re * re + 0.0 * 0.0);
+                } else {
+                    double r = std::sqrt(re * re + 0.0 * 0.0);
+                    v = d.rho * (r * r) / (1 + std::sqrt(1 - d.k1rho2 * (r * r)));
+                    double y = 0.0;
+                    for (int j = s.ncoeff - 1; j >= 0; j--) {
+                        y = y * r + s.coeff[j];
+                        y = y * r + 0.0;
+                    }
+                    y = y * r + 0.0;
+                    v += y;
+                }
+                d.edge_val = s.pos[2] + v;
+            }
+            break;
+        }
+        default:
+            return fail(OT_ERR_INVALID, "surface: unknown kind");
+    }
+    return OT_OK;
+}
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
+    if (!desc || !out) return fail(OT_ERR_INVALID, "ot_scene_create: null argument");
+    if (int rc = require_device()) return rc;
+    if (desc->n_elements < 1 || desc->n_surfaces < 1 || desc->n_media < 1)
+        return fail(OT_ERR_INVALID, "scene needs at least one element, surface and medium");
+    if (desc->n0 < 0 || desc->n0 >= desc->n_media) return fail(OT_ERR_INVALID, "scene: n0 out of range");
+
+    std::vector<SurfDev> surfs(desc->n_surfaces);
+    for (int i = 0; i < desc->n_surfaces; i++)
+        if (int rc = compile_surface(desc->surfaces[i], surfs[i])) return rc;
+
+    std::vector<ElemDev> elems(desc->n_elements);
+    int nt = 2, n_hurb = 0;
+    for (int i = 0; i < desc->n_elements; i++) {
+        const ot_element& e = desc->elements[i];
+        ElemDev& d = elems[i];
+        std::memset(&d, 0, sizeof(d));
+        d.kind = e.kind;
+        d.front = e.front;
+        d.back = e.back;
+        d.n_lens = e.n_lens;
+        d.n_after = e.n_after;
+        d.filter = e.filter;
+        d.hurb = (desc->use_hurb && e.hurb && e.kind == OT_EL_APERTURE && i != desc->n_elements - 1) ? 1 : 0;
+        d.hurb_slot = d.hurb ? n_hurb++ : -1;
+        if (e.front < 0 || e.front >= desc->n_surfaces) return fail(OT_ERR_INVALID, "element: front surface out of range");
+        switch (e.kind) {
+            case OT_EL_LENS:
+                if (e.back < 0 || e.back >= desc->n_surfaces) return fail(OT_ERR_INVALID, "lens: back surface out of range");
+                if (e.n_lens < 0 || e.n_lens >= desc->n_media || e.n_after < 0 || e.n_after >= desc->n_media)
+                    return fail(OT_ERR_INVALID, "lens: medium out of range");
+                nt += 2;
+                break;
+            case OT_EL_IDEAL_LENS:
+                if (e.n_after < 0 || e.n_after >= desc->n_media) return fail(OT_ERR_INVALID, "ideal lens: medium out of range");
+                if (e.D == 0.0) return fail(OT_ERR_INVALID, "ideal lens: optical power must be non-zero");
+                d.D = e.D;
+                d.f = 1000 / e.D;
+                d.fsign = (d.f > 0) - (d.f < 0);
+                nt += 1;
+                break;
+            case OT_EL_FILTER:
+                if (e.filter < 0 || e.filter >= desc->n_filters) return fail(OT_ERR_INVALID, "filter index out of range");
+                nt += 1;
+                break;
+            case OT_EL_APERTURE:
+                if (d.hurb && surfs[e.front].kind != OT_SURF_RING && surfs[e.front].kind != OT_SURF_SLIT)
+                    return fail(OT_ERR_UNSUPPORTED, "HURB is only defined for ring and slit apertures (raytracer.py:548-552)");
+                nt += 1;
+                break;
+            default:
+                return fail(OT_ERR_INVALID, "element: unknown kind");
+        }
+    }
+    nt -= 1;  // sections = tracing surfaces + 2; the loop above started from 2 and the end aperture is a surface
+
+    std::vector<FilterDev> filts(desc->n_filters > 0 ? desc->n_filters : 1);
+    for (int i = 0; i < desc->n_filters; i++) {
+        const ot_filter& f = desc->filters[i];
+        FilterDev& d = filts[i];
+        std::memset(&d, 0, sizeof(d));
+        d.type = f.type;
+        d.inverse = f.inverse;
+        d.tab_len = f.tab_len;
+        d.tab_off = f.tab_off;
+        d.val = f.val;
+        d.wl0 = f.wl0;
+        d.wl1 = f.wl1;
+        d.mu32 = (float)f.mu;
+        d.den32 = (float)(2 * std::pow(f.sig, 2.0));
+        d.val32 = (float)f.val;
+        if ((f.type == OT_T_DATA || f.type == OT_T_LINES) &&
+            (f.tab_off < 0 || f.tab_off + 2 * (int64_t)f.tab_len > desc->table_pool_len))
+            return fail(OT_ERR_INVALID, "filter table outside the pool");
+    }
+    for (int i = 0; i < desc->n_media; i++) {
+        const ot_medium& m = desc->media[i];
+        if ((m.model == OT_N_DATA || m.model == OT_N_LINES) &&
+            (m.tab_off < 0 || m.tab_off + 2 * (int64_t)m.tab_len > desc->table_pool_len))
+            return fail(OT_ERR_INVALID, "medium table outside the pool");
+    }
+
+    // one device blob: header | surfaces | elements | media | filters | pool
+    size_t o_hdr = 0;
+    size_t o_surf = align_up(o_hdr + sizeof(SceneDev));
+    size_t o_elem = align_up(o_surf + sizeof(SurfDev) * surfs.size());
+    size_t o_med = align_up(o_elem + sizeof(ElemDev) * elems.size());
+    size_t o_flt = align_up(o_med + sizeof(ot_medium) * desc->n_media);
+    size_t o_pool = align_up(o_flt + sizeof(FilterDev) * filts.size());
+    size_t pool_n = desc->table_pool_len > 0 ? (size_t)desc->table_pool_len : 1;
+    size_t total = align_up(o_pool + sizeof(double) * pool_n);
+
+    std::vector<char> host(total, 0);
+    char* blob = nullptr;
+    HIP_TRY(hipMalloc((void**)&blob, total));
+
+    SceneDev h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.outline, desc->outline, sizeof(h.outline));
+    h.n_surfaces = desc->n_surfaces;
+    h.n_elements = desc->n_elements;
+    h.n_media = desc->n_media;
+    h.n_filters = desc->n_filters;
+    h.n0 = desc->n0;
+    h.no_pol = desc->no_pol;
+    h.use_hurb = desc->use_hurb;
+    h.nt = nt;
+    h.n_hurb = n_hurb;
+    h.hurb_factor = desc->hurb_factor;
+    h.surfaces = (const SurfDev*)(blob + o_surf);
+    h.elements = (const ElemDev*)(blob + o_elem);
+    h.media = (const ot_medium*)(blob + o_med);
+    h.filters = (const FilterDev*)(blob + o_flt);
+    h.pool = (const double*)(blob + o_pool);
+    h.pool_len = desc->table_pool_len;
+
+    std::memcpy(host.data() + o_hdr, &h, sizeof(h));
+    std::memcpy(host.data() + o_surf, surfs.data(), sizeof(SurfDev) * surfs.size());
+    std::memcpy(host.data() + o_elem, elems.data(), sizeof(ElemDev) * elems.size());
+    std::memcpy(host.data() + o_med, desc->media, sizeof(ot_medium) * desc->n_media);
+    std::memcpy(host.data() + o_flt, filts.data(), sizeof(FilterDev) * filts.size());
+    if (desc->table_pool_len > 0)
+        std::memcpy(host.data() + o_pool, desc->table_pool, sizeof(double) * desc->table_pool_len);
+    hipError_t e = hipMemcpy(blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        return fail(OT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+
+    ot_scene* sc = new ot_scene;
+    sc->h = h;
+    sc->d = (SceneDev*)(blob + o_hdr);
+    sc->blob = blob;
+    (void)hipGetDevice(&sc->device);
+    *out = sc;
+    return OT_OK;
+}
+
+extern "C" void ot_scene_destroy(ot_scene* sc) {
+    if (!sc) return;
+    (void)hipFree(sc->blob);
+    delete sc;
+}
+
+extern "C" int ot_scene_sections(const ot_scene* sc) { return sc ? sc->h.nt : OT_ERR_INVALID; }
+
+// ---------------------------------------------------------------------------------------------------------
+// sources (host)
+// ---------------------------------------------------------------------------------------------------------
+static double gauss_peak1(double x, double mu, double sig) {  // color/srgb.py:447-457
+    return 1 / (sig * std::sqrt(2 * M_PI)) * std::exp(-0.5 / (sig * sig) * (x - mu) * (x - mu));
+}
+
+static double srgb_primary(int c, double wl) {  // color/srgb.py:469-509
+    if (wl < 380. || wl > 780.) return 0.0;
+    switch (c) {
+        case 0: return 75.1660756583 * 0.951190393 * (gauss_peak1(wl, 639.854491, 30.0) + 0.0500907584 * gauss_peak1(wl, 418.905848, 80.6220465));
+        case 1: return 83.4999222966 * 1 * gauss_peak1(wl, 539.13108974, 33.31164968);
+        default: return 47.99521746361 * 1.16364585503 * (gauss_peak1(wl, 454.833119, 20.1460206) + 0.184484176 * gauss_peak1(wl, 459.658190, 71.0927568));
+    }
+}
+
+static double srgb_to_linear(double v) {  // color/srgb.py:30-47
+    double a = 0.055, av = std::fabs(v);
+    if (av <= 0.04045) return 1 / 12.92 * v;
+    double sg = (v > 0) - (v < 0);
+    return sg * std::pow(1 / (1 + a) * (av + a), 2.4);
+}
+
+extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot_sources** out) {
+    if (!sources || !out || n_sources < 1) return fail(OT_ERR_INVALID, "ot_sources_create: bad argument");
+    if (int rc = require_device()) return rc;
+
+    std::vector<SourceDev> devs(n_sources);
+    std::vector<double> tabs;                 // all tables, offsets resolved after upload
+    std::vector<std::vector<size_t>> offs(n_sources, std::vector<size_t>(6, (size_t)-1));
+    auto push = [&](const double* p, size_t n) {
+        size_t o = tabs.size();
+        tabs.insert(tabs.end(), p, p + n);
+        return o;
+    };
+    bool any_rgb = false;
+    for (int i = 0; i < n_sources; i++) {
+        const ot_source& s = sources[i];
+        SourceDev& d = devs[i];
+        std::memset(&d, 0, sizeof(d));
+        d.shape = s.shape; d.divergence = s.divergence; d.div_2d = s.div_2d; d.orientation = s.orientation;
+        d.polarization = s.polarization; d.spectrum = s.spectrum; d.img_w = s.img_w; d.img_h = s.img_h;
+        std::memcpy(d.pos, s.pos, sizeof(d.pos));
+        d.r = s.r; d.ri = s.ri; d.dim[0] = s.dim[0]; d.dim[1] = s.dim[1];
+        d.ca = (s.angle != 0.0) ? std::cos(s.angle) : 1.0;
+        d.sa = (s.angle != 0.0) ? std::sin(s.angle) : 0.0;
+        d.div_rad = s.div_angle * (M_PI / 180.0);
+        d.div_sin = std::sin(d.div_rad);
+        d.div_axis = s.div_axis_angle * (M_PI / 180.0);
+        std::memcpy(d.s, s.s, sizeof(d.s));
+        std::memcpy(d.conv_pos, s.conv_pos, sizeof(d.conv_pos));
+        d.pol_angle = s.pol_angle;
+        d.wl = s.wl; d.wl0 = s.wl0; d.wl1 = s.wl1; d.mu = s.mu; d.sig = s.sig;
+        d.power = s.power;
+        if (s.spectrum == OT_SPEC_GAUSSIAN) {  // light_spectrum.py:117-118
+            d.gauss_xl = (1 + std::erf((s.wl0 - s.mu) / (std::sqrt(2.0) * s.sig))) / 2;
+            d.gauss_xr = (1 + std::erf((s.wl1 - s.mu) / (std::sqrt(2.0) * s.sig))) / 2;
+        }
+        if (s.shape < OT_SRC_POINT || s.shape > OT_SRC_IMAGE_GRAY) return fail(OT_ERR_INVALID, "source: unknown shape");
+        bool needs_spec = s.shape != OT_SRC_IMAGE_RGB && (s.spectrum == OT_SPEC_LINES || s.spectrum == OT_SPEC_TABLE);
+        if (needs_spec) {
+            if (!s.spec_tab || s.n_spec < 1) return fail(OT_ERR_INVALID, "source: spectrum table missing");
+            offs[i][0] = push(s.spec_tab, 2 * (size_t)s.n_spec);
+            d.n_spec = s.n_spec;
+        }
+        if (s.polarization == OT_POL_LIST || s.polarization == OT_POL_TABLE) {
+            if (!s.pol_tab || s.n_pol < 1) return fail(OT_ERR_INVALID, "source: polarisation table missing");
+            offs[i][1] = push(s.pol_tab, 2 * (size_t)s.n_pol);
+            d.n_pol = s.n_pol;
+        }
+        if (s.divergence == OT_DIV_TABLE) {
+            if (!s.div_tab || s.n_div < 2) return fail(OT_ERR_INVALID, "source: divergence table missing");
+            offs[i][2] = push(s.div_tab, 2 * (size_t)s.n_div);
+            d.n_div = s.n_div;
+        }
+        if (s.shape == OT_SRC_IMAGE_RGB || s.shape == OT_SRC_IMAGE_GRAY) {
+            size_t npx = (size_t)s.img_w * (size_t)s.img_h;
+            if (!s.img_pdf || npx < 1) return fail(OT_ERR_INVALID, "image source: pixel pdf missing");
+            std::vector<double> cdf(npx);
+            double acc = 0.0;  // np.cumsum of the pixel pdf (random.py:133 on f_ = f[f > 0]; zero-weight pixels
+            for (size_t j = 0; j < npx; j++) {  // keep the running sum and can never be selected by "next")
+                acc += s.img_pdf[j];
+                cdf[j] = acc;
+            }
+            offs[i][3] = push(cdf.data(), npx);
+            if (s.shape == OT_SRC_IMAGE_RGB) {
+                if (!s.img_rgb) return fail(OT_ERR_INVALID, "RGB image source: pixel colours missing");
+                std::vector<double> mix(2 * npx);
+                const double fr = 0.885651229244, fb = 0.775993481741;  // srgb.py:24-26
+                for (size_t j = 0; j < npx; j++) {
+                    double r = srgb_to_linear(s.img_rgb[3 * j]) * fr;
+                    double g = srgb_to_linear(s.img_rgb[3 * j + 1]);
+                    double b = srgb_to_linear(s.img_rgb[3 * j + 2]) * fb;
+                    double c0 = r, c1 = r + g, c2 = r + g + b;
+                    double den = (c2 != 0.0) ? c2 : 1.0;
+                    mix[2 * j] = c0 / den;
+                    mix[2 * j + 1] = c1 / den;
+                }
+                offs[i][4] = push(mix.data(), 2 * npx);
+                any_rgb = true;
+            }
+        }
+    }
+    size_t prim_off = (size_t)-1;
+    if (any_rgb) {  // inverse-CDF tables of the three primaries over wavelengths(5000) (srgb.py:528, 549-551)
+        std::vector<double> prim(3 * 2 * OT_PRIM_N);
+        for (int c = 0; c < 3; c++) {
+            double* x = prim.data() + (size_t)c * 2 * OT_PRIM_N;
+            double* F = x + OT_PRIM_N;
+            double prev = 0.0;
+            for (int j = 0; j < OT_PRIM_N; j++) {
+                x[j] = 380.0 + (780.0 - 380.0) * (double)j / (double)(OT_PRIM_N - 1);
+                double f = srgb_primary(c, x[j]);
+                F[j] = (j == 0) ? 0.0 : F[j - 1] + (f + prev) / 2;
+                prev = f;
+            }
+        }
+        prim_off = push(prim.data(), prim.size());
+    }
+
+    size_t o_tab = align_up(sizeof(SourceDev) * n_sources);
+    size_t total = align_up(o_tab + sizeof(double) * (tabs.size() + 1));
+    char* blob = nullptr;
+    HIP_TRY(hipMalloc((void**)&blob, total));
+    const double* dtab = (const double*)(blob + o_tab);
+    for (int i = 0; i < n_sources; i++) {
+        SourceDev& d = devs[i];
+        if (offs[i][0] != (size_t)-1) d.spec_tab = dtab + offs[i][0];
+        if (offs[i][1] != (size_t)-1) d.pol_tab = dtab + offs[i][1];
+        if (offs[i][2] != (size_t)-1) d.div_tab = dtab + offs[i][2];
+        if (offs[i][3] != (size_t)-1) d.img_cdf = dtab + offs[i][3];
+        if (offs[i][4] != (size_t)-1) d.img_rgb = dtab + offs[i][4];
+        if (prim_off != (size_t)-1) d.prim_tab = dtab + prim_off;
+    }
+    std::vector<char> host(total, 0);
+    std::memcpy(host.data(), devs.data(), sizeof(SourceDev) * n_sources);
+    if (!tabs.empty()) std::memcpy(host.data() + o_tab, tabs.data(), sizeof(double) * tabs.size());
+    hipError_t e = hipMemcpy(blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        return fail(OT_ERR_HIP, std::string("source upload: ") + hipGetErrorString(e));
+    }
+    ot_sources* so = new ot_sources;
+    so->d = (SourceDev*)blob;
+    so->n = n_sources;
+    so->blob = blob;
+    (void)hipGetDevice(&so->device);
+    *out = so;
+    return OT_OK;
+}
+
+extern "C" void ot_sources_destroy(ot_sources* s) {
+    if (!s) return;
+    (void)hipFree(s->blob);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------
+#define OT_MAX_RANGES 64
+
+struct RangeArgs {
+    int32_t n;
+    int32_t source[OT_MAX_RANGES];
+    int64_t first[OT_MAX_RANGES];
+    int64_t count[OT_MAX_RANGES];
+};
+
+OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& src) {
+    for (int k = 0; k < rg.n; k++) {
+        if (ray >= rg.first[k] && ray < rg.first[k] + rg.count[k]) {
+            g.j = (uint32_t)(ray - rg.first[k]);
+            g.n = (uint32_t)rg.count[k];
+            g.range = (uint32_t)k;
+            src = rg.source[k];
+            return true;
+        }
+    }
+    return false;
+}
+
+// Raytracer.trace: optional on-the-fly generation, then all elements.  256 threads = 4 waves per workgroup.
+template <bool POL, bool GEN>
+__global__ __launch_bounds__(256) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
+                                                    const SourceDev* __restrict__ sources, RangeArgs rg,
+                                                    const double* __restrict__ hurb_normals, uint64_t seed,
+                                                    unsigned long long* __restrict__ msgs) {
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= R.N) return;
+    const SceneDev& sc = *scp;
+    RayState r;
+    if (GEN) {
+        GenCtx g;
+        g.seed = seed;
+        g.gidx = (uint64_t)ray;
+        int src = 0;
+        if (!locate_range(rg, ray, g, src)) return;
+        NewRay nr = generate_ray(sources[src], g, !POL);
+        r.p = nr.p;
+        r.s = nr.s;
+        r.w = nr.w;
+        r.wl = nr.wl;
+        r.polx = (float)nr.polx;
+        r.poly = (float)nr.poly;
+        r.polz = (float)nr.polz;
+        R.wl[ray] = r.wl;
+    } else {
+        const int64_t N = R.N, nt = R.nt;
+        r.p.x = R.p[ray];
+        r.p.y = R.p[ray + N * nt];
+        r.p.z = R.p[ray + N * 2 * nt];
+        r.s.x = R.s[ray];
+        r.s.y = R.s[ray + N];
+        r.s.z = R.s[ray + 2 * N];
+        r.w = R.w[ray];
+        r.wl = R.wl[ray];
+        r.polx = r.poly = r.polz = 0.f;
+        if (POL) {
+            r.polx = R.pol[ray];
+            r.poly = R.pol[ray + N * nt];
+            r.polz = R.pol[ray + N * 2 * nt];
+        }
+    }
+    bool ok = trace_ray<POL>(sc, R, ray, r, hurb_normals, seed, msgs);
+    if (!ok) atomicOr(&msgs[OT_N_INFOS * sc.nt], 1ull);  // numeric hit search timed out (surface.py:403)
+}
+
+// RaySource.create_rays only: writes section 0 (ot_rays_generate)
+template <bool POL>
+__global__ __launch_bounds__(256) void generate_kernel(ot_rays R, const SourceDev* __restrict__ sources, RangeArgs rg,
+                                                       uint64_t seed) {
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= R.N) return;
+    GenCtx g;
+    g.seed = seed;
+    g.gidx = (uint64_t)ray;
+    int src = 0;
+    if (!locate_range(rg, ray, g, src)) return;
+    NewRay nr = generate_ray(sources[src], g, !POL);
+    const int64_t N = R.N, nt = R.nt;
+    R.p[ray] = nr.p.x;
+    R.p[ray + N * nt] = nr.p.y;
+    R.p[ray + N * 2 * nt] = nr.p.z;
+    R.s[ray] = nr.s.x;
+    R.s[ray + N] = nr.s.y;
+    R.s[ray + 2 * N] = nr.s.z;
+    R.w[ray] = nr.w;
+    R.wl[ray] = nr.wl;
+    if (POL) {
+        R.pol[ray] = (float)nr.polx;
+        R.pol[ray + N * nt] = (float)nr.poly;
+        R.pol[ray + N * 2 * nt] = (float)nr.polz;
+    }
+}
+
+// ---- leaf kernels (one lane per element) -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void find_hit_kernel(SurfDev sf, int64_t n, const double* __restrict__ p,
+                                                       const double* __restrict__ s, double* __restrict__ ph_out,
+                                                       uint8_t* __restrict__ hit_out, uint8_t* __restrict__ ill_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 pp = {p[i], p[i + n], p[i + 2 * n]}, ss = {s[i], s[i + n], s[i + 2 * n]}, ph;
+    bool hit, ill;
+    bool ok = find_hit(sf, pp, ss, ph, hit, ill);
+    ph_out[i] = ph.x;
+    ph_out[i + n] = ph.y;
+    ph_out[i + 2 * n] = ph.z;
+    hit_out[i] = hit;
+    ill_out[i] = (uint8_t)((ill ? 1 : 0) | (ok ? 0 : 2));
+}
+
+__global__ __launch_bounds__(256) void normals_kernel(SurfDev sf, int64_t n, const double* __restrict__ x,
+                                                      const double* __restrict__ y, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 nn = surf_normal(sf, x[i], y[i]);
+    out[i] = nn.x;
+    out[i + n] = nn.y;
+    out[i + 2 * n] = nn.z;
+}
+
+__global__ __launch_bounds__(256) void mask_kernel(SurfDev sf, int64_t n, const double* __restrict__ x,
+                                                   const double* __restrict__ y, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = surf_mask(sf, x[i], y[i]);
+}
+
+__global__ __launch_bounds__(256) void values_kernel(SurfDev sf, int64_t n, const double* __restrict__ x,
+                                                     const double* __restrict__ y, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = surf_values(sf, x[i], y[i]);
+}
+
+__global__ __launch_bounds__(256) void hurb_props_kernel(SurfDev sf, int64_t n, const double* __restrict__ x,
+                                                         const double* __restrict__ y, double* __restrict__ a_,
+                                                         double* __restrict__ b_, double* __restrict__ b,
+                                                         uint8_t* __restrict__ inside) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, bb;
+    V3 bv;
+    bool in;
+    hurb_props(sf, x[i], y[i], a, bb, bv, in);
+    a_[i] = a;
+    b_[i] = bb;
+    b[i] = bv.x;
+    b[i + n] = bv.y;
+    b[i + 2 * n] = bv.z;
+    inside[i] = in;
+}
+
+__global__ __launch_bounds__(256) void refraction_index_kernel(ot_medium md, const double* __restrict__ pool, int64_t n,
+                                                               const float* __restrict__ wl, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = medium_n(md, pool, wl[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot_sources* src, int64_t N, RangeArgs& rg) {
+    if (!ranges || n_ranges < 1 || n_ranges > OT_MAX_RANGES)
+        return fail(OT_ERR_INVALID, "between 1 and 64 source ranges are supported per launch");
+    rg.n = n_ranges;
+    int64_t covered = 0;
+    for (int k = 0; k < n_ranges; k++) {
+        if (ranges[k].source < 0 || ranges[k].source >= src->n) return fail(OT_ERR_INVALID, "range: source out of range");
+        if (ranges[k].first < 0 || ranges[k].count < 0 || ranges[k].first + ranges[k].count > N)
+            return fail(OT_ERR_INVALID, "range outside the ray storage");
+        if (ranges[k].count > 0xffffffffll) return fail(OT_ERR_UNSUPPORTED, "more than 2^32 rays in one source range");
+        rg.source[k] = ranges[k].source;
+        rg.first[k] = ranges[k].first;
+        rg.count[k] = ranges[k].count;
+        covered += ranges[k].count;
+    }
+    if (covered != N) return fail(OT_ERR_INVALID, "source ranges must cover all N rays exactly once");
+    return OT_OK;
+}
+
+static int check_rays(const ot_rays* r, bool need_pol) {
+    if (!r || r->N < 0 || r->nt < 1) return fail(OT_ERR_INVALID, "bad ray storage");
+    if (!r->p || !r->s || !r->w || !r->n || !r->wl) return fail(OT_ERR_INVALID, "ray storage: null buffer");
+    if (need_pol && !r->pol) return fail(OT_ERR_INVALID, "ray storage: pol buffer missing although polarisation is on");
+    return OT_OK;
+}
+
+extern "C" int ot_rays_generate(const ot_sources* src, const ot_source_range* ranges, int32_t n_ranges, uint64_t seed,
+                                int32_t no_pol, const ot_rays* rays, void* stream) {
+    if (!src) return fail(OT_ERR_INVALID, "ot_rays_generate: null sources");
+    if (int rc = check_rays(rays, !no_pol)) return rc;
+    RangeArgs rg;
+    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg)) return rc;
+    if (rays->N == 0) return OT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (no_pol)
+        hipLaunchKernelGGL(generate_kernel<false>, grid_for(rays->N), dim3(256), 0, st, *rays, src->d, rg, seed);
+    else
+        hipLaunchKernelGGL(generate_kernel<true>, grid_for(rays->N), dim3(256), 0, st, *rays, src->d, rg, seed);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeArgs* rg, const ot_rays* rays,
+                        const double* hurb_normals, uint64_t seed, int64_t* msgs, void* stream) {
+    if (!sc || !msgs) return fail(OT_ERR_INVALID, "ot_trace: null argument");
+    bool pol = !sc->h.no_pol;
+    if (int rc = check_rays(rays, pol)) return rc;
+    if (rays->nt != sc->h.nt) return fail(OT_ERR_INVALID, "ray storage has " + std::to_string(rays->nt) +
+                                                             " sections, the scene needs " + std::to_string(sc->h.nt));
+    if (rays->N == 0) return OT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    RangeArgs none;
+    none.n = 0;
+    const RangeArgs& r = rg ? *rg : none;
+    const SourceDev* sd = src ? src->d : nullptr;
+    unsigned long long* m = (unsigned long long*)msgs;
+    dim3 grid = grid_for(rays->N), block(256);
+    if (src) {
+        if (pol) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
+        else     hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
+    } else {
+        if (pol) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
+        else     hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
+    }
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_trace(const ot_scene* scene, const ot_rays* rays, const double* hurb_normals, uint64_t seed,
+                        int64_t* msgs, void* stream) {
+    return launch_trace(scene, nullptr, nullptr, rays, hurb_normals, seed, msgs, stream);
+}
+
+extern "C" int ot_generate_and_trace(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,
+                                     int32_t n_ranges, uint64_t seed, const ot_rays* rays, int64_t* msgs, void* stream) {
+    if (!src || !rays) return fail(OT_ERR_INVALID, "ot_generate_and_trace: null argument");
+    RangeArgs rg;
+    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg)) return rc;
+    return launch_trace(scene, src, &rg, rays, nullptr, seed, msgs, stream);
+}
+
+// ---- leaf entry points -------------------------------------------------------------------------------------
+extern "C" int ot_surface_find_hit(const ot_surface* surf, int64_t n, const double* p, const double* s, double* p_hit,
+                                   uint8_t* is_hit, uint8_t* ill, void* stream) {
+    if (!surf || n < 0 || (n && (!p || !s || !p_hit || !is_hit || !ill))) return fail(OT_ERR_INVALID, "ot_surface_find_hit: bad argument");
+    if (int rc = require_device()) return rc;
+    SurfDev d;
+    if (int rc = compile_surface(*surf, d)) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(find_hit_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, p, s, p_hit, is_hit, ill);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_surface_normals(const ot_surface* surf, int64_t n, const double* x, const double* y, double* normals,
+                                  void* stream) {
+    if (!surf || n < 0 || (n && (!x || !y || !normals))) return fail(OT_ERR_INVALID, "ot_surface_normals: bad argument");
+    if (int rc = require_device()) return rc;
+    SurfDev d;
+    if (int rc = compile_surface(*surf, d)) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(normals_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, normals);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_surface_mask(const ot_surface* surf, int64_t n, const double* x, const double* y, uint8_t* mask,
+                               void* stream) {
+    if (!surf || n < 0 || (n && (!x || !y || !mask))) return fail(OT_ERR_INVALID, "ot_surface_mask: bad argument");
+    if (int rc = require_device()) return rc;
+    SurfDev d;
+    if (int rc = compile_surface(*surf, d)) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(mask_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, mask);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_surface_values(const ot_surface* surf, int64_t n, const double* x, const double* y, double* z,
+                                 void* stream) {
+    if (!surf || n < 0 || (n && (!x || !y || !z))) return fail(OT_ERR_INVALID, "ot_surface_values: bad argument");
+    if (int rc = require_device()) return rc;
+    SurfDev d;
+    if (int rc = compile_surface(*surf, d)) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(values_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, z);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_surface_hurb_props(const ot_surface* surf, int64_t n, const double* x, const double* y, double* a_,
+                                     double* b_, double* b, uint8_t* inside, void* stream) {
+    if (!surf || n < 0 || (n && (!x || !y || !a_ || !b_ || !b || !inside)))
+        return fail(OT_ERR_INVALID, "ot_surface_hurb_props: bad argument");
+    if (surf->kind != OT_SURF_RING && surf->kind != OT_SURF_SLIT)
+        return fail(OT_ERR_UNSUPPORTED, "hurb_props is defined for ring and slit surfaces only");
+    if (int rc = require_device()) return rc;
+    SurfDev d;
+    if (int rc = compile_surface(*surf, d)) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(hurb_props_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, a_, b_, b, inside);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_refraction_index(const ot_medium* medium, const double* table_pool, int64_t table_pool_len, int64_t n,
+                                   const float* wl, double* out, void* stream) {
+    if (!medium || n < 0 || (n && (!wl || !out))) return fail(OT_ERR_INVALID, "ot_refraction_index: bad argument");
+    if ((medium->model == OT_N_DATA || medium->model == OT_N_LINES) &&
+        (!table_pool || medium->tab_off < 0 || medium->tab_off + 2 * (int64_t)medium->tab_len > table_pool_len))
+        return fail(OT_ERR_INVALID, "ot_refraction_index: table outside the pool");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(refraction_index_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, *medium, table_pool, n, wl, out);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+// ---- detector + render -------------------------------------------------------------------------------------
+extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
+                                int32_t projection, double* ph, float* hw, double* extent4, int64_t* ill_count,
+                                void* stream) {
+    if (!rays || !detector || !ph || !hw || !ill_count) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
+    if (!rays->p || !rays->w) return fail(OT_ERR_INVALID, "ot_detector_hits: ray storage has null buffers");
+    if (first < 0 || count < 0 || first + count > rays->N) return fail(OT_ERR_INVALID, "ot_detector_hits: range outside the storage");
+    if (projection < OT_PROJ_NONE || projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
+    if (int rc = require_device()) return rc;
+    SurfDev d;
+    if (int rc = compile_surface(*detector, d)) return rc;
+    if (count == 0) return OT_OK;
+    double R = detector->R;
+    hipLaunchKernelGGL(detector_kernel, grid_for(count), dim3(256), 0, (hipStream_t)stream, *rays, first, count, d, R,
+                       projection, ph, hw, extent4, (unsigned long long*)ill_count);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, const double* p, double* out,
+                                    void* stream) {
+    if (!surf || n < 0 || (n && (!p || !out))) return fail(OT_ERR_INVALID, "ot_sphere_projection: bad argument");
+    if (surf->kind != OT_SURF_CONIC || surf->k != 0.0) return fail(OT_ERR_INVALID, "sphere projection needs a spherical surface");
+    if (projection < OT_PROJ_NONE || projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(projection_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, surf->pos[0], surf->pos[1],
+                       surf->pos[2], surf->R, projection, n, p, out);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* py, const float* w, const float* wl,
+                                    const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream) {
+    if (n < 0 || !extent || !hist || Nx < 1 || Ny < 1 || (n && (!px || !py || !w || !wl)))
+        return fail(OT_ERR_INVALID, "ot_render_accumulate: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return OT_OK;
+    RenderArgs a;
+    a.x0 = extent[0];
+    a.y0 = extent[2];
+    a.x1 = extent[1];
+    a.y1 = extent[3];
+    a.fx = (double)Nx / (extent[1] - extent[0]);  // Nx / s[0]  misc.py:75
+    a.fy = (double)Ny / (extent[3] - extent[2]);
+    a.Nx = Nx;
+    a.Ny = Ny;
+    const double* table = observer_table_device();
+    if (!table) return fail(OT_ERR_HIP, "could not upload the CIE observer table");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;  // grid-stride: the LDS table is staged once per workgroup
+    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, px, py, w, wl, a, table, hist);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}

@@ -1,0 +1,234 @@
+// Detector stage: hit search over the stored ray sections, sphere projection, and XYZ binning.
+// Reference: Raytracer._hit_detector raytracer.py:881-1051, SphericalSurface.sphere_projection
+// spherical_surface.py:36-97, RenderImage.render render_image.py:361-421 (+ misc.binning_indices_2d
+// misc.py:59-91, color.x/y/z_observer observers.py:14-41).
+#pragma once
+#include "ot_device.hpp"
+#include "cie_observer_table.inc"
+
+// ---- double min / max atomics (no native f64 min/max on global memory: CAS loop, one lane per wave) -------
+OT_DEV void atomic_min_f64(double* addr, double v) {
+    unsigned long long* a = (unsigned long long*)addr;
+    unsigned long long old = *a;
+    while (v < __longlong_as_double((long long)old)) {
+        unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+        if (old == assumed) break;
+    }
+}
+
+OT_DEV void atomic_max_f64(double* addr, double v) {
+    unsigned long long* a = (unsigned long long*)addr;
+    unsigned long long old = *a;
+    while (v > __longlong_as_double((long long)old)) {
+        unsigned long long assumed = old;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+        if (old == assumed) break;
+    }
+}
+
+OT_DEV double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+
+OT_DEV double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// SphericalSurface.sphere_projection spherical_surface.py:36-97
+OT_DEV void sphere_project(double x0, double y0, double z0, double R, int projection, V3& p) {
+    if (projection == OT_PROJ_NONE || projection == OT_PROJ_ORTHOGRAPHIC) return;
+    double zm = z0 + R;
+    double sgnR = (R > 0) - (R < 0);
+    double dx = p.x - x0, dy = p.y - y0;
+    if (projection == OT_PROJ_EQUAL_AREA) {
+        double aR = fabs(R);
+        double x_ = dx / aR, y_ = dy / aR, z_ = (p.z - zm) / R;
+        double f = sqrt(2 / (1 - z_));
+        p.x = f * x_;
+        p.y = f * y_;
+        return;
+    }
+    double r = sqrt(dx * dx + dy * dy);
+    double c = (r > 0.0) ? dx / r : 1.0;  // cos(atan2(dy, dx))
+    double s = (r > 0.0) ? dy / r : 0.0;  // sin(atan2(dy, dx))
+    double q;
+    if (projection == OT_PROJ_EQUIDISTANT) {
+        q = -sgnR * atan(r / (p.z - zm));
+    } else {
+        double theta = M_PI / 2 - atan(r / (p.z - zm));
+        q = -2 * sgnR * tan(M_PI / 4 - theta / 2);
+    }
+    p.x = q * c;
+    p.y = q * s;
+}
+
+__global__ __launch_bounds__(256) void projection_kernel(double x0, double y0, double z0, double R, int projection,
+                                                         int64_t n, const double* __restrict__ p, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 v = {p[i], p[i + n], p[i + 2 * n]};
+    sphere_project(x0, y0, z0, R, projection, v);
+    out[i] = v.x;
+    out[i + n] = v.y;
+    out[i + 2 * n] = v.z;
+}
+
+// direction of section k re-derived from the stored positions (RayStorage.rays_by_mask ray_storage.py:274-279)
+OT_DEV V3 section_dir(const ot_rays& R, int64_t r, int k) {
+    const int64_t N = R.N, nt = R.nt;
+    int k1 = (k < R.nt - 1) ? k + 1 : k;
+    V3 d = {R.p[r + N * k1] - R.p[r + N * k], R.p[r + N * (k1 + nt)] - R.p[r + N * (k + nt)],
+            R.p[r + N * (k1 + 2 * nt)] - R.p[r + N * (k + 2 * nt)]};
+    return normalize3(d);
+}
+
+// Raytracer._hit_detector raytracer.py:922-1051, one lane per ray of [first, first+count).
+// ill_count[0] += ill-conditioned rays, ill_count[1] += rays whose numeric hit search timed out.
+__global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first, int64_t count, SurfDev det, double Rcurv,
+                                                       int projection, double* __restrict__ ph_out, float* __restrict__ hw_out,
+                                                       double* __restrict__ extent4, unsigned long long* __restrict__ ill_count) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < count;
+    const int64_t r = first + (active ? q : 0);
+    const int64_t N = R.N;
+    const int nt = R.nt;
+
+    V3 ph = {0.0, 0.0, 0.0};
+    float w = 0.f;
+    bool ish = false, any_ill = false, timeout = false;
+
+    if (active) {
+        // section search (raytracer.py:929-938): first section whose start lies at/behind the detector's z_min
+        bool all_b = true, all_nb = true;
+        int first_ge = -1;
+        for (int j = 0; j < nt; j++) {
+            double z = R.p[r + N * (j + 2 * (int64_t)nt)];
+            bool bmin = z >= det.z_min, bmax = z >= det.z_max;
+            all_b = all_b && bmin && bmax;
+            all_nb = all_nb && !bmin && !bmax;
+            if (bmin && first_ge < 0) first_ge = j;
+        }
+        if (!(all_b || all_nb)) {
+            int k = (first_ge < 0 ? 0 : first_ge) - 1;
+            if (k < 0) k = 0;
+            V3 p = {R.p[r + N * k], R.p[r + N * (k + (int64_t)nt)], R.p[r + N * (k + 2 * (int64_t)nt)]};
+            V3 s = section_dir(R, r, k);
+            w = R.w[r + N * k];
+            for (;;) {
+                k += 1;
+                if (k >= nt) {
+                    w = 0.f;
+                    break;
+                }
+                bool ill;
+                if (!find_hit(det, p, s, ph, ish, ill)) timeout = true;
+                any_ill = any_ill || ill;
+                double p2z = R.p[r + N * (k + 2 * (int64_t)nt)];
+                if (!(ph.z > p2z + OT_C_EPS)) break;  // hit lies inside this section (raytracer.py:985)
+                p.x = R.p[r + N * k];
+                p.y = R.p[r + N * (k + (int64_t)nt)];
+                p.z = p2z;
+                s = section_dir(R, r, k);
+                w = R.w[r + N * k];
+            }
+        }
+    }
+    bool valid = active && ish && (w > 0);
+    if (valid) sphere_project(det.px, det.py, det.pz, Rcurv, projection, ph);
+    if (active) {
+        ph_out[q] = valid ? ph.x : 0.0;
+        ph_out[q + count] = valid ? ph.y : 0.0;
+        ph_out[q + 2 * count] = valid ? ph.z : 0.0;
+        hw_out[q] = valid ? w : 0.f;
+    }
+    // counters and extent: wave-level reduction, one atomic per wave
+    unsigned long long m_ill = __ballot(any_ill), m_to = __ballot(timeout);
+    const int lane = __lane_id();
+    if (lane == 0) {
+        if (m_ill) atomicAdd(&ill_count[0], (unsigned long long)__popcll(m_ill));
+        if (m_to) atomicAdd(&ill_count[1], (unsigned long long)__popcll(m_to));
+    }
+    if (extent4) {
+        const double inf = __builtin_inf();
+        double xmin = wave_min(valid ? ph.x : inf), xmax = wave_max(valid ? ph.x : -inf);
+        double ymin = wave_min(valid ? ph.y : inf), ymax = wave_max(valid ? ph.y : -inf);
+        if (lane == 0 && xmin <= xmax) {
+            atomic_min_f64(&extent4[0], xmin);
+            atomic_max_f64(&extent4[1], xmax);
+            atomic_min_f64(&extent4[2], ymin);
+            atomic_max_f64(&extent4[3], ymax);
+        }
+    }
+}
+
+// ---- rendering ---------------------------------------------------------------------------------------------
+struct RenderArgs {
+    double x0, x1, y0, y1;
+    double fx, fy;  // Nx / sx, Ny / sy  (misc.py:75-76)
+    int32_t Nx, Ny;
+};
+
+static const double* observer_table_device() {
+    static thread_local const double* tab[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!tab[dev]) {
+        double* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(ot_observer_xyz)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, ot_observer_xyz, sizeof(ot_observer_xyz), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        tab[dev] = d;
+    }
+    return tab[dev];
+}
+
+// RenderImage.render render_image.py:396-418.  The 471x3 observer table (11 KB) is staged in LDS once per
+// workgroup because every lane indexes it with its own wavelength; hist updates are f64 hardware atomics
+// (global_atomic_add_f64) on the (Ny, Nx, 4) image.
+__global__ __launch_bounds__(256) void render_kernel(int64_t n, const double* __restrict__ px, const double* __restrict__ py,
+                                                     const float* __restrict__ w, const float* __restrict__ wl, RenderArgs a,
+                                                     const double* __restrict__ table, double* __restrict__ hist) {
+    __shared__ double obs[OT_OBS_N * 3];
+    for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float wi = w[i];
+        if (!(wi > 0.f || wi < 0.f)) continue;  // w == 0: adds nothing (and NaN weights are dropped)
+        double x = px[i], y = py[i];
+        // misc.binning_indices_2d misc.py:75-89
+        int32_t ix = (int32_t)floor(a.fx * (x - a.x0));
+        int32_t iy = (int32_t)floor(a.fy * (y - a.y0));
+        if (y == a.y1) iy = a.Ny - 1;
+        if (x == a.x1) ix = a.Nx - 1;
+        if (ix < 0 || iy < 0 || iy >= a.Ny || ix >= a.Nx) continue;  // outside: weight 0 in the reference
+        // np.interp on the 1 nm grid: interval index is floor(wl - 360)
+        double l = (double)wl[i];
+        double xo = 0.0, yo = 0.0, zo = 0.0;
+        double u = l - OT_OBS_WL0;
+        if (u >= 0.0 && u <= (double)(OT_OBS_N - 1)) {
+            int j = (int)floor(u);
+            if (j >= OT_OBS_N - 1) {
+                xo = obs[3 * (OT_OBS_N - 1)];
+                yo = obs[3 * (OT_OBS_N - 1) + 1];
+                zo = obs[3 * (OT_OBS_N - 1) + 2];
+            } else {
+                double t = l - (OT_OBS_WL0 + (double)j);
+                const double* f0 = &obs[3 * j];
+                xo = (f0[3] - f0[0]) / 1.0 * t + f0[0];
+                yo = (f0[4] - f0[1]) / 1.0 * t + f0[1];
+                zo = (f0[5] - f0[2]) / 1.0 * t + f0[2];
+            }
+        }
+        double wm = (double)wi;
+        double* h = hist + ((int64_t)iy * a.Nx + ix) * 4;
+        unsafeAtomicAdd(h + 0, xo * wm);
+        unsafeAtomicAdd(h + 1, yo * wm);
+        unsafeAtomicAdd(h + 2, zo * wm);
+        unsafeAtomicAdd(h + 3, 1.0 * wm);
+    }
+}

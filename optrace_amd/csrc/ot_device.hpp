@@ -1,0 +1,435 @@
+// Per-ray device functions of the sequential tracer (gfx950, wave64).
+//
+// Everything here is written against the NumPy behaviour of the reference (file:line cited per function),
+// NOT translated from it: one ray per lane, state in VGPRs, surface constants as wave-uniform scalars,
+// IEEE f64 +,-,*,/ and sqrt in the reference's evaluation order (compile with -ffp-contract=off) so that hit
+// masks and counters come out bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "ot_scene.hpp"
+
+#define OT_DEV __device__ __forceinline__
+
+struct V3 {
+    double x, y, z;
+};
+
+OT_DEV double dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // misc.py:94
+
+OT_DEV V3 cross3(const V3& a, const V3& b) {  // misc.py:152
+    V3 n;
+    n.x = a.y * b.z - a.z * b.y;
+    n.y = a.z * b.x - a.x * b.z;
+    n.z = a.x * b.y - a.y * b.x;
+    return n;
+}
+
+OT_DEV V3 normalize3(const V3& a) {  // misc.py:136 (zero vectors -> NaN)
+    double l = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    V3 r = {a.x / l, a.y / l, a.z / l};
+    return r;
+}
+
+OT_DEV V3 along(const V3& p, const V3& s, double t) {
+    V3 r = {p.x + s.x * t, p.y + s.y * t, p.z + s.z * t};
+    return r;
+}
+
+// ---- masks: surface.py:235, ring_surface.py:123, rectangular_surface.py:100, slit_surface.py:89 ----------
+OT_DEV bool surf_mask(const SurfDev& sf, double x, double y) {
+    if (sf.kind == OT_SURF_RECT || sf.kind == OT_SURF_SLIT) {
+        double dx = x - sf.px, dy = y - sf.py;
+        double xr = dx, yr = dy;
+        if (sf.rot) {
+            xr = dx * sf.cna - dy * sf.sna;
+            yr = dx * sf.sna + dy * sf.cna;
+        }
+        bool outer = (sf.ox_lo <= xr) && (xr <= sf.ox_hi) && (sf.oy_lo <= yr) && (yr <= sf.oy_hi);
+        if (sf.kind == OT_SURF_RECT) return outer;
+        bool inner = (sf.ix_lo <= xr) && (xr <= sf.ix_hi) && (sf.iy_lo <= yr) && (yr <= sf.iy_hi);
+        return outer && !inner;
+    }
+    double dx = x - sf.px, dy = y - sf.py;
+    double r2 = dx * dx + dy * dy;
+    bool in = r2 <= sf.r_eps2;
+    if (sf.kind == OT_SURF_RING) in = in && (sf.ri_eps2 <= r2);
+    return in;
+}
+
+// numpy.polyval over AsphericSurface._np_coeff (aspheric_surface.py:104-113): Horner including the zero
+// odd-order coefficients, i.e. y = (y*r + a)*r + 0 per even coefficient
+OT_DEV double asph_poly(const SurfDev& sf, double r) {
+    double y = 0.0;
+    for (int j = sf.ncoeff - 1; j >= 0; j--) {
+        y = y * r + sf.coeff[j];
+        y = y * r + 0.0;
+    }
+    y = y * r + 0.0;
+    return y;
+}
+
+OT_DEV double asph_poly_deriv(const SurfDev& sf, double r) {  // polyval(polyder(..)) aspheric_surface.py:79
+    double y = 0.0;
+    for (int j = sf.ncoeff - 1; j >= 0; j--) {
+        y = y * r + sf.dcoeff[j];
+        y = y * r + 0.0;
+    }
+    return y;
+}
+
+// Surface._values relative to the centre: conic_surface.py:57, aspheric_surface.py:51
+OT_DEV double surf_values_rel(const SurfDev& sf, double x, double y) {
+    if (sf.kind == OT_SURF_CONIC) {
+        double r2 = x * x + y * y;
+        return sf.rho * r2 / (1 + sqrt(1 - sf.k1rho2 * r2));
+    }
+    double r = sqrt(x * x + y * y);
+    double rr = r * r;
+    double z = sf.rho * rr / (1 + sqrt(1 - sf.k1rho2 * rr));
+    z += asph_poly(sf, r);
+    return z;
+}
+
+// Surface.values surface.py:137-164
+OT_DEV double surf_values(const SurfDev& sf, double x, double y) {
+    if (sf.flat) return sf.z_max;
+    if (surf_mask(sf, x, y)) return sf.pz + surf_values_rel(sf, x - sf.px, y - sf.py);
+    return sf.edge_val;
+}
+
+// Surface.normals surface.py:247, ConicSurface.normals conic_surface.py:70-124,
+// FunctionSurface2D.normals (1D branch) function_surface_2d.py:216-251 + AsphericSurface._deriv :67-82.
+// cos(atan2(dy,dx)) and sin(atan2(dy,dx)) are formed as dx/r, dy/r: same value to 1-2 ulp without three
+// transcendental calls per ray (normals never feed a mask directly; tolerance 1e-6).
+OT_DEV V3 surf_normal(const SurfDev& sf, double x, double y) {
+    V3 n = {0.0, 0.0, 1.0};
+    if (sf.kind != OT_SURF_CONIC && sf.kind != OT_SURF_ASPHERE) return n;
+    if (sf.flat) return n;
+    if (!surf_mask(sf, x, y)) return n;
+    double dx = x - sf.px, dy = y - sf.py;
+    if (sf.kind == OT_SURF_CONIC) {
+        if (sf.k == 0.0) {
+            n.x = sf.nrho * dx;
+            n.y = sf.nrho * dy;
+            n.z = sqrt(1 - sf.rho2 * (dx * dx) - sf.rho2 * (dy * dy));
+            return n;
+        }
+        double r = sqrt(dx * dx + dy * dy);
+        double n_r = sf.nrho * r / sqrt(1 - sf.krho2 * (r * r));
+        double c = (r > 0.0) ? dx / r : 1.0;
+        double s = (r > 0.0) ? dy / r : 0.0;
+        n.x = n_r * c;
+        n.y = n_r * s;
+        n.z = sqrt(1 - n_r * n_r);
+        return n;
+    }
+    double rm = sqrt(dx * dx + dy * dy);
+    double fr = rm * sf.rho / sqrt(1 - sf.k1rho2 * (rm * rm));
+    fr += asph_poly_deriv(sf, rm);
+    double c = (rm > 0.0) ? dx / rm : 1.0;
+    double s = (rm > 0.0) ? dy / rm : 0.0;
+    V3 m = {-(fr * c), -(fr * s), 1.0};
+    return normalize3(m);
+}
+
+// Surface._find_hit_handle_abnormal surface.py:436-479
+OT_DEV void handle_abnormal(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
+    double zs = surf_values(sf, ph.x, ph.y);
+    bool dev = fabs(ph.z - zs) > OT_C_EPS;
+    bool beh = p.z > sf.z_beh;
+    bool neg = ph.z < p.z - OT_C_EPS;
+    if ((neg || dev) && !beh) {
+        double tnm = (sf.z_max - p.z) / s.z;
+        ph = along(p, s, tnm);
+        hit = false;
+    }
+    if (beh) {
+        ph = p;
+        hit = false;
+    }
+}
+
+// ConicSurface.find_hit conic_surface.py:126-203 (closed-form quadratic)
+OT_DEV void find_hit_conic(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
+    double ox = p.x - sf.px, oy = p.y - sf.py, oz = p.z - sf.pz;
+    double A = (sf.k != 0.0) ? 1 + sf.k * (s.z * s.z) : 1.0;
+    double ozk = oz * sf.k1;
+    double B = s.x * ox + s.y * oy + s.z * (ozk - sf.inv_rho);
+    double C = oy * oy + ox * ox + oz * (ozk - sf.two_inv_rho);
+    double D = sqrt(B * B - C * A);
+    double t1 = (-B - D) / A;
+    double t2 = (-B + D) / A;
+    double z = p.z;
+    double z1 = z + s.z * t1;
+    double z2 = z + s.z * t2;
+    bool c1 = (sf.z_lo <= z1) && (z1 <= sf.z_hi) && (z1 >= z);
+    bool c2 = (sf.z_lo <= z2) && (z2 <= sf.z_hi) && (z2 >= z) && (t2 < t1);
+    double t = (c1 && !c2) ? t1 : t2;
+    ph = along(p, s, t);
+    hit = surf_mask(sf, ph.x, ph.y);
+    if (A == 0 && B != 0) {
+        t = -C / (2 * B);
+        ph = along(p, s, t);
+        hit = surf_mask(sf, ph.x, ph.y);
+    }
+    bool nh = !hit || !isfinite(D) || (A == 0 && B == 0) || (ph.z < sf.z_lo) || (ph.z > sf.z_hi);
+    if (nh) {
+        double tnh = (sf.z_max - p.z) / s.z;
+        ph = along(p, s, tnh);
+        hit = false;
+    }
+    if (z > sf.z_max) {
+        ph = p;
+        hit = false;
+    }
+}
+
+// Surface.find_hit surface.py:307-414.  Numeric branch = Illinois regula falsi.  The reference shrinks its
+// active set with boolean masks every iteration; on the GPU the same thing is the wavefront's EXEC mask: the
+// loop below runs while the 64-bit ballot of unconverged lanes is non-zero (one scalar branch per iteration)
+// and converged lanes idle, so a wave pays max(iterations) of its own 64 rays only.
+// Returns false if a lane hit the 200-iteration timeout (surface.py:403).
+OT_DEV bool find_hit(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& ill) {
+    ill = false;
+    if (sf.kind == OT_SURF_CONIC) {
+        find_hit_conic(sf, p, s, ph, hit);
+        return true;
+    }
+    if (sf.flat) {
+        double t = (sf.pz - p.z) / s.z;
+        ph = along(p, s, t);
+        hit = surf_mask(sf, ph.x, ph.y);
+        handle_abnormal(sf, p, s, ph, hit);
+        return true;
+    }
+    double t1 = (sf.zt1 - p.z) / s.z;
+    double t2 = (sf.zt2 - p.z) / s.z;
+    if (t1 < 0) t1 = -OT_C_EPS;
+    V3 p1 = along(p, s, t1), p2 = along(p, s, t2);
+    double f1 = p1.z - surf_values(sf, p1.x, p1.y);
+    double f2 = p2.z - surf_values(sf, p2.x, p2.y);
+    bool w = isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
+    ph.x = ph.y = ph.z = 0.0;
+    if (!w) ph = p1;
+    ill = f1 * f2 > 0;
+    bool ok = true;
+    int it = 1;
+    while (__ballot(w) != 0ull) {
+        if (w) {
+            double ts = t1 - f1 / (f2 - f1) * (t2 - t1);
+            V3 pl = along(p, s, ts);
+            double fts = pl.z - surf_values(sf, pl.x, pl.y);
+            double prod = fts * f2;
+            if (prod < 0) {
+                t1 = t2;
+                t2 = ts;
+                f1 = f2;
+                f2 = fts;
+            } else if (prod > 0) {
+                t2 = ts;
+                f1 = 0.5 * f1;
+                f2 = fts;
+            } else if (prod == 0) {
+                t1 = ts;
+                t2 = ts;
+                f1 = fts;
+                f2 = fts;
+            }
+            if (fabs(t2 - t1) < OT_C_EPS / 10) {
+                ph = pl;
+                w = false;
+            }
+        }
+        if (it == OT_MAX_HIT_ITER) {  // every wave reaches this exit: the loop is bounded
+            ok = !w;
+            w = false;
+        }
+        it++;
+    }
+    hit = surf_mask(sf, ph.x, ph.y);
+    handle_abnormal(sf, p, s, ph, hit);
+    return ok;
+}
+
+// RingSurface.hurb_props ring_surface.py:88-121, SlitSurface.hurb_props slit_surface.py:65-87
+OT_DEV void hurb_props(const SurfDev& sf, double x, double y, double& a_, double& b_, V3& b, bool& inside) {
+    double dx = x - sf.px, dy = y - sf.py;
+    if (sf.kind == OT_SURF_RING) {
+        double r = sqrt(dx * dx + dy * dy);
+        inside = r < sf.ri;
+        b_ = sf.ri - r;
+        a_ = sqrt(b_ * sf.ri);
+        b.x = (r > 0.0) ? dx / r : 1.0;  // cos(atan2(dy, dx))
+        b.y = (r > 0.0) ? dy / r : 0.0;  // sin(atan2(dy, dx))
+        b.z = 0.0;
+    } else {
+        double xr = dx, yr = dy;
+        if (sf.rot) {
+            xr = dx * sf.cna - dy * sf.sna;
+            yr = dx * sf.sna + dy * sf.cna;
+        }
+        a_ = sf.hdy - fabs(yr);
+        b_ = sf.hdx - fabs(xr);
+        inside = (a_ > 0) && (b_ > 0);
+        b.x = sf.cpa;
+        b.y = sf.spa;
+        b.z = 0.0;
+    }
+}
+
+// ---- media: RefractionIndex.__call__ refraction_index.py:62-169 ------------------------------------------
+// numpy.interp on a sorted table (compiled_base.c arr_interp): binary search for the interval, exact value
+// on a node, linear elsewhere; `left`/`right` = 0 outside (spectrum.py:106)
+OT_DEV double interp_tab(double x, const double* __restrict__ xp, const double* __restrict__ fp, int n) {
+    if (isnan(x)) return x;
+    if (x < xp[0] || x > xp[n - 1]) return 0.0;
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    int j = (xp[hi] <= x) ? hi : lo;
+    if (j == n - 1) return fp[j];
+    if (xp[j] == x) return fp[j];
+    double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    double res = slope * (x - xp[j]) + fp[j];
+    if (isnan(res)) {
+        res = slope * (x - xp[j + 1]) + fp[j + 1];
+        if (isnan(res) && fp[j] == fp[j + 1]) res = fp[j];
+    }
+    return res;
+}
+
+OT_DEV double ipow3(double x) { return pow(x, 3.0); }
+
+OT_DEV double medium_n(const ot_medium& md, const double* __restrict__ pool, float wl32) {
+    double wl = (double)wl32;
+    const double* c = md.c;
+    double um = wl * 1e-3;
+    double wl2 = um * um;
+    switch (md.model) {
+        case OT_N_CONSTANT: return c[0];
+        case OT_N_ABBE: return c[0] + c[1] / (wl2 - c[2]);
+        case OT_N_CONRADY: return c[0] + c[1] / um + c[2] / pow(um, 3.5);
+        case OT_N_CAUCHY: return c[0] + c[1] / wl2 + c[2] / (wl2 * wl2) + c[3] / pow(wl2, 3.0);
+        case OT_N_SELLMEIER1:
+            return sqrt(1 + c[0] * wl2 / (wl2 - c[1]) + c[2] * wl2 / (wl2 - c[3]) + c[4] * wl2 / (wl2 - c[5]));
+        case OT_N_SELLMEIER2:
+            return sqrt(1 + c[0] + c[1] * wl2 / (wl2 - c[2] * c[2]) + c[3] / (wl2 - c[4] * c[4]));
+        case OT_N_SELLMEIER3:
+            return sqrt(1 + c[0] * wl2 / (wl2 - c[1]) + c[2] * wl2 / (wl2 - c[3]) + c[4] * wl2 / (wl2 - c[5]) +
+                        c[6] * wl2 / (wl2 - c[7]));
+        case OT_N_SELLMEIER4: return sqrt(c[0] + c[1] * wl2 / (wl2 - c[2]) + c[3] * wl2 / (wl2 - c[4]));
+        case OT_N_SELLMEIER5:
+            return sqrt(1 + c[0] * wl2 / (wl2 - c[1]) + c[2] * wl2 / (wl2 - c[3]) + c[4] * wl2 / (wl2 - c[5]) +
+                        c[6] * wl2 / (wl2 - c[7]) + c[8] * wl2 / (wl2 - c[9]));
+        case OT_N_SCHOTT:
+            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / pow(wl2, 3.0) +
+                        c[5] / pow(wl2, 4.0));
+        case OT_N_HERZBERGER: {
+            double L = 1 / (wl2 - 0.028);
+            return c[0] + c[1] * L + c[2] * (L * L) + c[3] * wl2 + c[4] * (wl2 * wl2) + c[5] * pow(wl2, 3.0);
+        }
+        case OT_N_HOO1: return sqrt(c[0] + c[1] / (wl2 - c[2]) - c[3] * wl2);
+        case OT_N_HOO2: return sqrt(c[0] + c[1] * wl2 / (wl2 - c[2]) - c[3] * wl2);
+        case OT_N_EXTENDED:
+            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / pow(wl2, 3.0) +
+                        c[5] / pow(wl2, 4.0) + c[6] / pow(wl2, 5.0) + c[7] / pow(wl2, 6.0));
+        case OT_N_EXTENDED2:
+            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / pow(wl2, 3.0) +
+                        c[5] / pow(wl2, 4.0) + c[6] * (wl2 * wl2) + c[7] * pow(wl2, 3.0));
+        case OT_N_EXTENDED3:
+            return sqrt(c[0] + c[1] * wl2 + c[2] * (wl2 * wl2) + c[3] / wl2 + c[4] / (wl2 * wl2) +
+                        c[5] / pow(wl2, 3.0) + c[6] * pow(wl2, 4.0) + c[7] * pow(wl2, 5.0) + c[8] / pow(wl2, 6.0));
+        case OT_N_DATA: {
+            const double* xp = pool + md.tab_off;
+            return interp_tab(wl, xp, xp + md.tab_len, md.tab_len);
+        }
+        case OT_N_LINES: {
+            const double* xp = pool + md.tab_off;
+            double v = __builtin_nan("");
+            for (int j = 0; j < md.tab_len; j++)
+                if (xp[j] == wl) v = xp[md.tab_len + j];
+            return v;
+        }
+    }
+    return __builtin_nan("");
+}
+
+// Filter.__call__ filter.py:39 -> transmission_spectrum.py:73-84 -> spectrum.py:81-120
+OT_DEV double filter_T(const FilterDev& f, const double* __restrict__ pool, float wl32) {
+    double wl = (double)wl32;
+    double T;
+    switch (f.type) {
+        case OT_T_CONSTANT: T = f.val; break;
+        case OT_T_DATA: {
+            const double* xp = pool + f.tab_off;
+            T = interp_tab(wl, xp, xp + f.tab_len, f.tab_len);
+            break;
+        }
+        case OT_T_RECTANGLE: T = (f.wl0 <= wl && wl <= f.wl1) ? f.val : 0.0; break;
+        case OT_T_GAUSSIAN: {  // float32 arithmetic, spectrum.py:113-115 with the tracer's f32 wavelengths
+            float d = wl32 - f.mu32;
+            float q = -(d * d) / f.den32;
+            T = (double)(f.val32 * expf(q));
+            break;
+        }
+        case OT_T_LINES: {
+            const double* xp = pool + f.tab_off;
+            T = __builtin_nan("");
+            for (int j = 0; j < f.tab_len; j++)
+                if (xp[j] == wl) T = xp[f.tab_len + j];
+            break;
+        }
+        default: T = __builtin_nan("");
+    }
+    return f.inverse ? 1.0 - T : T;
+}
+
+// ---- counter-based RNG: Philox-4x32-10 (Salmon et al., SC'11) ---------------------------------------------
+struct Philox {
+    uint32_t c[4];
+};
+
+OT_DEV Philox philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += W0;
+        k1 += W1;
+    }
+    Philox p = {{c0, c1, c2, c3}};
+    return p;
+}
+
+// two uniforms in [0, 1) with 53 random bits each
+OT_DEV void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, uint32_t sub, double& u0, double& u1) {
+    Philox p = philox4x32((uint32_t)idx, (uint32_t)(idx >> 32), stream, sub, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint64_t a = ((uint64_t)p.c[1] << 32) | p.c[0];
+    uint64_t b = ((uint64_t)p.c[3] << 32) | p.c[2];
+    u0 = (double)(a >> 11) * 0x1.0p-53;
+    u1 = (double)(b >> 11) * 0x1.0p-53;
+}
+
+// two independent standard normals (Box-Muller on Philox uniforms)
+OT_DEV void philox_normal2(uint64_t seed, uint64_t idx, uint32_t stream, uint32_t sub, double& z0, double& z1) {
+    double u0, u1;
+    philox_u2(seed, idx, stream, sub, u0, u1);
+    double r = sqrt(-2.0 * log(1.0 - u0));  // 1-u0 in (0, 1]
+    double sn, cs;
+    sincos(6.283185307179586 * u1, &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}

@@ -1,0 +1,339 @@
+// On-device ray generation: RaySource.create_rays (ray_source.py:204-437) with the sampling helpers of
+// optrace/tracer/random.py, redesigned for a counter-based GPU RNG.
+//
+// The reference builds whole arrays (stratified grid + dither, then a Fisher-Yates shuffle, random.py:32-43)
+// with a sequential SFC64 stream.  Neither the stream nor the shuffle can be reproduced in parallel, so the
+// device version is stateless per ray: ray j of a source range of n rays takes stratum perm_K(j), where perm_K
+// is a keyed bijection of [0, n) (cycle-walking hash permutation), and its dither comes from Philox-4x32-10
+// keyed by (seed, global ray index, stream).  Every independently shuffled quantity of the reference
+// (position, divergence, wavelength, polarisation, ...) gets its own permutation key, which gives the same
+// joint distribution: stratified marginals, independent pairing.  Parity is therefore statistical
+// (tests/test_sources_gpu.py against fingerprints of the reference) -- SURVEY.md section 7 "RNG".
+#pragma once
+#include "ot_device.hpp"
+
+enum : uint32_t {
+    ST_POS = 1, ST_PIX_JITTER = 2, ST_DIV = 3, ST_DIV_ALPHA = 4, ST_WL = 5, ST_POL = 6, ST_RGB_CHOICE = 7,
+    ST_RGB_WL = 8, ST_PIXEL = 9
+};
+
+// Keyed bijection of [0, l): hash rounds on the enclosing power of two with cycle walking
+// (construction of A. Kensler, "Correlated Multi-Jittered Sampling", Pixar TM 13-01, 2013).
+OT_DEV uint32_t permute_index(uint32_t i, uint32_t l, uint32_t key) {
+    if (l <= 1) return 0;
+    uint32_t w = l - 1;
+    w |= w >> 1;
+    w |= w >> 2;
+    w |= w >> 4;
+    w |= w >> 8;
+    w |= w >> 16;
+    do {
+        i ^= key;
+        i *= 0xe170893du;
+        i ^= key >> 16;
+        i ^= (i & w) >> 4;
+        i ^= key >> 8;
+        i *= 0x0929eb3fu;
+        i ^= key >> 23;
+        i ^= (i & w) >> 1;
+        i *= 1u | key >> 27;
+        i *= 0x6935fa69u;
+        i ^= (i & w) >> 11;
+        i *= 0x74dcb303u;
+        i ^= (i & w) >> 2;
+        i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2;
+        i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + key) % l;
+}
+
+OT_DEV uint32_t stream_key(uint64_t seed, uint32_t range, uint32_t stream) {
+    Philox p = philox4x32(range, stream, 0x5eedu, 0x0badu, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return p.c[0];
+}
+
+struct GenCtx {
+    uint64_t seed;
+    uint64_t gidx;   // global ray index in the launch (Philox counter)
+    uint32_t j;      // index inside the source range
+    uint32_t n;      // rays in the source range (stratification domain)
+    uint32_t range;  // range id (permutation keys differ per range)
+};
+
+// random.stratified_interval_sampling random.py:48-67: one of n strata of [a, b), uniformly dithered
+OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double b) {
+    uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
+    double u0, u1;
+    philox_u2(g.seed, g.gidx, stream, 0, u0, u1);
+    double dba = (b - a) / (double)g.n;
+    return a + ((double)k + u0) * dba;
+}
+
+// random.stratified_rectangle_sampling random.py:8-45: floor(sqrt(n))^2 jittered grid cells, the remaining
+// n - N2^2 samples uniform over the rectangle
+OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, double c, double d, double& x, double& y) {
+    uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
+    double u0, u1;
+    philox_u2(g.seed, g.gidx, stream, 0, u0, u1);
+    uint32_t N2 = (uint32_t)sqrt((double)g.n);
+    while ((uint64_t)N2 * N2 > g.n) N2--;
+    while ((uint64_t)(N2 + 1) * (N2 + 1) <= g.n) N2++;
+    if (k < N2 * N2) {
+        uint32_t iy = k / N2, ix = k - iy * N2;
+        x = a + ((double)ix + u0) * ((b - a) / (double)N2);
+        y = c + ((double)iy + u1) * ((d - c) / (double)N2);
+    } else {
+        x = a + u0 * (b - a);
+        y = c + u1 * (d - c);
+    }
+}
+
+// random.stratified_ring_sampling random.py:70-110: Shirley's equal-area square->disc map, then disc->annulus.
+// polar == false: cartesian (x, y); polar == true: (|r|, theta) with theta shifted by -pi for negative r.
+OT_DEV void strat_ring(const GenCtx& g, uint32_t stream, double ri, double r, bool polar, double& o0, double& o1) {
+    double x, y;
+    strat_rect(g, stream, -r, r, -r, r, x, y);
+    double x2 = x * x, y2 = y * y;
+    double r_ = 0.0, theta = 0.0;
+    if (x2 > y2) {
+        r_ = x;
+        theta = M_PI / 4 * y / x;
+    } else if (y2 > 0) {
+        r_ = y;
+        theta = M_PI / 2 - M_PI / 4 * x / y;
+    }
+    if (ri != 0.0) {
+        double q = ri / r;
+        double m = sqrt(ri * ri + r_ * r_ * (1 - q * q));
+        r_ = (r_ < 0) ? -m : m;
+    }
+    if (!polar) {
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        o0 = r_ * cs;
+        o1 = r_ * sn;
+    } else {
+        if (r_ < 0) theta -= M_PI;
+        o0 = fabs(r_);
+        o1 = theta;
+    }
+}
+
+// random.inverse_transform_sampling random.py:113-159, kind="discrete": first entry whose cumulative weight
+// reaches X (scipy interp1d kind="next"); tab = n values then n cumulative weights
+OT_DEV double inv_cdf_discrete(const double* __restrict__ tab, int n, double X) {
+    const double* F = tab + n;
+    int lo = 0, hi = n - 1;  // smallest j with F[j] >= X
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (F[mid] >= X)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return tab[lo];
+}
+
+// kind="continuous": linear interpolation of the inverse cumulative-trapezoid table; tab = n x then n F
+OT_DEV double inv_cdf_linear(const double* __restrict__ tab, int n, double X) {
+    const double* F = tab + n;
+    int lo = 0, hi = n - 1;  // F[lo] <= X <= F[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (F[mid] <= X)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    double dF = F[hi] - F[lo];
+    if (!(dF > 0)) return tab[lo];
+    return tab[lo] + (X - F[lo]) / dF * (tab[hi] - tab[lo]);
+}
+
+struct NewRay {
+    V3 p, s;
+    double polx, poly, polz;
+    float w, wl;
+};
+
+// RaySource.create_rays ray_source.py:204-437 for ray j of a range of n rays of source `src`
+OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
+    NewRay o;
+    o.w = (float)(src.power / (double)g.n);  // ray_source.py:220
+
+    // ---- wavelength (light_spectrum.py:81-138) ----
+    double wl = 0.0;
+    if (src.shape != OT_SRC_IMAGE_RGB) {
+        switch (src.spectrum) {
+            case OT_SPEC_MONO: wl = (double)(float)src.wl; break;
+            case OT_SPEC_UNIFORM: wl = strat_interval(g, ST_WL, src.wl0, src.wl1); break;
+            case OT_SPEC_LINES: {
+                const double* F = src.spec_tab + src.n_spec;
+                double X = strat_interval(g, ST_WL, 0.0, F[src.n_spec - 1]);
+                wl = inv_cdf_discrete(src.spec_tab, (int)src.n_spec, X);
+                break;
+            }
+            case OT_SPEC_GAUSSIAN: {
+                double X = strat_interval(g, ST_WL, src.gauss_xl, src.gauss_xr);
+                wl = src.mu + 1.4142135623730951 * src.sig * erfinv(2 * X - 1);
+                break;
+            }
+            default: {
+                const double* F = src.spec_tab + src.n_spec;
+                double X = strat_interval(g, ST_WL, F[0], F[src.n_spec - 1]);
+                wl = inv_cdf_linear(src.spec_tab, (int)src.n_spec, X);
+            }
+        }
+    }
+
+    // ---- start position (ray_source.py:229-255) ----
+    V3 p = {src.pos[0], src.pos[1], src.pos[2]};
+    switch (src.shape) {
+        case OT_SRC_POINT: break;
+        case OT_SRC_LINE: {
+            double t = strat_interval(g, ST_POS, -src.r, src.r);
+            p.x += src.ca * t;
+            p.y += src.sa * t;
+            break;
+        }
+        case OT_SRC_CIRCLE:
+        case OT_SRC_RING: {
+            double x, y;
+            strat_ring(g, ST_POS, src.shape == OT_SRC_RING ? src.ri : 0.0, src.r, false, x, y);
+            p.x += x;
+            p.y += y;
+            break;
+        }
+        case OT_SRC_RECT: {
+            double x, y;
+            strat_rect(g, ST_POS, -src.dim[0] / 2, src.dim[0] / 2, -src.dim[1] / 2, src.dim[1] / 2, x, y);
+            p.x += x * src.ca - y * src.sa;
+            p.y += x * src.sa + y * src.ca;
+            break;
+        }
+        default: {  // image sources: pixel by inverse CDF, uniform inside the pixel
+            uint32_t npx = (uint32_t)src.img_w * (uint32_t)src.img_h;
+            uint32_t P = 0;
+            if (npx > 1) {
+                double X = strat_interval(g, ST_PIXEL, 0.0, src.img_cdf[npx - 1]);
+                uint32_t lo = 0, hi = npx - 1;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (src.img_cdf[mid] >= X)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                P = lo;
+            }
+            uint32_t PY = P / (uint32_t)src.img_w, PX = P - PY * (uint32_t)src.img_w;
+            double rx, ry;
+            strat_rect(g, ST_PIX_JITTER, 0.0, 1.0, 0.0, 1.0, rx, ry);
+            double xs = src.pos[0] - src.dim[0] / 2, ys = src.pos[1] - src.dim[1] / 2;
+            p.x = src.dim[0] / (double)src.img_w * ((double)PX + rx) + xs;
+            p.y = src.dim[1] / (double)src.img_h * ((double)PY + ry) + ys;
+            if (src.shape == OT_SRC_IMAGE_RGB) {  // color.random_wavelengths_from_srgb srgb.py:513-553
+                double choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
+                double c_r = src.img_rgb[2 * (size_t)P], c_rg = src.img_rgb[2 * (size_t)P + 1];
+                int prim = (choice < c_r) ? 0 : ((choice > c_rg) ? 2 : 1);
+                const double* tab = src.prim_tab + (size_t)prim * 2 * OT_PRIM_N;
+                const double* F = tab + OT_PRIM_N;
+                double X = strat_interval(g, ST_RGB_WL, F[0], F[OT_PRIM_N - 1]);
+                wl = inv_cdf_linear(tab, OT_PRIM_N, X);
+            }
+        }
+    }
+    o.p = p;
+    o.wl = (float)wl;
+
+    // ---- orientation (ray_source.py:264-277) ----
+    V3 s_or;
+    if (src.orientation == OT_OR_CONVERGING) {
+        V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
+        s_or = normalize3(d);
+    } else {
+        s_or.x = src.s[0];
+        s_or.y = src.s[1];
+        s_or.z = src.s[2];
+    }
+
+    // ---- divergence (ray_source.py:290-351) ----
+    V3 s = s_or;
+    if (src.divergence != OT_DIV_NONE) {
+        double theta = 0.0, alpha = 0.0;
+        if (src.div_2d) {
+            double X = strat_interval(g, ST_DIV_ALPHA, 0.0, 2.0);
+            alpha = (X <= 1.0) ? src.div_axis : src.div_axis + M_PI;
+            switch (src.divergence) {
+                case OT_DIV_LAMBERTIAN: theta = asin(strat_interval(g, ST_DIV, 0.0, src.div_sin)); break;
+                case OT_DIV_ISOTROPIC: theta = strat_interval(g, ST_DIV, 0.0, src.div_rad); break;
+                default: {
+                    const double* F = src.div_tab + src.n_div;
+                    double X2 = strat_interval(g, ST_DIV, F[0], F[src.n_div - 1]);
+                    theta = inv_cdf_linear(src.div_tab, (int)src.n_div, X2);
+                }
+            }
+        } else {
+            double r;
+            strat_ring(g, ST_DIV, 0.0, src.div_sin, true, r, alpha);
+            switch (src.divergence) {
+                case OT_DIV_LAMBERTIAN: theta = asin(r); break;
+                case OT_DIV_ISOTROPIC: theta = acos(1 - r * r); break;
+                default: {
+                    const double* F = src.div_tab + src.n_div;
+                    double X0 = r * r / (src.div_sin * src.div_sin);
+                    theta = inv_cdf_linear(src.div_tab, (int)src.n_div, F[0] + X0 * (F[src.n_div - 1] - F[0]));
+                }
+            }
+        }
+        double fa = 1 / sqrt(1 - s_or.x * s_or.x);
+        V3 sy = {0.0, -s_or.z * fa, s_or.y * fa};
+        V3 sx = cross3(s_or, sy);
+        double st, ct, sa, ca;
+        sincos(theta, &st, &ct);
+        sincos(alpha, &sa, &ca);
+        s.x = ct * s_or.x + st * (ca * sx.x + sa * sy.x);
+        s.y = ct * s_or.y + st * (ca * sx.y + sa * sy.y);
+        s.z = ct * s_or.z + st * (ca * sx.z + sa * sy.z);
+    }
+    o.s = s;
+
+    // ---- polarisation (ray_source.py:359-433) ----
+    o.polx = o.poly = o.polz = 0.0;
+    if (!no_pol) {
+        double ang;
+        switch (src.polarization) {
+            case OT_POL_CONSTANT: ang = src.pol_angle; break;
+            case OT_POL_UNIFORM: ang = strat_interval(g, ST_POL, 0.0, 2 * M_PI); break;
+            case OT_POL_LIST: {
+                const double* F = src.pol_tab + src.n_pol;
+                ang = inv_cdf_discrete(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, 0.0, F[src.n_pol - 1]));
+                break;
+            }
+            default: {
+                const double* F = src.pol_tab + src.n_pol;
+                ang = inv_cdf_linear(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, F[0], F[src.n_pol - 1]));
+            }
+        }
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        double px = cs, py = sn, pz = 0.0;
+        if (s.z != 1) {
+            double fa = 1 / (sqrt(1 - s.z * s.z) + 1e-16);
+            V3 ps = {s.y * fa, -s.x * fa, 0.0};
+            double A_ts = ps.x * px + ps.y * py;
+            double A_tp = ps.y * px - ps.x * py;
+            V3 pp_ = cross3(ps, s);
+            px = ps.x * A_ts + pp_.x * A_tp;
+            py = ps.y * A_ts + pp_.y * A_tp;
+            pz = ps.z * A_ts + pp_.z * A_tp;
+        }
+        o.polx = px;
+        o.poly = py;
+        o.polz = pz;
+    }
+    return o;
+}

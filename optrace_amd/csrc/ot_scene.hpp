@@ -1,0 +1,106 @@
+// Device-side scene tables of the tracing kernels (gfx950).
+//
+// `ot_scene_create` turns the plain descriptors of include/optrace_amd.h into these "compiled" records:
+// every per-surface scalar sub-expression of the reference's NumPy code (e.g. (r + N_EPS)**2, 1/rho,
+// (k+1)*rho**2) is evaluated ONCE on the host with the same libm the reference uses, so that the per-ray
+// device code only contains IEEE +,-,*,/ and sqrt in the reference's operation order.  The records are
+// read through wave-uniform (scalar, SGPR) loads: every lane of a wavefront is at the same element of the
+// same scene, so a scalar broadcast beats an LDS copy (no LDS traffic, no bank conflicts, no barrier).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/optrace_amd.h"
+
+struct SurfDev {
+    int32_t kind;
+    int32_t ncoeff;
+    int32_t flat;  // z_max == z_min (surface.py:47)
+    int32_t rot;   // RECT/SLIT: angle != 0
+    double px, py, pz;
+    // masks
+    double r_eps2;   // (r + N_EPS)**2           surface.py:245
+    double ri_eps2;  // (ri - N_EPS)**2          ring_surface.py:133
+    double ox_lo, ox_hi, oy_lo, oy_hi;  // rect outer bounds incl. eps   rectangular_surface.py:112
+    double ix_lo, ix_hi, iy_lo, iy_hi;  // slit inner bounds incl. eps   slit_surface.py:100
+    double cna, sna;                    // cos(-angle), sin(-angle)     surface.py:432
+    // conic / asphere
+    double k, k1, rho, nrho, rho2, k1rho2, krho2, inv_rho, two_inv_rho;
+    double z_min, z_max;      // Surface.z_min / z_max
+    double z_lo, z_hi;        // z_min - N_EPS, z_max + N_EPS          conic_surface.py:162
+    double z_beh;             // z_max + N_EPS                          surface.py:460
+    double zt1, zt2;          // z_min - C_EPS/10, z_max + C_EPS/10     surface.py:331-332
+    double edge_val;          // value outside the mask                 surface.py:162
+    // hurb
+    double ri;                // ring inner radius
+    double hdx, hdy;          // dimi[0]/2, dimi[1]/2
+    double cpa, spa;          // cos(angle), sin(angle)                 slit_surface.py:83-84
+    double coeff[OT_MAX_ASPH];   // a2, a4, ...
+    double dcoeff[OT_MAX_ASPH];  // a_j * (2j+2): np.polyder coefficients
+};
+
+struct ElemDev {
+    int32_t kind, front, back, n_lens, n_after, filter, hurb, hurb_slot;
+    double D;      // ideal lens power
+    double f;      // 1000 / D
+    double fsign;  // np.sign(f)
+};
+
+struct FilterDev {
+    int32_t type, inverse, tab_len, _pad;
+    int64_t tab_off;
+    double val, wl0, wl1;
+    float mu32, den32, val32;  // Gaussian evaluated in float32: mu, 2*sig**2, val
+    float _pad2;
+};
+
+struct SceneDev {
+    double outline[6];
+    int32_t n_surfaces, n_elements, n_media, n_filters;
+    int32_t n0, no_pol, use_hurb, nt;
+    int32_t n_hurb, _pad;
+    double hurb_factor;
+    const SurfDev* surfaces;
+    const ElemDev* elements;
+    const ot_medium* media;
+    const FilterDev* filters;
+    const double* pool;
+    int64_t pool_len;
+};
+
+struct ot_scene {
+    SceneDev h;        // host copy of the header (pointers are device pointers)
+    SceneDev* d;       // device copy of the header
+    void* blob;        // one device allocation holding all tables
+    int device;
+};
+
+// ---- sources -------------------------------------------------------------------------------------------
+struct SourceDev {
+    int32_t shape, divergence, div_2d, orientation, polarization, spectrum, img_w, img_h;
+    double pos[3];
+    double r, ri, dim[2];
+    double ca, sa;          // cos/sin of the rectangle / line rotation
+    double div_sin;         // sin(radians(div_angle))          ray_source.py:303
+    double div_rad;         // radians(div_angle)
+    double div_axis;        // radians(div_axis_angle)
+    double s[3], conv_pos[3];
+    double pol_angle;
+    double wl, wl0, wl1, mu, sig;
+    double gauss_xl, gauss_xr;  // truncated-normal cdf bounds  light_spectrum.py:117-118
+    double power;
+    const double* spec_tab; int64_t n_spec;
+    const double* pol_tab;  int64_t n_pol;
+    const double* div_tab;  int64_t n_div;
+    const double* img_cdf;      // cumulative pixel pdf (img_w*img_h)
+    const double* img_rgb;      // per pixel cumulative primary mix: (r, r+g) / (r+g+b), 2 per pixel
+    const double* prim_tab;     // inverse-CDF tables of the three sRGB primaries: 3 x (PRIM_N wl, PRIM_N cdf)
+};
+
+struct ot_sources {
+    SourceDev* d;
+    int32_t n;
+    void* blob;
+    int device;
+};
+
+#define OT_PRIM_N 5000

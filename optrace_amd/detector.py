@@ -19,14 +19,17 @@ def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projec
     dev = require_device()
     ph = torch.empty(3 * count, dtype=torch.float64, device=dev)
     hw = torch.empty(count, dtype=torch.float32, device=dev)
-    ill = torch.zeros(1, dtype=torch.int64, device=dev)
+    ill = torch.zeros(2, dtype=torch.int64, device=dev)
     ext = None
     if want_extent:
         ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float64, device=dev)
     rs = rays._rays_struct()
     _capi.check(lib.ot_detector_hits(C.byref(rs), int(first), int(count), C.byref(surf_desc), int(projection),
                                      ptr(ph), ptr(hw), ptr(ext), ptr(ill), stream_ptr()))
-    return ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill.item())
+    ill_h = ill.cpu().numpy()
+    if ill_h[1]:
+        raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
+    return ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill_h[0])
 
 
 def project_points(surf_desc: _capi.Surface, p: np.ndarray, projection: int) -> np.ndarray:

@@ -32,8 +32,10 @@ def surface_find_hit(desc: _capi.Surface, p: np.ndarray, s: np.ndarray):
     hit = torch.empty(n, dtype=torch.uint8, device=dev)
     ill = torch.empty(n, dtype=torch.uint8, device=dev)
     _capi.check(lib.ot_surface_find_hit(C.byref(desc), n, ptr(dp), ptr(ds), ptr(ph), ptr(hit), ptr(ill), stream_ptr()))
-    return (np.asfortranarray(from_f_order(ph, n, 3)), hit.cpu().numpy().astype(bool),
-            ill.cpu().numpy().astype(bool))
+    ill_h = ill.cpu().numpy()
+    if np.any(ill_h & 2):
+        raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
+    return np.asfortranarray(from_f_order(ph, n, 3)), hit.cpu().numpy().astype(bool), (ill_h & 1).astype(bool)
 
 
 def surface_normals(desc: _capi.Surface, x, y) -> np.ndarray:

@@ -296,7 +296,7 @@ class Raytracer(Group):
         assert scene.nt == nt
         self.rays.init(self.ray_sources, N, nt, self.no_pol)
         rays = self.rays._rays_struct()
-        msgs = torch.zeros(len(self.INFOS) * nt, dtype=torch.int64, device=dev)
+        msgs = torch.zeros(len(self.INFOS) * nt + 1, dtype=torch.int64, device=dev)
         seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed)
 
         if _initial_rays is None:
@@ -313,7 +313,10 @@ class Raytracer(Group):
 
         torch.cuda.current_stream().synchronize()
         self.rays.lock()
-        self._msgs = msgs.cpu().numpy().reshape(len(self.INFOS), nt).astype(int)
+        msgs_h = msgs.cpu().numpy()
+        if msgs_h[-1]:
+            raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
+        self._msgs = msgs_h[:-1].reshape(len(self.INFOS), nt).astype(int)
         self._show_messages(N)
         self._last_trace_snapshot = self.tracing_snapshot()
 

@@ -1,0 +1,84 @@
+"""CPU-only checks of the C-ABI boundary: the HIP library loads, exports every symbol that
+include/optrace_amd.h declares, the ctypes structures mirror the header, and the product path refuses to
+run without a device instead of falling back to the CPU."""
+import ctypes as C
+import pathlib
+import re
+import subprocess
+
+import pytest
+
+from optrace_amd import _capi
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "optrace_amd.h"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not _capi.library_path().exists():
+        import __graft_entry__ as g
+        g.build()
+    return C.CDLL(str(_capi.library_path()))
+
+
+def declared_symbols():
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ot_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _capi.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_capi.SIGNATURES) == names
+
+
+def test_abi_version(lib):
+    lib.ot_abi_version.restype = C.c_int
+    assert lib.ot_abi_version() == 1
+
+
+def test_struct_layout_matches_header(tmp_path):
+    src = tmp_path / "sz.c"
+    names = ["ot_surface", "ot_medium", "ot_filter", "ot_element", "ot_scene_desc", "ot_source",
+             "ot_source_range", "ot_rays"]
+    body = "\n".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names)
+    extra = 'printf("off_coeff %zu\\n", offsetof(ot_surface, coeff)); printf("off_spec %zu\\n", offsetof(ot_source, spec_tab));'
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(){{{body}{extra}return 0;}}')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    py = {"ot_surface": _capi.Surface, "ot_medium": _capi.Medium, "ot_filter": _capi.Filter,
+          "ot_element": _capi.Element, "ot_scene_desc": _capi.SceneDesc, "ot_source": _capi.Source,
+          "ot_source_range": _capi.SourceRange, "ot_rays": _capi.Rays}
+    for n, cls in py.items():
+        assert C.sizeof(cls) == int(out[n]), n
+    assert _capi.Surface.coeff.offset == int(out["off_coeff"])
+    assert _capi.Source.spec_tab.offset == int(out["off_spec"])
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("device present")
+    import numpy as np
+    import optrace_amd as ot
+    sf = ot.SphericalSurface(r=1, R=5)
+    with pytest.raises(ot.BackendError):
+        sf.find_hit(np.zeros((2, 3)), np.array([[0., 0., 1.], [0., 0., 1.]]))
+    RT = ot.Raytracer(outline=[-1, 1, -1, 1, -1, 10])
+    RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0]))
+    with pytest.raises(ot.BackendError):
+        RT.trace(100)
+
+
+def test_product_package_does_not_reference_the_oracle():
+    """optrace_amd must not import, load or call anything under oracle/ (task rule 3)."""
+    for path in (ROOT / "optrace_amd").rglob("*"):
+        if path.suffix in (".py", ".hip", ".hpp", ".h", ".inc") and path.is_file():
+            text = path.read_text()
+            assert "liboracle" not in text and "oracle_bridge" not in text and "orc_" not in text, path
