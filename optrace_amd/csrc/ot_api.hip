@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,6 +18,8 @@
 // ---------------------------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------------------------
+#define OT_CNT_SLOTS 1024  // counter slot tables per scene (see trace_kernel)
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string& msg) {
@@ -159,50 +162,63 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     for (int i = 0; i < desc->n_surfaces; i++)
         if (int rc = compile_surface(desc->surfaces[i], surfs[i])) return rc;
 
-    std::vector<ElemDev> elems(desc->n_elements);
-    int nt = 2, n_hurb = 0;
+    // flatten elements into one step per tracing surface
+    std::vector<StepDev> steps;
+    int n_hurb = 0;
     for (int i = 0; i < desc->n_elements; i++) {
         const ot_element& e = desc->elements[i];
-        ElemDev& d = elems[i];
-        std::memset(&d, 0, sizeof(d));
-        d.kind = e.kind;
-        d.front = e.front;
-        d.back = e.back;
-        d.n_lens = e.n_lens;
-        d.n_after = e.n_after;
-        d.filter = e.filter;
-        d.hurb = (desc->use_hurb && e.hurb && e.kind == OT_EL_APERTURE && i != desc->n_elements - 1) ? 1 : 0;
-        d.hurb_slot = d.hurb ? n_hurb++ : -1;
         if (e.front < 0 || e.front >= desc->n_surfaces) return fail(OT_ERR_INVALID, "element: front surface out of range");
+        StepDev d;
+        std::memset(&d, 0, sizeof(d));
+        d.surf = e.front;
+        d.n_next = -1;
+        d.filter = -1;
+        d.hurb_slot = -1;
         switch (e.kind) {
-            case OT_EL_LENS:
+            case OT_EL_LENS: {
                 if (e.back < 0 || e.back >= desc->n_surfaces) return fail(OT_ERR_INVALID, "lens: back surface out of range");
                 if (e.n_lens < 0 || e.n_lens >= desc->n_media || e.n_after < 0 || e.n_after >= desc->n_media)
                     return fail(OT_ERR_INVALID, "lens: medium out of range");
-                nt += 2;
+                d.kind = OT_STEP_LENS_FRONT;
+                d.n_next = e.n_lens;
+                steps.push_back(d);
+                d.kind = OT_STEP_LENS_BACK;
+                d.surf = e.back;
+                d.n_next = e.n_after;
+                steps.push_back(d);
                 break;
+            }
             case OT_EL_IDEAL_LENS:
                 if (e.n_after < 0 || e.n_after >= desc->n_media) return fail(OT_ERR_INVALID, "ideal lens: medium out of range");
                 if (e.D == 0.0) return fail(OT_ERR_INVALID, "ideal lens: optical power must be non-zero");
-                d.D = e.D;
+                d.kind = OT_STEP_IDEAL;
+                d.n_next = e.n_after;
                 d.f = 1000 / e.D;
                 d.fsign = (d.f > 0) - (d.f < 0);
-                nt += 1;
+                steps.push_back(d);
                 break;
             case OT_EL_FILTER:
                 if (e.filter < 0 || e.filter >= desc->n_filters) return fail(OT_ERR_INVALID, "filter index out of range");
-                nt += 1;
+                d.kind = OT_STEP_FILTER;
+                d.filter = e.filter;
+                steps.push_back(d);
                 break;
             case OT_EL_APERTURE:
+                d.kind = OT_STEP_APERTURE;
+                d.hurb = (desc->use_hurb && e.hurb && i != desc->n_elements - 1) ? 1 : 0;  // raytracer.py:385
                 if (d.hurb && surfs[e.front].kind != OT_SURF_RING && surfs[e.front].kind != OT_SURF_SLIT)
                     return fail(OT_ERR_UNSUPPORTED, "HURB is only defined for ring and slit apertures (raytracer.py:548-552)");
-                nt += 1;
+                d.hurb_slot = d.hurb ? n_hurb++ : -1;
+                steps.push_back(d);
                 break;
             default:
                 return fail(OT_ERR_INVALID, "element: unknown kind");
         }
     }
-    nt -= 1;  // sections = tracing surfaces + 2; the loop above started from 2 and the end aperture is a surface
+    bool needs_full = false;  // anything beyond conic/flat lens surfaces and plain apertures
+    for (const StepDev& d : steps)
+        needs_full |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER || d.hurb || surfs[d.surf].kind == OT_SURF_ASPHERE;
+    const int nt = (int)steps.size() + 1;  // sections = tracing surfaces + 2, the end aperture being a step
 
     std::vector<FilterDev> filts(desc->n_filters > 0 ? desc->n_filters : 1);
     for (int i = 0; i < desc->n_filters; i++) {
@@ -223,8 +239,12 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
             (f.tab_off < 0 || f.tab_off + 2 * (int64_t)f.tab_len > desc->table_pool_len))
             return fail(OT_ERR_INVALID, "filter table outside the pool");
     }
+    bool needs_tables = false;
+    for (int i = 0; i < desc->n_filters; i++)
+        needs_tables |= (desc->filters[i].type == OT_T_DATA || desc->filters[i].type == OT_T_LINES);
     for (int i = 0; i < desc->n_media; i++) {
         const ot_medium& m = desc->media[i];
+        needs_tables |= (m.model == OT_N_DATA || m.model == OT_N_LINES);
         if ((m.model == OT_N_DATA || m.model == OT_N_LINES) &&
             (m.tab_off < 0 || m.tab_off + 2 * (int64_t)m.tab_len > desc->table_pool_len))
             return fail(OT_ERR_INVALID, "medium table outside the pool");
@@ -234,11 +254,12 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     size_t o_hdr = 0;
     size_t o_surf = align_up(o_hdr + sizeof(SceneDev));
     size_t o_elem = align_up(o_surf + sizeof(SurfDev) * surfs.size());
-    size_t o_med = align_up(o_elem + sizeof(ElemDev) * elems.size());
+    size_t o_med = align_up(o_elem + sizeof(StepDev) * steps.size());
     size_t o_flt = align_up(o_med + sizeof(ot_medium) * desc->n_media);
     size_t o_pool = align_up(o_flt + sizeof(FilterDev) * filts.size());
     size_t pool_n = desc->table_pool_len > 0 ? (size_t)desc->table_pool_len : 1;
-    size_t total = align_up(o_pool + sizeof(double) * pool_n);
+    size_t o_cnt = align_up(o_pool + sizeof(double) * pool_n);
+    size_t total = align_up(o_cnt + sizeof(unsigned int) * (size_t)OT_CNT_SLOTS * (OT_N_INFOS * nt + 1));
 
     std::vector<char> host(total, 0);
     char* blob = nullptr;
@@ -248,7 +269,7 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     std::memset(&h, 0, sizeof(h));
     std::memcpy(h.outline, desc->outline, sizeof(h.outline));
     h.n_surfaces = desc->n_surfaces;
-    h.n_elements = desc->n_elements;
+    h.n_steps = (int32_t)steps.size();
     h.n_media = desc->n_media;
     h.n_filters = desc->n_filters;
     h.n0 = desc->n0;
@@ -258,7 +279,7 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     h.n_hurb = n_hurb;
     h.hurb_factor = desc->hurb_factor;
     h.surfaces = (const SurfDev*)(blob + o_surf);
-    h.elements = (const ElemDev*)(blob + o_elem);
+    h.steps = (const StepDev*)(blob + o_elem);
     h.media = (const ot_medium*)(blob + o_med);
     h.filters = (const FilterDev*)(blob + o_flt);
     h.pool = (const double*)(blob + o_pool);
@@ -266,7 +287,7 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
 
     std::memcpy(host.data() + o_hdr, &h, sizeof(h));
     std::memcpy(host.data() + o_surf, surfs.data(), sizeof(SurfDev) * surfs.size());
-    std::memcpy(host.data() + o_elem, elems.data(), sizeof(ElemDev) * elems.size());
+    std::memcpy(host.data() + o_elem, steps.data(), sizeof(StepDev) * steps.size());
     std::memcpy(host.data() + o_med, desc->media, sizeof(ot_medium) * desc->n_media);
     std::memcpy(host.data() + o_flt, filts.data(), sizeof(FilterDev) * filts.size());
     if (desc->table_pool_len > 0)
@@ -279,6 +300,9 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
 
     ot_scene* sc = new ot_scene;
     sc->h = h;
+    sc->needs_tables = needs_tables;
+    sc->cnt_slots = (unsigned int*)(blob + o_cnt);
+    sc->needs_full = needs_full;
     sc->d = (SceneDev*)(blob + o_hdr);
     sc->blob = blob;
     (void)hipGetDevice(&sc->device);
@@ -455,6 +479,9 @@ extern "C" void ot_sources_destroy(ot_sources* s) {
 // kernels
 // ---------------------------------------------------------------------------------------------------------
 #define OT_MAX_RANGES 64
+#ifndef OT_TRACE_MIN_WAVES
+#define OT_TRACE_MIN_WAVES 1
+#endif
 
 struct RangeArgs {
     int32_t n;
@@ -476,50 +503,99 @@ OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& src) 
     return false;
 }
 
-// Raytracer.trace: optional on-the-fly generation, then all elements.  256 threads = 4 waves per workgroup.
-template <bool POL, bool GEN>
-__global__ __launch_bounds__(256) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
+// Raytracer.trace: optional on-the-fly generation, then all steps.  One ray per lane, 256-thread workgroups
+// (4 wave64); template switches select a kernel that only contains what the scene needs:
+//   POL  polarisation tracked          GEN  rays generated in registers (no section-0 round trip)
+//   TAB  tabulated media/filters or injected HURB normals (per-lane global loads inside the loop)
+//   FULL numeric (aspheric) surfaces, ideal lenses, filters, HURB; without it the kernel holds only conic /
+//        flat surfaces and apertures: 98 VGPRs instead of 165
+// Event counters go wave -> LDS (per workgroup) -> one of OT_CNT_SLOTS global slot tables (blockIdx % slots) ->
+// reduce_counters_kernel, so that no two workgroups hammer the same address (see count_event).
+template <bool POL, bool GEN, bool TAB, bool FULL>
+__global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
                                                     const SourceDev* __restrict__ sources, RangeArgs rg,
                                                     const double* __restrict__ hurb_normals, uint64_t seed,
-                                                    unsigned long long* __restrict__ msgs) {
+                                                    unsigned int* __restrict__ slots) {
+    extern __shared__ unsigned int cnt[];  // (OT_N_INFOS x nt) event counters + 1 timeout flag
+    auto& sc = *as_const(scp);
+    const int n_cnt = OT_N_INFOS * sc.nt + 1;
+    for (int k = threadIdx.x; k < n_cnt; k += blockDim.x) cnt[k] = 0u;
+    __syncthreads();
+
     const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ray >= R.N) return;
-    const SceneDev& sc = *scp;
+    bool have = ray < R.N;
     RayState r;
-    if (GEN) {
-        GenCtx g;
-        g.seed = seed;
-        g.gidx = (uint64_t)ray;
-        int src = 0;
-        if (!locate_range(rg, ray, g, src)) return;
-        NewRay nr = generate_ray(sources[src], g, !POL);
-        r.p = nr.p;
-        r.s = nr.s;
-        r.w = nr.w;
-        r.wl = nr.wl;
-        r.polx = (float)nr.polx;
-        r.poly = (float)nr.poly;
-        r.polz = (float)nr.polz;
-        R.wl[ray] = r.wl;
-    } else {
-        const int64_t N = R.N, nt = R.nt;
-        r.p.x = R.p[ray];
-        r.p.y = R.p[ray + N * nt];
-        r.p.z = R.p[ray + N * 2 * nt];
-        r.s.x = R.s[ray];
-        r.s.y = R.s[ray + N];
-        r.s.z = R.s[ray + 2 * N];
-        r.w = R.w[ray];
-        r.wl = R.wl[ray];
-        r.polx = r.poly = r.polz = 0.f;
-        if (POL) {
-            r.polx = R.pol[ray];
-            r.poly = R.pol[ray + N * nt];
-            r.polz = R.pol[ray + N * 2 * nt];
+    if (have) {
+        if (GEN) {
+            GenCtx g;
+            g.seed = seed;
+            g.gidx = (uint64_t)ray;
+            int src = 0;
+            have = locate_range(rg, ray, g, src);
+            if (have) {
+                fill_dither(g);
+                NewRay nr = generate_ray(sources[src], g, !POL);
+                r.p = nr.p;
+                r.s = nr.s;
+                r.w = nr.w;
+                r.wl = nr.wl;
+                r.polx = (float)nr.polx;
+                r.poly = (float)nr.poly;
+                r.polz = (float)nr.polz;
+                R.wl[ray] = r.wl;
+            }
+        } else {
+            const int64_t N = R.N, nt = R.nt;
+            r.p.x = R.p[ray];
+            r.p.y = R.p[ray + N * nt];
+            r.p.z = R.p[ray + N * 2 * nt];
+            r.s.x = R.s[ray];
+            r.s.y = R.s[ray + N];
+            r.s.z = R.s[ray + 2 * N];
+            r.w = R.w[ray];
+            r.wl = R.wl[ray];
+            r.polx = r.poly = r.polz = 0.f;
+            if (POL) {
+                r.polx = R.pol[ray];
+                r.poly = R.pol[ray + N * nt];
+                r.polz = R.pol[ray + N * 2 * nt];
+            }
         }
     }
-    bool ok = trace_ray<POL>(sc, R, ray, r, hurb_normals, seed, msgs);
-    if (!ok) atomicOr(&msgs[OT_N_INFOS * sc.nt], 1ull);  // numeric hit search timed out (surface.py:403)
+    if (have) {
+        bool ok = trace_ray<POL, TAB, FULL>(sc, R, ray, r, hurb_normals, seed, cnt);
+        if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)
+    }
+    __syncthreads();
+    unsigned int* slot = slots + (size_t)(blockIdx.x % OT_CNT_SLOTS) * n_cnt;
+    for (int k = threadIdx.x; k < n_cnt; k += blockDim.x)
+        if (cnt[k]) atomicAdd(&slot[k], cnt[k]);
+}
+
+// sums the slot tables into the caller's int64 counters (ADD) and clears them for the next launch:
+// one workgroup per counter, one lane per 4 slots, wave shuffle + LDS reduction
+__global__ __launch_bounds__(256) void reduce_counters_kernel(unsigned int* __restrict__ slots, int n_cnt,
+                                                              unsigned long long* __restrict__ msgs) {
+    __shared__ unsigned long long part[4];
+    const int k = blockIdx.x;
+    unsigned long long sum = 0;
+    for (int sidx = threadIdx.x; sidx < OT_CNT_SLOTS; sidx += blockDim.x) {
+        unsigned int v = slots[(size_t)sidx * n_cnt + k];
+        if (v) {
+            sum += v;
+            slots[(size_t)sidx * n_cnt + k] = 0u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) {
+            if (k == n_cnt - 1) msgs[k] = 1ull; else msgs[k] += t;
+        }
+    }
 }
 
 // RaySource.create_rays only: writes section 0 (ot_rays_generate)
@@ -533,6 +609,7 @@ __global__ __launch_bounds__(256) void generate_kernel(ot_rays R, const SourceDe
     g.gidx = (uint64_t)ray;
     int src = 0;
     if (!locate_range(rg, ray, g, src)) return;
+    fill_dither(g);
     NewRay nr = generate_ray(sources[src], g, !POL);
     const int64_t N = R.N, nt = R.nt;
     R.p[ray] = nr.p.x;
@@ -677,13 +754,26 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     const SourceDev* sd = src ? src->d : nullptr;
     unsigned long long* m = (unsigned long long*)msgs;
     dim3 grid = grid_for(rays->N), block(256);
+    // kernel variant: polarisation x on-device generation x per-lane table loads x feature set
+    const bool tab = sc->needs_tables || hurb_normals != nullptr;
+    const bool full = sc->needs_full;
+    const int n_cnt = OT_N_INFOS * sc->h.nt + 1;
+    const size_t lds = sizeof(unsigned int) * (size_t)n_cnt;
+    unsigned int* slots = sc->cnt_slots;
+#define OT_LAUNCH(P, G, T, F) \
+    hipLaunchKernelGGL((trace_kernel<P, G, T, F>), grid, block, lds, st, sc->d, *rays, sd, r, hurb_normals, seed, slots)
+#define OT_LAUNCH_F(P, G, T) do { if (full) OT_LAUNCH(P, G, T, true); else OT_LAUNCH(P, G, T, false); } while (0)
+#define OT_LAUNCH_T(P, G) do { if (tab) OT_LAUNCH_F(P, G, true); else OT_LAUNCH_F(P, G, false); } while (0)
     if (src) {
-        if (pol) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
-        else     hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
+        if (pol) OT_LAUNCH_T(true, true); else OT_LAUNCH_T(false, true);
     } else {
-        if (pol) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
-        else     hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, st, sc->d, *rays, sd, r, hurb_normals, seed, m);
+        if (pol) OT_LAUNCH_T(true, false); else OT_LAUNCH_T(false, false);
     }
+#undef OT_LAUNCH_T
+#undef OT_LAUNCH_F
+#undef OT_LAUNCH
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3(n_cnt), dim3(256), 0, st, slots, n_cnt, m);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

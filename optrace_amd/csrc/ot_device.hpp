@@ -12,6 +12,14 @@
 
 #define OT_DEV __device__ __forceinline__
 
+// Scene tables are read through the CONSTANT address space: with a wave-uniform index the backend then emits
+// scalar loads (s_load_dwordx*) into SGPRs instead of per-lane flat loads into VGPRs.
+#define OT_CONST __attribute__((address_space(4)))
+template <class T>
+OT_DEV const OT_CONST T* as_const(const T* p) {
+    return (const OT_CONST T*)p;
+}
+
 struct V3 {
     double x, y, z;
 };
@@ -38,7 +46,8 @@ OT_DEV V3 along(const V3& p, const V3& s, double t) {
 }
 
 // ---- masks: surface.py:235, ring_surface.py:123, rectangular_surface.py:100, slit_surface.py:89 ----------
-OT_DEV bool surf_mask(const SurfDev& sf, double x, double y) {
+template <class SF>
+OT_DEV bool surf_mask(SF& sf, double x, double y) {
     if (sf.kind == OT_SURF_RECT || sf.kind == OT_SURF_SLIT) {
         double dx = x - sf.px, dy = y - sf.py;
         double xr = dx, yr = dy;
@@ -60,7 +69,8 @@ OT_DEV bool surf_mask(const SurfDev& sf, double x, double y) {
 
 // numpy.polyval over AsphericSurface._np_coeff (aspheric_surface.py:104-113): Horner including the zero
 // odd-order coefficients, i.e. y = (y*r + a)*r + 0 per even coefficient
-OT_DEV double asph_poly(const SurfDev& sf, double r) {
+template <class SF>
+OT_DEV double asph_poly(SF& sf, double r) {
     double y = 0.0;
     for (int j = sf.ncoeff - 1; j >= 0; j--) {
         y = y * r + sf.coeff[j];
@@ -70,7 +80,8 @@ OT_DEV double asph_poly(const SurfDev& sf, double r) {
     return y;
 }
 
-OT_DEV double asph_poly_deriv(const SurfDev& sf, double r) {  // polyval(polyder(..)) aspheric_surface.py:79
+template <class SF>
+OT_DEV double asph_poly_deriv(SF& sf, double r) {  // polyval(polyder(..)) aspheric_surface.py:79
     double y = 0.0;
     for (int j = sf.ncoeff - 1; j >= 0; j--) {
         y = y * r + sf.dcoeff[j];
@@ -80,7 +91,8 @@ OT_DEV double asph_poly_deriv(const SurfDev& sf, double r) {  // polyval(polyder
 }
 
 // Surface._values relative to the centre: conic_surface.py:57, aspheric_surface.py:51
-OT_DEV double surf_values_rel(const SurfDev& sf, double x, double y) {
+template <class SF>
+OT_DEV double surf_values_rel(SF& sf, double x, double y) {
     if (sf.kind == OT_SURF_CONIC) {
         double r2 = x * x + y * y;
         return sf.rho * r2 / (1 + sqrt(1 - sf.k1rho2 * r2));
@@ -93,7 +105,8 @@ OT_DEV double surf_values_rel(const SurfDev& sf, double x, double y) {
 }
 
 // Surface.values surface.py:137-164
-OT_DEV double surf_values(const SurfDev& sf, double x, double y) {
+template <class SF>
+OT_DEV double surf_values(SF& sf, double x, double y) {
     if (sf.flat) return sf.z_max;
     if (surf_mask(sf, x, y)) return sf.pz + surf_values_rel(sf, x - sf.px, y - sf.py);
     return sf.edge_val;
@@ -103,7 +116,8 @@ OT_DEV double surf_values(const SurfDev& sf, double x, double y) {
 // FunctionSurface2D.normals (1D branch) function_surface_2d.py:216-251 + AsphericSurface._deriv :67-82.
 // cos(atan2(dy,dx)) and sin(atan2(dy,dx)) are formed as dx/r, dy/r: same value to 1-2 ulp without three
 // transcendental calls per ray (normals never feed a mask directly; tolerance 1e-6).
-OT_DEV V3 surf_normal(const SurfDev& sf, double x, double y) {
+template <class SF>
+OT_DEV V3 surf_normal(SF& sf, double x, double y) {
     V3 n = {0.0, 0.0, 1.0};
     if (sf.kind != OT_SURF_CONIC && sf.kind != OT_SURF_ASPHERE) return n;
     if (sf.flat) return n;
@@ -135,7 +149,8 @@ OT_DEV V3 surf_normal(const SurfDev& sf, double x, double y) {
 }
 
 // Surface._find_hit_handle_abnormal surface.py:436-479
-OT_DEV void handle_abnormal(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
+template <class SF>
+OT_DEV void handle_abnormal(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
     double zs = surf_values(sf, ph.x, ph.y);
     bool dev = fabs(ph.z - zs) > OT_C_EPS;
     bool beh = p.z > sf.z_beh;
@@ -152,7 +167,8 @@ OT_DEV void handle_abnormal(const SurfDev& sf, const V3& p, const V3& s, V3& ph,
 }
 
 // ConicSurface.find_hit conic_surface.py:126-203 (closed-form quadratic)
-OT_DEV void find_hit_conic(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
+template <class SF>
+OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
     double ox = p.x - sf.px, oy = p.y - sf.py, oz = p.z - sf.pz;
     double A = (sf.k != 0.0) ? 1 + sf.k * (s.z * s.z) : 1.0;
     double ozk = oz * sf.k1;
@@ -191,7 +207,8 @@ OT_DEV void find_hit_conic(const SurfDev& sf, const V3& p, const V3& s, V3& ph, 
 // loop below runs while the 64-bit ballot of unconverged lanes is non-zero (one scalar branch per iteration)
 // and converged lanes idle, so a wave pays max(iterations) of its own 64 rays only.
 // Returns false if a lane hit the 200-iteration timeout (surface.py:403).
-OT_DEV bool find_hit(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& ill) {
+template <bool NUMERIC = true, class SF>
+OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& ill) {
     ill = false;
     if (sf.kind == OT_SURF_CONIC) {
         find_hit_conic(sf, p, s, ph, hit);
@@ -202,6 +219,11 @@ OT_DEV bool find_hit(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& 
         ph = along(p, s, t);
         hit = surf_mask(sf, ph.x, ph.y);
         handle_abnormal(sf, p, s, ph, hit);
+        return true;
+    }
+    if (!NUMERIC) {  // kernel variant without numeric surfaces: unreachable, keeps the Illinois loop out of it
+        ph = p;
+        hit = false;
         return true;
     }
     double t1 = (sf.zt1 - p.z) / s.z;
@@ -254,7 +276,8 @@ OT_DEV bool find_hit(const SurfDev& sf, const V3& p, const V3& s, V3& ph, bool& 
 }
 
 // RingSurface.hurb_props ring_surface.py:88-121, SlitSurface.hurb_props slit_surface.py:65-87
-OT_DEV void hurb_props(const SurfDev& sf, double x, double y, double& a_, double& b_, V3& b, bool& inside) {
+template <class SF>
+OT_DEV void hurb_props(SF& sf, double x, double y, double& a_, double& b_, V3& b, bool& inside) {
     double dx = x - sf.px, dy = y - sf.py;
     if (sf.kind == OT_SURF_RING) {
         double r = sqrt(dx * dx + dy * dy);
@@ -282,7 +305,8 @@ OT_DEV void hurb_props(const SurfDev& sf, double x, double y, double& a_, double
 // ---- media: RefractionIndex.__call__ refraction_index.py:62-169 ------------------------------------------
 // numpy.interp on a sorted table (compiled_base.c arr_interp): binary search for the interval, exact value
 // on a node, linear elsewhere; `left`/`right` = 0 outside (spectrum.py:106)
-OT_DEV double interp_tab(double x, const double* __restrict__ xp, const double* __restrict__ fp, int n) {
+template <class PL>
+OT_DEV double interp_tab(double x, PL xp, PL fp, int n) {
     if (isnan(x)) return x;
     if (x < xp[0] || x > xp[n - 1]) return 0.0;
     int lo = 0, hi = n - 1;
@@ -307,9 +331,15 @@ OT_DEV double interp_tab(double x, const double* __restrict__ xp, const double* 
 
 OT_DEV double ipow3(double x) { return pow(x, 3.0); }
 
-OT_DEV double medium_n(const ot_medium& md, const double* __restrict__ pool, float wl32) {
+// TAB = false compiles the table models (per-lane global loads) out.  That matters far beyond the two cases:
+// vmcnt retires in order, so ANY vector-memory load in the tracing loop makes the compiler wait for all section
+// stores issued before it (and, through control-flow merges, before every write of the register the load might
+// target).  Scenes without tabulated media/filters therefore run a loop that contains no VMEM load at all and
+// never drains its store queue.
+template <bool TAB = true, class MD, class PL>
+OT_DEV double medium_n(MD& md, PL pool, float wl32) {
     double wl = (double)wl32;
-    const double* c = md.c;
+    auto* c = md.c;
     double um = wl * 1e-3;
     double wl2 = um * um;
     switch (md.model) {
@@ -347,11 +377,13 @@ OT_DEV double medium_n(const ot_medium& md, const double* __restrict__ pool, flo
             return sqrt(c[0] + c[1] * wl2 + c[2] * (wl2 * wl2) + c[3] / wl2 + c[4] / (wl2 * wl2) +
                         c[5] / pow(wl2, 3.0) + c[6] * pow(wl2, 4.0) + c[7] * pow(wl2, 5.0) + c[8] / pow(wl2, 6.0));
         case OT_N_DATA: {
-            const double* xp = pool + md.tab_off;
+            if (!TAB) break;
+            auto xp = pool + md.tab_off;
             return interp_tab(wl, xp, xp + md.tab_len, md.tab_len);
         }
         case OT_N_LINES: {
-            const double* xp = pool + md.tab_off;
+            if (!TAB) break;
+            auto xp = pool + md.tab_off;
             double v = __builtin_nan("");
             for (int j = 0; j < md.tab_len; j++)
                 if (xp[j] == wl) v = xp[md.tab_len + j];
@@ -362,13 +394,15 @@ OT_DEV double medium_n(const ot_medium& md, const double* __restrict__ pool, flo
 }
 
 // Filter.__call__ filter.py:39 -> transmission_spectrum.py:73-84 -> spectrum.py:81-120
-OT_DEV double filter_T(const FilterDev& f, const double* __restrict__ pool, float wl32) {
+template <bool TAB = true, class FD, class PL>
+OT_DEV double filter_T(FD& f, PL pool, float wl32) {
     double wl = (double)wl32;
     double T;
     switch (f.type) {
         case OT_T_CONSTANT: T = f.val; break;
         case OT_T_DATA: {
-            const double* xp = pool + f.tab_off;
+            if (!TAB) { T = __builtin_nan(""); break; }
+            auto xp = pool + f.tab_off;
             T = interp_tab(wl, xp, xp + f.tab_len, f.tab_len);
             break;
         }
@@ -380,8 +414,9 @@ OT_DEV double filter_T(const FilterDev& f, const double* __restrict__ pool, floa
             break;
         }
         case OT_T_LINES: {
-            const double* xp = pool + f.tab_off;
             T = __builtin_nan("");
+            if (!TAB) break;
+            auto xp = pool + f.tab_off;
             for (int j = 0; j < f.tab_len; j++)
                 if (xp[j] == wl) T = xp[f.tab_len + j];
             break;

@@ -50,9 +50,15 @@ OT_DEV uint32_t permute_index(uint32_t i, uint32_t l, uint32_t key) {
     return (i + key) % l;
 }
 
+// permutation key of one (seed, range, stream): a 32-bit finaliser-style mix (wave-uniform, a few SALU ops)
 OT_DEV uint32_t stream_key(uint64_t seed, uint32_t range, uint32_t stream) {
-    Philox p = philox4x32(range, stream, 0x5eedu, 0x0badu, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return p.c[0];
+    uint32_t h = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (range * 0x85EBCA77u) ^ (stream * 0xC2B2AE3Du);
+    h ^= h >> 16;
+    h *= 0x7feb352du;
+    h ^= h >> 15;
+    h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return h;
 }
 
 struct GenCtx {
@@ -61,13 +67,40 @@ struct GenCtx {
     uint32_t j;      // index inside the source range
     uint32_t n;      // rays in the source range (stratification domain)
     uint32_t range;  // range id (permutation keys differ per range)
+    double u[8];     // dither values in [0,1): two Philox-4x32-10 calls per ray, 32 random bits each
 };
+
+// stream -> which of the 8 dither values it uses (pairs for the 2-D samplers)
+OT_DEV int dither_slot(uint32_t stream) {
+    switch (stream) {
+        case ST_POS: return 0;         // u0, u1
+        case ST_PIX_JITTER: return 6;  // u6, u7 (image sources; ST_POS unused there)
+        case ST_DIV: return 2;         // u2, u3
+        case ST_WL: return 4;
+        case ST_POL: return 5;
+        case ST_DIV_ALPHA: return 6;
+        case ST_RGB_CHOICE: return 0;  // image sources only
+        case ST_RGB_WL: return 1;      // image sources only
+        default: return 3;             // ST_PIXEL (image sources; u3 is free there unless the divergence is 3-D,
+                                       // in which case pixel choice and divergence radius share a dither value
+                                       // but not a permutation, which keeps them independent across rays)
+    }
+}
+
+OT_DEV void fill_dither(GenCtx& g) {
+    Philox a = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e31u, 0, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+    Philox b = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e32u, 1, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        g.u[k] = ((double)a.c[k] + 0.5) * 0x1.0p-32;
+        g.u[4 + k] = ((double)b.c[k] + 0.5) * 0x1.0p-32;
+    }
+}
 
 // random.stratified_interval_sampling random.py:48-67: one of n strata of [a, b), uniformly dithered
 OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double b) {
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
-    double u0, u1;
-    philox_u2(g.seed, g.gidx, stream, 0, u0, u1);
+    double u0 = g.u[dither_slot(stream)];
     double dba = (b - a) / (double)g.n;
     return a + ((double)k + u0) * dba;
 }
@@ -76,8 +109,8 @@ OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double 
 // n - N2^2 samples uniform over the rectangle
 OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, double c, double d, double& x, double& y) {
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
-    double u0, u1;
-    philox_u2(g.seed, g.gidx, stream, 0, u0, u1);
+    const int slot = dither_slot(stream);
+    double u0 = g.u[slot], u1 = g.u[slot + 1];
     uint32_t N2 = (uint32_t)sqrt((double)g.n);
     while ((uint64_t)N2 * N2 > g.n) N2--;
     while ((uint64_t)(N2 + 1) * (N2 + 1) <= g.n) N2++;

@@ -38,11 +38,17 @@ struct SurfDev {
     double dcoeff[OT_MAX_ASPH];  // a_j * (2j+2): np.polyder coefficients
 };
 
-struct ElemDev {
-    int32_t kind, front, back, n_lens, n_after, filter, hurb, hurb_slot;
-    double D;      // ideal lens power
-    double f;      // 1000 / D
-    double fsign;  // np.sign(f)
+// One step per tracing surface, in ray order (the element list of raytracer.py:492-508 flattened).
+#define OT_STEP_LENS_FRONT 0  // raytracer.py:316-338  medium behind = lens material
+#define OT_STEP_LENS_BACK 1   // raytracer.py:340-367  medium behind = n2 or n0
+#define OT_STEP_IDEAL 2       // raytracer.py:360-363
+#define OT_STEP_FILTER 3      // raytracer.py:379-380
+#define OT_STEP_APERTURE 4    // raytracer.py:381-386
+
+struct StepDev {
+    int32_t kind, surf, n_next, filter, hurb, hurb_slot, _pad0, _pad1;
+    double f;      // ideal lens: 1000 / D          raytracer.py:748
+    double fsign;  // ideal lens: np.sign(f)        raytracer.py:755
 };
 
 struct FilterDev {
@@ -55,12 +61,12 @@ struct FilterDev {
 
 struct SceneDev {
     double outline[6];
-    int32_t n_surfaces, n_elements, n_media, n_filters;
+    int32_t n_surfaces, n_steps, n_media, n_filters;
     int32_t n0, no_pol, use_hurb, nt;
     int32_t n_hurb, _pad;
     double hurb_factor;
     const SurfDev* surfaces;
-    const ElemDev* elements;
+    const StepDev* steps;
     const ot_medium* media;
     const FilterDev* filters;
     const double* pool;
@@ -72,6 +78,9 @@ struct ot_scene {
     SceneDev* d;       // device copy of the header
     void* blob;        // one device allocation holding all tables
     int device;
+    unsigned int* cnt_slots;  // OT_CNT_SLOTS x (5*nt+1) counter slot tables (zero between launches)
+    bool needs_full;   // aspheres, ideal lenses, filters or HURB present: full-feature kernel variant
+    bool needs_tables; // some medium / filter is tabulated (DATA / LINES): per-lane global loads in the loop
 };
 
 // ---- sources -------------------------------------------------------------------------------------------
