@@ -917,9 +917,14 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     a.Ny = Ny;
     const double* table = observer_table_device();
     if (!table) return fail(OT_ERR_HIP, "could not upload the CIE observer table");
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;  // grid-stride: the LDS table is staged once per workgroup
-    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, px, py, w, wl, a, table, hist);
+    // one 1024-thread workgroup per CU (grid-stride): LDS-privatised histogram, see render_kernel
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, n, px, py, w, wl, a, table, hist);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

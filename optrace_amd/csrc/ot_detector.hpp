@@ -186,14 +186,28 @@ static const double* observer_table_device() {
     return tab[dev];
 }
 
-// RenderImage.render render_image.py:396-418.  The 471x3 observer table (11 KB) is staged in LDS once per
-// workgroup because every lane indexes it with its own wavelength; hist updates are f64 hardware atomics
-// (global_atomic_add_f64) on the (Ny, Nx, 4) image.
-__global__ __launch_bounds__(256) void render_kernel(int64_t n, const double* __restrict__ px, const double* __restrict__ py,
-                                                     const float* __restrict__ w, const float* __restrict__ wl, RenderArgs a,
-                                                     const double* __restrict__ table, double* __restrict__ hist) {
+// RenderImage.render render_image.py:396-418.
+//   * the 471x3 CIE observer table (11 KB) is staged in LDS once per workgroup: every lane indexes it with its
+//     own wavelength;
+//   * histogram updates are privatised per workgroup in an LDS hash table (pixel -> 4 x f64, ds_add_f64):
+//     images of point-like objects put millions of hits into a few hundred pixels, and global f64 atomics to the
+//     same few cache lines serialise in one L2 channel (measured: 90 ms for 10 M hits).  The grid is one
+//     1024-thread workgroup per CU, so the final flush issues at most OT_HASH_N x 4 global atomics per CU;
+//   * hits that find their hash neighbourhood occupied (wide images) fall back to global_atomic_add_f64, which
+//     is the fast path for spread-out addresses.
+#define OT_HASH_N 2048      // entries per workgroup (72 KB of LDS with the values)
+#define OT_HASH_PROBES 4    // linear probes before falling back to a global atomic
+#define OT_HASH_EMPTY (-1)
+
+__global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* __restrict__ px, const double* __restrict__ py,
+                                                      const float* __restrict__ w, const float* __restrict__ wl, RenderArgs a,
+                                                      const double* __restrict__ table, double* __restrict__ hist) {
     __shared__ double obs[OT_OBS_N * 3];
+    __shared__ double hval[OT_HASH_N * 4];
+    __shared__ int hkey[OT_HASH_N];
     for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
+    for (int i = threadIdx.x; i < OT_HASH_N; i += blockDim.x) hkey[i] = OT_HASH_EMPTY;
+    for (int i = threadIdx.x; i < OT_HASH_N * 4; i += blockDim.x) hval[i] = 0.0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -225,10 +239,44 @@ __global__ __launch_bounds__(256) void render_kernel(int64_t n, const double* __
             }
         }
         double wm = (double)wi;
-        double* h = hist + ((int64_t)iy * a.Nx + ix) * 4;
-        unsafeAtomicAdd(h + 0, xo * wm);
-        unsafeAtomicAdd(h + 1, yo * wm);
-        unsafeAtomicAdd(h + 2, zo * wm);
-        unsafeAtomicAdd(h + 3, 1.0 * wm);
+        const int pix = iy * a.Nx + ix;
+        // LDS hash insert: claim or match one of OT_HASH_PROBES consecutive entries
+        unsigned int h = ((unsigned int)pix * 2654435761u) >> (32 - 11);  // OT_HASH_N = 2^11
+        int slot = -1;
+#pragma unroll
+        for (int pr = 0; pr < OT_HASH_PROBES; pr++) {
+            int sidx = (int)((h + pr) & (OT_HASH_N - 1));
+            int k = hkey[sidx];
+            if (k == OT_HASH_EMPTY) k = atomicCAS(&hkey[sidx], OT_HASH_EMPTY, pix);
+            if (k == OT_HASH_EMPTY || k == pix) {
+                slot = sidx;
+                break;
+            }
+        }
+        if (slot >= 0) {
+            double* hv = &hval[slot * 4];
+            unsafeAtomicAdd(hv + 0, xo * wm);
+            unsafeAtomicAdd(hv + 1, yo * wm);
+            unsafeAtomicAdd(hv + 2, zo * wm);
+            unsafeAtomicAdd(hv + 3, 1.0 * wm);
+        } else {
+            double* hg = hist + (int64_t)pix * 4;
+            unsafeAtomicAdd(hg + 0, xo * wm);
+            unsafeAtomicAdd(hg + 1, yo * wm);
+            unsafeAtomicAdd(hg + 2, zo * wm);
+            unsafeAtomicAdd(hg + 3, 1.0 * wm);
+        }
+    }
+    __syncthreads();
+    for (int sidx = threadIdx.x; sidx < OT_HASH_N; sidx += blockDim.x) {
+        int k = hkey[sidx];
+        if (k != OT_HASH_EMPTY) {
+            double* hg = hist + (int64_t)k * 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double v = hval[sidx * 4 + c];
+                if (v != 0.0) unsafeAtomicAdd(hg + c, v);
+            }
+        }
     }
 }

@@ -43,3 +43,16 @@ t_fused = timeit(fused)
 M = sc.nt - 2
 print(f"{scene_name} N={N} M={M} pol={not RT.no_pol}: generate {t_gen:.3f} ms | trace(injected) {t_trace:.3f} ms | fused {t_fused:.3f} ms"
       f" | {N*M/t_fused/1e6:.1f} G ray-surf/s")
+
+# ---- detector stage -------------------------------------------------------------------------------------
+if "det" in sys.argv:
+    fused(); torch.cuda.synchronize()
+    RT.rays.lock(); RT._last_trace_snapshot = RT.tracing_snapshot()
+    import time
+    ext = None if "auto" in sys.argv else [-45., 45., -45., 45.]
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with ot.global_options.no_warnings():
+            img = RT.detector_image(extent=ext, _keep_on_device=True)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        print(f"detector_image rep{rep}: {1e3*(t1-t0):.2f} ms  power {float(img._dev[...,3].sum()):.5f} shape {tuple(img._dev.shape)}")
