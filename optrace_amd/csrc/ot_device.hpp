@@ -116,12 +116,12 @@ OT_DEV double surf_values(SF& sf, double x, double y) {
 // FunctionSurface2D.normals (1D branch) function_surface_2d.py:216-251 + AsphericSurface._deriv :67-82.
 // cos(atan2(dy,dx)) and sin(atan2(dy,dx)) are formed as dx/r, dy/r: same value to 1-2 ulp without three
 // transcendental calls per ray (normals never feed a mask directly; tolerance 1e-6).
-template <class SF>
+template <bool INSIDE = false, class SF>
 OT_DEV V3 surf_normal(SF& sf, double x, double y) {
     V3 n = {0.0, 0.0, 1.0};
     if (sf.kind != OT_SURF_CONIC && sf.kind != OT_SURF_ASPHERE) return n;
     if (sf.flat) return n;
-    if (!surf_mask(sf, x, y)) return n;
+    if (!INSIDE && !surf_mask(sf, x, y)) return n;  // INSIDE: caller already knows mask(x, y) is true
     double dx = x - sf.px, dy = y - sf.py;
     if (sf.kind == OT_SURF_CONIC) {
         if (sf.k == 0.0) {
@@ -170,13 +170,17 @@ OT_DEV void handle_abnormal(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit)
 template <class SF>
 OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
     double ox = p.x - sf.px, oy = p.y - sf.py, oz = p.z - sf.pz;
-    double A = (sf.k != 0.0) ? 1 + sf.k * (s.z * s.z) : 1.0;
+    const bool sphere = (sf.k == 0.0);  // wave-uniform
+    double A = sphere ? 1.0 : 1 + sf.k * (s.z * s.z);
     double ozk = oz * sf.k1;
     double B = s.x * ox + s.y * oy + s.z * (ozk - sf.inv_rho);
     double C = oy * oy + ox * ox + oz * (ozk - sf.two_inv_rho);
     double D = sqrt(B * B - C * A);
-    double t1 = (-B - D) / A;
-    double t2 = (-B + D) / A;
+    double t1 = -B - D, t2 = -B + D;
+    if (!sphere) {  // x / 1.0 == x exactly, so spheres skip both IEEE divisions
+        t1 = t1 / A;
+        t2 = t2 / A;
+    }
     double z = p.z;
     double z1 = z + s.z * t1;
     double z2 = z + s.z * t2;

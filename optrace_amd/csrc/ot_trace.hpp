@@ -88,7 +88,7 @@ OT_DEV double fresnel_T(double n1, double n2, double ns, double W, double A_ts, 
 template <bool POL, class SF>
 OT_DEV bool refract(SF& sf, RayState& r, const V3& pn, float& wn, float& npx, float& npy, float& npz,
                     double n1, double n2) {
-    V3 n = surf_normal(sf, pn.x, pn.y);
+    V3 n = surf_normal<true>(sf, pn.x, pn.y);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
     V3 s = r.s;
     double ns = dot3(n, s);
     double N = n1 / n2;
