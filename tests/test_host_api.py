@@ -1,0 +1,227 @@
+"""CPU tests of the host-side mirror of the reference API: constructor validation and error types, lens
+thickness logic, groups, geometry checks, scene flattening, storage accounting.  Modelled on the reference's
+tests/test_geometry.py, tests/test_surface.py, tests/test_refraction_index.py, tests/test_misc.py:172-203."""
+import doctest
+
+import numpy as np
+import pytest
+
+import optrace_amd as ot
+from optrace_amd import _capi, misc
+from optrace_amd.scene import CompiledScene
+
+import scenes
+
+
+def test_misc_doctests():
+    assert doctest.testmod(misc, optionflags=doctest.ELLIPSIS | doctest.NORMALIZE_WHITESPACE).failed == 0
+
+
+def test_surface_validation():
+    with pytest.raises(ValueError):
+        ot.CircularSurface(r=0)
+    with pytest.raises(TypeError):
+        ot.CircularSurface(r=[1])
+    with pytest.raises(ValueError):
+        ot.RingSurface(r=1, ri=1)
+    with pytest.raises(ValueError):
+        ot.ConicSurface(r=3, R=2, k=1)  # r beyond the conic's rim
+    with pytest.raises(ValueError):
+        ot.SphericalSurface(r=1, R=0)
+    with pytest.raises(ValueError):
+        ot.SphericalSurface(r=1, R=np.inf)
+    with pytest.raises(ValueError):
+        ot.RectangularSurface(dim=[1, -1])
+    with pytest.raises(ValueError):
+        ot.SlitSurface(dim=[1, 1], dimi=[2, 0.1])
+    with pytest.raises(ValueError):
+        ot.AsphericSurface(r=1, R=10, k=0, coeff=[])
+    s = ot.SphericalSurface(r=1, R=5)
+    with pytest.raises(RuntimeError):
+        s.r = 2  # locked
+    with pytest.raises(AttributeError):
+        ot.Aperture(ot.CircularSurface(r=1), pos=[0, 0, 0]).foo = 1
+
+
+def test_surface_geometry_bookkeeping():
+    s = ot.SphericalSurface(r=3, R=8)
+    z1 = 8 - np.sqrt(64 - 9)
+    assert s.z_min == 0 and abs(s.z_max - z1) < 1e-14
+    s.move_to([1, 2, 3])
+    assert np.allclose(s.extent, [-2, 4, -1, 5, 3, 3 + z1])
+    assert abs(s.dp - z1) < 1e-14 and s.dn == 0 and abs(s.ds - z1) < 1e-14
+    s.flip()
+    assert s.R == -8 and abs(s.z_min - (3 - z1)) < 1e-14 and s.z_max == 3
+    r = ot.RectangularSurface(dim=[4, 2])
+    r.rotate(90)
+    assert np.allclose(r.extent[:4], [-1, 1, -2, 2])
+    c = s.copy()
+    assert c is not s and c.R == s.R
+
+
+def test_lens_thickness_logic():
+    f, b = ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8)
+    n = ot.RefractionIndex("Constant", n=1.5)
+    L = ot.Lens(f, b, n=n, pos=[0, 0, 10], de=0.1)
+    assert abs(L.de - 0.1) < 1e-12
+    assert abs(L.d - (0.1 + f.dp + b.dn)) < 1e-12
+    L2 = ot.Lens(f, b, n=n, pos=[0, 0, 0], d=2.0)
+    assert abs(L2.d - 2.0) < 1e-12
+    L3 = ot.Lens(f, b, n=n, pos=[0, 0, 0], d1=0.3, d2=0.9)
+    assert L3.front.pos[2] == -0.3 and L3.back.pos[2] == 0.9
+    with pytest.raises(ValueError):
+        ot.Lens(f, b, n=n, pos=[0, 0, 0], de=None, d1=1)
+    with pytest.raises(TypeError):
+        ot.Lens(f, b, n=1.5, pos=[0, 0, 0])
+    with pytest.raises(RuntimeError):
+        L.front = f  # geometry lock
+    assert L.front is not f  # elements own copies of their surfaces
+
+
+def test_refraction_index_validation_and_equality():
+    with pytest.raises(ValueError):
+        ot.RefractionIndex("Constant", n=0.9)
+    with pytest.raises(ValueError):
+        ot.RefractionIndex("Cauchy", coeff=[1.5, 0.1])
+    with pytest.raises(ValueError):
+        ot.RefractionIndex("Nope")
+    with pytest.raises(ValueError):
+        ot.RefractionIndex("Abbe", n=1.5, V=-3)
+    a, b = ot.RefractionIndex("Abbe", n=1.5, V=40), ot.RefractionIndex("Abbe", n=1.5, V=40)
+    assert a == b and a != ot.RefractionIndex("Abbe", n=1.5, V=41)
+    # Abbe coefficients are solved in the reference's float32 line arithmetic
+    A, B, d = a._abbe_AB()
+    assert A == float(np.float32(A)) and B == float(np.float32(B)) and d == 0.014
+
+
+def test_ray_source_validation():
+    with pytest.raises(ValueError):
+        ot.RaySource(ot.Point(), divergence="Nope")
+    with pytest.raises(ValueError):
+        ot.RaySource(ot.Point(), s=[0, 0, -1])
+    with pytest.raises(ValueError):
+        ot.RaySource(ot.SphericalSurface(r=1, R=5))
+    with pytest.raises(ValueError):
+        ot.RaySource(ot.Point(), power=0)
+    with pytest.raises(TypeError):
+        ot.RaySource(ot.Point(), spectrum=ot.TransmissionSpectrum("Constant", val=0.5))
+    rs = ot.RaySource(ot.Point(), s_sph=[90 - 1e-9, 0])
+    assert rs.s[2] > 0
+    f = ot.RaySource(ot.RectangularSurface(dim=[2, 1]), polarization="List", pol_angles=[0, 90], pol_probs=[1, 3])._source_fields()
+    assert f["polarization"] == _capi.POL_LIST and f["n_pol"] == 2 and np.allclose(f["pol_tab"], [0, np.pi / 2, 1, 4])
+
+
+def test_group_and_tracing_surfaces():
+    RT = scenes.mixed_geometry(ot)
+    assert len(RT.lenses) == 5 and len(RT.apertures) == 1 and len(RT.filters) == 1 and len(RT.detectors) == 2
+    z = [el.pos[2] for el in RT.elements]
+    assert z == sorted(z)
+    assert len(RT.tracing_surfaces) == 11  # 4 lenses x 2 + aperture + filter + ideal lens
+    L = RT.lenses[0]
+    assert RT.has(L)
+    assert RT.remove(L) and not RT.has(L) and not RT.remove(L)
+    RT.clear()
+    assert RT.elements == []
+    G = ot.presets.geometry.arizona_eye()
+    RT2 = ot.Raytracer(outline=[-10, 10, -10, 10, -10, 30])
+    with pytest.warns(ot.OptraceWarning):
+        RT2.n0 = ot.RefractionIndex("Constant", n=1.2)
+        RT2.add(G)  # different ambient index in the group: overwritten with a warning
+    assert len(RT2.lenses) == 2 and len(RT2.apertures) == 1 and len(RT2.detectors) == 1
+
+
+def test_scene_flattening_tables():
+    RT = scenes.mixed_geometry(ot)
+    RT._geometry_checks()
+    assert not RT.geometry_error
+    sc = CompiledScene(RT)
+    assert sc.nt == 13 and sc.desc.n_elements == 8 and sc.desc.n_surfaces == 12
+    kinds = [sc.elements[i].kind for i in range(sc.desc.n_elements)]
+    assert kinds == [_capi.EL_LENS, _capi.EL_LENS, _capi.EL_APERTURE, _capi.EL_LENS, _capi.EL_FILTER, _capi.EL_LENS,
+                     _capi.EL_IDEAL_LENS, _capi.EL_APERTURE]
+    assert sc.desc.filters[0].type == _capi.T_DATA  # Function spectrum, continuous source -> host table
+    # the same medium object is uploaded once
+    RT2 = scenes.double_gauss(ot)
+    sc2 = CompiledScene(RT2)
+    assert sc2.desc.n_media == 1 + 7 and sc2.desc.n_surfaces == 16
+    assert all(sc2.media[i].model == _capi.N_ABBE for i in range(1, 8)) and sc2.media[0].model == _capi.N_CONSTANT
+
+
+def test_geometry_checks_report_errors_as_warnings():
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -5, 5])
+    with pytest.warns(ot.OptraceWarning, match="RaySource Missing"):
+        RT._geometry_checks()
+    assert RT.geometry_error
+    RT.add(ot.RaySource(ot.Point(), pos=[0, 0, -2]))
+    RT.add(ot.Aperture(ot.CircularSurface(r=1), pos=[0, 0, 20]))
+    with pytest.warns(ot.OptraceWarning, match="outside outline"):
+        RT._geometry_checks()
+    assert RT.geometry_error
+    # colliding surfaces
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -5, 15])
+    RT.add(ot.RaySource(ot.Point(), pos=[0, 0, -2]))
+    n = ot.RefractionIndex("Constant", n=1.5)
+    RT.add(ot.Lens(ot.SphericalSurface(r=3, R=4), ot.SphericalSurface(r=3, R=-4), n=n, pos=[0, 0, 2], de=0.1))
+    RT.add(ot.Lens(ot.SphericalSurface(r=3, R=-4), ot.SphericalSurface(r=3, R=4), n=n, pos=[0, 0, 3.5], d=0.4))
+    with pytest.warns(ot.OptraceWarning, match="collision"):
+        RT._geometry_checks()
+    assert RT.geometry_error and RT.fault_pos.shape[1] == 3
+    with pytest.raises(ValueError):
+        RT.trace(0)
+    with pytest.raises(TypeError):
+        RT.trace(10.5)
+    with pytest.raises(ValueError):
+        ot.Raytracer(outline=[0, 0, 1, 2, 3, 4])
+    # HURB only for ring / slit apertures
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -5, 15], use_hurb=True)
+    RT.add(ot.RaySource(ot.Point(), pos=[0, 0, -2]))
+    RT.add(ot.Aperture(ot.CircularSurface(r=1), pos=[0, 0, 2]))
+    with pytest.warns(ot.OptraceWarning, match="Ray bending"):
+        RT._geometry_checks()
+    assert RT.geometry_error
+
+
+def test_storage_size_accounting():
+    RS = ot.RayStorage
+    for nt in [2, 3, 8, 17]:
+        for no_pol in [False, True]:
+            for N in [1, 101, 2000, 321455]:
+                size = RS.storage_size(N, nt, no_pol)
+                expect = N * nt * 24 + N * 24 + N * nt * 4 + N * nt * 8 + N * 4 + (8 if no_pol else N * nt * 12)
+                assert size == expect
+            for max_size in [1000, 46570689, 6000000000]:
+                Nmax = RS.max_rays_for_size(max_size, nt, no_pol)
+                sz = RS.storage_size(Nmax, nt, no_pol)
+                assert 0 <= max_size - sz < sz / max(Nmax, 1) + 1
+    # the survey's per-unit byte figures: N*[(M+2)*48+28] with pol
+    assert RS.storage_size(10_000_000, 17, False) == 10_000_000 * (17 * 48 + 28)
+    assert RS.storage_size(10_000_000, 17, True) == 10_000_000 * (17 * 36 + 28) + 8
+
+
+def test_render_image_extent_logic():
+    img = ot.RenderImage(extent=[0, 0, 0, 0])
+    img._fix_extent()
+    assert np.allclose(img.extent, [-1e-9, 1e-9, -1e-9, 1e-9])
+    img = ot.RenderImage(extent=[0, 1, 0, 100])
+    img._fix_extent()
+    assert np.isclose(img.extent[1] - img.extent[0], 20)  # ratio limited to 5
+    assert img._pixel_counts() == (945, 945 * 5)
+    img = ot.RenderImage(extent=[-1.0, 2.0, 0.5, 1.5])
+    img._fix_extent()
+    assert img._pixel_counts() == (945 * 3, 945)
+    with pytest.raises(ValueError):
+        ot.RenderImage(extent=[1, 0, 0, 1])
+
+
+def test_spectrum_descriptors():
+    f = ot.LightSpectrum("Lines", lines=[486.1327, 589.2938, 656.272], line_vals=[1, 2, 0.5])._source_fields()
+    assert f["spectrum"] == _capi.SPEC_LINES and f["n_spec"] == 3
+    assert np.array_equal(f["spec_tab"][:3], np.float32([486.1327, 589.2938, 656.272]).astype(np.float64))
+    assert np.allclose(f["spec_tab"][3:], [1, 3, 3.5])
+    f = ot.LightSpectrum("Blackbody", T=5000)._source_fields()
+    assert f["spectrum"] == _capi.SPEC_TABLE and f["n_spec"] == 4000 and f["spec_tab"][4000] == 0
+    assert np.all(np.diff(f["spec_tab"][4000:]) > 0)
+    with pytest.raises(ValueError):
+        ot.LightSpectrum("Lines", lines=[300.], line_vals=[1])
+    with pytest.raises(ValueError):
+        ot.TransmissionSpectrum("Constant", val=1.5)
