@@ -1,0 +1,175 @@
+"""Physics / property tests of the GPU path, after the reference's own test strategy for its unseeded RNG
+(SURVEY.md section 4): counters equal N for forced events (tests/test_tracer_special.py:570-627), Fresnel /
+Brewster transmission values (:629-699), focal lengths (tests/test_tracer.py:295-347), ideal-lens imaging,
+iterative rendering, HURB statistics."""
+import numpy as np
+import pytest
+
+import optrace_amd as ot
+
+pytestmark = pytest.mark.gpu
+
+MONO = dict(spectrum=ot.LightSpectrum("Monochromatic", wl=555.))
+
+
+def test_absorb_missing_counts_all_rays():
+    RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 50], seed=1)
+    RT.add(ot.RaySource(ot.CircularSurface(r=2), divergence="None", pos=[0, 0, -3], **MONO))
+    surf = ot.CircularSurface(r=1e-6)
+    RT.add(ot.Lens(surf, surf, n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 0], d=0.1))
+    N = 10000
+    with ot.global_options.no_warnings():
+        RT.trace(N)
+    assert abs(1 - RT._msgs[RT.INFOS.ABSORB_MISSING, 1] / N) < 1e-3
+    assert np.all(RT.rays.p_list[:, -1, 2] < RT.outline[5] - 1)
+
+
+def test_total_internal_reflection_counts_all_rays():
+    RT = ot.Raytracer(outline=[-10, 10, -10, 10, -10, 50], n0=ot.RefractionIndex("Constant", 100), seed=1)
+    RT.add(ot.RaySource(ot.CircularSurface(r=2), divergence="None", pos=[0, 0, -3], s=[0, 0.1, 0.99], **MONO))
+    RT.add(ot.Lens(ot.CircularSurface(r=10), ot.CircularSurface(r=10), n=ot.RefractionIndex("Constant", n=1.5),
+                   pos=[0, 0, 0], d=0.1))
+    N = 10000
+    with ot.global_options.no_warnings():
+        RT.trace(N)
+    assert RT._msgs[RT.INFOS.TIR, 0] == N
+    assert np.all(RT.rays.w_list[:, 1] == 0) and np.all(np.isnan(RT.rays.s0_list))  # s' is NaN like the reference
+
+
+def test_outline_intersection_counts_almost_all_rays():
+    RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 5000], seed=1)
+    RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=80, pos=[0, 0, -3], **MONO))
+    N = 10000
+    with ot.global_options.no_warnings():
+        RT.trace(N)
+    assert abs(1 - RT._msgs[RT.INFOS.OUTLINE_INTERSECTION, 0] / N) < 1e-3
+    p = RT.rays.p_list[:, 1]
+    on_wall = (np.abs(np.abs(p[:, 0]) - 3) < 1e-9) | (np.abs(np.abs(p[:, 1]) - 3) < 1e-9) | (np.abs(p[:, 2] - 5000) < 1e-6)
+    assert np.all(on_wall)
+
+
+def test_brewster_and_fresnel_transmission():
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -10, 10], seed=4)
+    n = ot.RefractionIndex("Constant", n=1.55)
+    b_ang = np.arctan(1.55 / 1)
+    s = [0, np.sin(b_ang), np.cos(b_ang)]
+    spectrum = ot.LightSpectrum("Monochromatic", wl=550.)
+    RSS = ot.CircularSurface(r=0.05)
+    RT.add(ot.RaySource(RSS, divergence="None", spectrum=spectrum, pos=[2, -2.5, -2], s=s, polarization="x", power=1))
+    RT.add(ot.RaySource(RSS, divergence="None", spectrum=spectrum, pos=[0, -2.5, -2], s=s, polarization="y", power=1))
+    RT.add(ot.RaySource(RSS, divergence="None", spectrum=spectrum, pos=[-2, -2.5, -2], s=s, polarization="Uniform", power=10))
+    rect = ot.RectangularSurface(dim=[10, 10])
+    RT.add(ot.Lens(rect, rect, de=0.5, pos=[0, 0, 0], n=n, n2=n))
+    with ot.global_options.no_warnings():
+        RT.trace(120000)
+    B = RT.rays.B_list
+    w, pol = RT.rays.w_list, RT.rays.pol_list
+    w0 = w[B[2], 0]
+    assert np.allclose(w[B[0]:B[1], 1] / w0, 0.8301, atol=1e-3)       # s-polarised at the Brewster angle
+    assert np.allclose(w[B[1]:B[2], 1] / w0, 1.0000, atol=1e-3)       # p-polarised: no reflection
+    assert abs(np.mean(w[B[2]:, 1]) / w0 - 0.915) < 1e-3              # unpolarised
+    assert np.allclose(pol[B[0]:B[1], 0, 1] ** 2 + pol[B[0]:B[1], 0, 2] ** 2, 0, atol=1e-5)
+    assert np.allclose(pol[B[1]:B[2], 1, 1] ** 2 + pol[B[1]:B[2], 1, 2] ** 2, 1, atol=1e-5)
+    d = np.diff(RT.rays.p_list[:, :3], axis=1)
+    sdir = d / np.linalg.norm(d, axis=2)[:, :, None]
+    for sec in (0, 1):
+        pp = pol[:, sec].astype(np.float64)
+        assert np.allclose((pp ** 2).sum(axis=1), 1, atol=1e-4)
+        assert np.allclose(np.abs((pp * sdir[:, sec]).sum(axis=1)), 0, atol=1e-4)  # pol perpendicular to s
+
+
+@pytest.mark.parametrize("R1,R2,n", [(8., -8., 1.5), (12., -30., 1.7), (-15., 9.5, 1.45)])
+def test_paraxial_focus_matches_lensmaker(R1, R2, n):
+    d = 1.0
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -10, 400], seed=2, no_pol=True)
+    RT.add(ot.RaySource(ot.CircularSurface(r=0.05), divergence="None", pos=[0, 0, -5], **MONO))
+    L = ot.Lens(ot.SphericalSurface(r=2, R=R1), ot.SphericalSurface(r=2, R=R2), n=ot.RefractionIndex("Constant", n=n),
+                pos=[0, 0, 0], d=d)
+    RT.add(L)
+    with ot.global_options.no_warnings():
+        RT.trace(20000)
+    assert not RT.geometry_error
+    inv_f = (n - 1) * (1 / R1 - 1 / R2 + (n - 1) * d / (n * R1 * R2))
+    f = 1 / inv_f
+    bfl = f * (1 - (n - 1) * d / (n * R1))  # back focal distance from the back vertex
+    z_focus = L.back.pos[2] + bfl
+    p, s = RT.rays.p_list[:, 2], RT.rays.s0_list
+    if f > 0:
+        t = -(p[:, 0] * s[:, 0] + p[:, 1] * s[:, 1]) / (s[:, 0] ** 2 + s[:, 1] ** 2 + 1e-300)
+        z_cross = p[:, 2] + s[:, 2] * t
+        sel = np.hypot(p[:, 0], p[:, 1]) > 1e-3
+        assert abs(np.median(z_cross[sel]) - z_focus) < 2e-3 * abs(f)
+    else:  # diverging: virtual focus in front of the lens
+        t = -(p[:, 0] * s[:, 0] + p[:, 1] * s[:, 1]) / (s[:, 0] ** 2 + s[:, 1] ** 2 + 1e-300)
+        sel = np.hypot(p[:, 0], p[:, 1]) > 1e-3
+        assert abs(np.median((p[:, 2] + s[:, 2] * t)[sel]) - z_focus) < 2e-3 * abs(f)
+
+
+def test_ideal_lens_images_point_to_point():
+    D = 20.0  # f = 50 mm
+    RT = ot.Raytracer(outline=[-20, 20, -20, 20, -110, 120], seed=5)
+    RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=4, pos=[1.0, -0.5, -100], **MONO))
+    RT.add(ot.IdealLens(r=15, D=D, pos=[0, 0, 0]))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[10, 10]), pos=[0, 0, 100]))  # 1/f = 1/g + 1/b -> b = 100
+    with ot.global_options.no_warnings():
+        RT.trace(50000)
+        ph, hw, wl, ext, proj, ill = RT._hit_detector("x", 0, None, None, None)
+    n = hw.shape[0]
+    ph = ph.cpu().numpy().reshape(3, n).T[hw.cpu().numpy() > 0]
+    assert ph.shape[0] == 50000
+    assert np.allclose(ph[:, 0], -1.0, atol=1e-8) and np.allclose(ph[:, 1], 0.5, atol=1e-8)  # magnification -1
+
+
+def test_iterative_render_accumulates_chunks():
+    with ot.global_options.no_warnings():
+        import scenes
+        RT = scenes.c1_single_lens(ot, seed=9)
+        RT.ITER_RAYS_STEP = 200000
+        imgs = RT.iterative_render(650000, extent=[-2, 2, -2, 2])
+        assert len(imgs) == 1 and imgs[0]._data.shape == (945, 945, 4)
+        RT2 = scenes.c1_single_lens(ot, seed=9)
+        RT2.trace(650000)
+        ref = RT2.detector_image(extent=[-2, 2, -2, 2])
+    # same source power, independent ray sets: total power equal within sampling noise of the edge losses
+    assert abs(imgs[0].power() - ref.power()) < 2e-3 * ref.power()
+    assert RT._msgs.shape == (5, 4) and RT._msgs.sum() > 0
+    # two positions at once
+    with ot.global_options.no_warnings():
+        imgs = RT.iterative_render(400000, pos=[[0, 0, 15], [0, 0, 25]], extent=[-3, 3, -3, 3])
+    assert len(imgs) == 2 and imgs[0].power() > 0 and imgs[1].power() > 0
+
+
+def test_hurb_spread_matches_uncertainty_formula():
+    """Rays through the middle of a slit are bent by tan(theta) ~ N(0, HURB_FACTOR / (2 * dist * k))
+    (raytracer.py:463-469); device Philox normals must reproduce that spread."""
+    wl, half = 550., 0.025
+    RT = ot.Raytracer(outline=[-3, 3, -3, 3, -5, 40], use_hurb=True, seed=21, no_pol=True)
+    RT.add(ot.RaySource(ot.RectangularSurface(dim=[1e-6, 1e-6]), divergence="None", s=[0, 0, 1], pos=[0, 0, -4],
+                        spectrum=ot.LightSpectrum("Monochromatic", wl=wl)))
+    RT.add(ot.Aperture(ot.SlitSurface(dim=[2.5, 2.5], dimi=[2 * half, 2.0]), pos=[0, 0, 0]))
+    N = 200000
+    with ot.global_options.no_warnings():
+        RT.trace(N)
+    s = RT.rays.s0_list
+    k = 2 * np.pi * 1.0 / (np.float32(wl) * np.float32(1e-9))
+    sig_b = RT.HURB_FACTOR / (2 * half * 1e-3 * k)   # across the slit (x)
+    sig_a = RT.HURB_FACTOR / (2 * 1.0 * 1e-3 * k)    # along the slit (y)
+    tx, ty = s[:, 0] / s[:, 2], s[:, 1] / s[:, 2]
+    assert abs(np.std(tx) / sig_b - 1) < 0.01 and abs(np.std(ty) / sig_a - 1) < 0.01
+    assert abs(np.mean(tx)) < 0.01 * sig_b
+    # normality: kurtosis of a Gaussian
+    assert abs(np.mean(tx ** 4) / np.std(tx) ** 4 - 3) < 0.05
+    assert RT._msgs[RT.INFOS.HURB_NEG_DIR].sum() == 0
+
+
+def test_sharded_trace_single_process_equals_plain():
+    """optrace_amd.distributed with world size 1 = plain trace + detector image."""
+    from optrace_amd import distributed as D
+    import scenes
+    with ot.global_options.no_warnings():
+        RT = scenes.c1_single_lens(ot)
+        img = D.sharded_detector_image(RT, 100000, extent=[-2, 2, -2, 2], base_seed=3)
+        RT2 = scenes.c1_single_lens(ot, seed=3)
+        RT2.trace(100000)
+        ref = RT2.detector_image(extent=[-2, 2, -2, 2])
+    assert np.allclose(img._data, ref._data, rtol=1e-12, atol=1e-18)
