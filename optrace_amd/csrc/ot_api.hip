@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
             int src = 0;
             have = locate_range(rg, ray, g, src);
             if (have) {
-                fill_dither(g);
+                fill_dither(g, sources[src].shape >= OT_SRC_IMAGE_RGB);
                 NewRay nr = generate_ray(sources[src], g, !POL);
                 r.p = nr.p;
                 r.s = nr.s;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void generate_kernel(ot_rays R, const SourceDe
     g.gidx = (uint64_t)ray;
     int src = 0;
     if (!locate_range(rg, ray, g, src)) return;
-    fill_dither(g);
+    fill_dither(g, sources[src].shape >= OT_SRC_IMAGE_RGB);
     NewRay nr = generate_ray(sources[src], g, !POL);
     const int64_t N = R.N, nt = R.nt;
     R.p[ray] = nr.p.x;

@@ -5,7 +5,7 @@
 // with a sequential SFC64 stream.  Neither the stream nor the shuffle can be reproduced in parallel, so the
 // device version is stateless per ray: ray j of a source range of n rays takes stratum perm_K(j), where perm_K
 // is a keyed bijection of [0, n) (cycle-walking hash permutation), and its dither comes from Philox-4x32-10
-// keyed by (seed, global ray index, stream).  Every independently shuffled quantity of the reference
+// keyed by (seed, global ray index).  Every independently shuffled quantity of the reference
 // (position, divergence, wavelength, polarisation, ...) gets its own permutation key, which gives the same
 // joint distribution: stratified marginals, independent pairing.  Parity is therefore statistical
 // (tests/test_sources_gpu.py against fingerprints of the reference) -- SURVEY.md section 7 "RNG".
@@ -67,33 +67,38 @@ struct GenCtx {
     uint32_t j;      // index inside the source range
     uint32_t n;      // rays in the source range (stratification domain)
     uint32_t range;  // range id (permutation keys differ per range)
-    double u[8];     // dither values in [0,1): two Philox-4x32-10 calls per ray, 32 random bits each
+    double u[12];    // dither values in [0,1), 32 random bits each: two Philox-4x32-10 calls per ray,
+                     // a third one for image sources
 };
 
-// stream -> which of the 8 dither values it uses (pairs for the 2-D samplers)
+// stream -> which dither value(s) it uses (consecutive pairs for the 2-D samplers)
 OT_DEV int dither_slot(uint32_t stream) {
     switch (stream) {
         case ST_POS: return 0;         // u0, u1
-        case ST_PIX_JITTER: return 6;  // u6, u7 (image sources; ST_POS unused there)
         case ST_DIV: return 2;         // u2, u3
         case ST_WL: return 4;
         case ST_POL: return 5;
         case ST_DIV_ALPHA: return 6;
-        case ST_RGB_CHOICE: return 0;  // image sources only
-        case ST_RGB_WL: return 1;      // image sources only
-        default: return 3;             // ST_PIXEL (image sources; u3 is free there unless the divergence is 3-D,
-                                       // in which case pixel choice and divergence radius share a dither value
-                                       // but not a permutation, which keeps them independent across rays)
+        case ST_RGB_WL: return 7;
+        case ST_PIXEL: return 8;       // image sources: third Philox call
+        case ST_PIX_JITTER: return 9;  // u9, u10
+        default: return 11;            // ST_RGB_CHOICE
     }
 }
 
-OT_DEV void fill_dither(GenCtx& g) {
+OT_DEV void fill_dither(GenCtx& g, bool image_source) {
     Philox a = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e31u, 0, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
     Philox b = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e32u, 1, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         g.u[k] = ((double)a.c[k] + 0.5) * 0x1.0p-32;
         g.u[4 + k] = ((double)b.c[k] + 0.5) * 0x1.0p-32;
+        g.u[8 + k] = 0.5;
+    }
+    if (image_source) {
+        Philox c = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e33u, 2, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+#pragma unroll
+        for (int k = 0; k < 4; k++) g.u[8 + k] = ((double)c.c[k] + 0.5) * 0x1.0p-32;
     }
 }
 

@@ -272,6 +272,28 @@ def gen_sources():
         pol = rs.create_rays(N)[2]
         ang = np.arctan2(pol[:, 1], pol[:, 0]) % (2 * np.pi)
         out[f"pol/{pname}/hist"] = np.histogram(ang, bins=16, range=(0, 2 * np.pi))[0]
+    # image sources (ray_source.py:120-146, 233-258): synthetic sRGB image, element [0, 0] = lower left corner
+    img = scenes.synthetic_rgb_image()
+    rs = ot.RaySource(ot.RGBImage(img, [4, 3]), divergence="Isotropic", div_angle=2, pos=[0.5, -0.25, 1.0])
+    p, s, pol, w, wl = rs.create_rays(N)
+    H, W = img.shape[:2]
+    ix = np.clip(((p[:, 0] - (0.5 - 2)) / 4 * W).astype(int), 0, W - 1)
+    iy = np.clip(((p[:, 1] - (-0.25 - 1.5)) / 3 * H).astype(int), 0, H - 1)
+    out["img/rgb/pixel_counts"] = np.bincount(iy * W + ix, minlength=H * W)
+    out["img/rgb/pIf"] = rs._pIf
+    out["img/rgb/wl_hist"] = np.histogram(wl, bins=40, range=(380, 780))[0]
+    for cname, cols in [("red", (0, 8)), ("green", (8, 16)), ("blue", (16, 24)), ("white", (24, 32))]:
+        m = (ix >= cols[0]) & (ix < cols[1])
+        out[f"img/rgb/wl_hist_{cname}"] = np.histogram(wl[m], bins=40, range=(380, 780))[0]
+    gimg = scenes.synthetic_gray_image()
+    rs = ot.RaySource(ot.GrayscaleImage(gimg, [2, 2]), divergence="None", pos=[0, 0, 0],
+                      spectrum=ot.LightSpectrum("Monochromatic", wl=600.))
+    p, s, pol, w, wl = rs.create_rays(N)
+    H, W = gimg.shape[:2]
+    ix = np.clip(((p[:, 0] + 1) / 2 * W).astype(int), 0, W - 1)
+    iy = np.clip(((p[:, 1] + 1) / 2 * H).astype(int), 0, H - 1)
+    out["img/gray/pixel_counts"] = np.bincount(iy * W + ix, minlength=H * W)
+    out["img/gray/pIf"] = rs._pIf
     out["N"] = N
     np.savez_compressed(HERE / "sources.npz", **out)
     print("sources.npz", len(out))

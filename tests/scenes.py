@@ -214,3 +214,25 @@ def transmission_zoo(ot):
         "Gaussian_inv": ot.TransmissionSpectrum("Gaussian", mu=500., sig=30., val=1.0, inverse=True),
         "Data": ot.TransmissionSpectrum("Data", wls=np.linspace(400., 700., 31), vals=np.linspace(0.1, 0.9, 31) ** 2),
     }
+
+
+def synthetic_rgb_image():
+    """24 x 32 sRGB test card: red / green / blue / white column blocks with a vertical brightness ramp and a
+    black stripe (pixels that must never emit)."""
+    H, W = 24, 32
+    img = np.zeros((H, W, 3))
+    ramp = np.linspace(0.15, 1.0, H)[:, None]
+    img[:, 0:8, 0] = ramp
+    img[:, 8:16, 1] = ramp
+    img[:, 16:24, 2] = ramp
+    img[:, 24:32, :] = ramp[:, :, None]
+    img[10:12, :, :] = 0.0
+    return img
+
+
+def synthetic_gray_image():
+    H, W = 16, 16
+    y, x = np.mgrid[0:H, 0:W]
+    g = ((x + 2 * y) % 7) / 6.0
+    g[4:6, 4:6] = 0.0
+    return g

@@ -131,3 +131,47 @@ def test_trace_splits_rays_by_source_power():
     assert np.all(RT.rays.p_list[:2500, 0, 0] == 0.) and np.all(RT.rays.p_list[2500:, 0, 0] == 1.)
     w0 = RT.rays.w_list[:, 0].astype(np.float64)
     assert abs(w0[:2500].sum() - 1.0) < 1e-4 and abs(w0[2500:].sum() - 3.0) < 1e-4
+
+
+def test_rgb_image_source(fp):
+    """RGBImage source: pixel choice by relative power, position jitter inside the pixel, wavelength from the
+    three sRGB primary spectra (ray_source.py:233-258, color/srgb.py:513-553)."""
+    import scenes
+    N = int(fp["N"])
+    img = scenes.synthetic_rgb_image()
+    rs = ot.RaySource(ot.RGBImage(img, [4, 3]), divergence="Isotropic", div_angle=2, pos=[0.5, -0.25, 1.0])
+    assert np.allclose(rs._pIf, fp["img/rgb/pIf"], rtol=1e-12)
+    p, s, pol, w, wl = rs.create_rays(N)
+    H, W = img.shape[:2]
+    assert p[:, 0].min() >= 0.5 - 2 and p[:, 0].max() <= 0.5 + 2 and p[:, 1].min() >= -1.75 and p[:, 1].max() <= 1.25
+    assert np.all(p[:, 2] == 1.0)
+    ix = np.clip(((p[:, 0] - (0.5 - 2)) / 4 * W).astype(int), 0, W - 1)
+    iy = np.clip(((p[:, 1] - (-0.25 - 1.5)) / 3 * H).astype(int), 0, H - 1)
+    counts = np.bincount(iy * W + ix, minlength=H * W)
+    expect = rs._pIf * N
+    assert np.all(counts[expect == 0] == 0), "black pixels never emit"
+    # stratified pixel choice: counts within a few rays of N * p (binomial would be ~sqrt)
+    assert np.max(np.abs(counts - expect)) < 3 + 0.05 * np.sqrt(expect.max())
+    assert np.abs(counts - fp["img/rgb/pixel_counts"]).max() < 6
+    assert hist_l1(np.histogram(wl, bins=40, range=(380, 780))[0], fp["img/rgb/wl_hist"]) < 0.02
+    for cname, cols in [("red", (0, 8)), ("green", (8, 16)), ("blue", (16, 24)), ("white", (24, 32))]:
+        m = (ix >= cols[0]) & (ix < cols[1])
+        assert hist_l1(np.histogram(wl[m], bins=40, range=(380, 780))[0], fp[f"img/rgb/wl_hist_{cname}"]) < 0.04
+
+
+def test_grayscale_image_source(fp):
+    import scenes
+    N = int(fp["N"])
+    g = scenes.synthetic_gray_image()
+    rs = ot.RaySource(ot.GrayscaleImage(g, [2, 2]), divergence="None", pos=[0, 0, 0],
+                      spectrum=ot.LightSpectrum("Monochromatic", wl=600.))
+    assert np.allclose(rs._pIf, fp["img/gray/pIf"], rtol=1e-12)
+    p, s, pol, w, wl = rs.create_rays(N)
+    H, W = g.shape
+    ix = np.clip(((p[:, 0] + 1) / 2 * W).astype(int), 0, W - 1)
+    iy = np.clip(((p[:, 1] + 1) / 2 * H).astype(int), 0, H - 1)
+    counts = np.bincount(iy * W + ix, minlength=H * W)
+    expect = rs._pIf * N
+    assert np.all(counts[expect == 0] == 0)
+    assert np.max(np.abs(counts - expect)) < 4
+    assert np.all(wl == 600.) and np.all(s[:, 2] == 1.0)
