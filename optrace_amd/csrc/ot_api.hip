@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
         }
     }
     if (have) {
-        bool ok = trace_ray<POL, TAB, FULL>(sc, R, ray, r, hurb_normals, seed, cnt);
+        bool ok = trace_ray<POL, TAB, FULL>(sc, R, (uint32_t)ray, r, hurb_normals, seed, cnt);
         if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)
     }
     __syncthreads();
@@ -744,6 +744,7 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     if (!sc || !msgs) return fail(OT_ERR_INVALID, "ot_trace: null argument");
     bool pol = !sc->h.no_pol;
     if (int rc = check_rays(rays, pol)) return rc;
+    if (rays->N >= (1ll << 29)) return fail(OT_ERR_UNSUPPORTED, "at most 2^29 - 1 rays per launch (32-bit lane offsets); split the bundle");
     if (rays->nt != sc->h.nt) return fail(OT_ERR_INVALID, "ray storage has " + std::to_string(rays->nt) +
                                                              " sections, the scene needs " + std::to_string(sc->h.nt));
     if (rays->N == 0) return OT_OK;
