@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU and step")
     ap.add_argument("--no-pol", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -75,6 +75,21 @@ def cpu_baseline(RT, scene, seconds: float) -> dict:
         t, n = run(n2), n2
     return {"value": n * M / t, "unit": "ray-surface-intersections/s", "cores": 1, "kind": "port",
             "sample": f"{n} rays x {M} surfaces of the same scene (device-generated rays), {t:.1f} s on 1 core"}
+
+
+def measured_traffic(pol: bool, N: int):
+    """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/<round>/trace_kernel_pmc.json; FETCH_SIZE
+    doubled as the gfx950 correction of MI355X_MICROARCH.md prescribes).  None if no profile matches."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*/trace_kernel_pmc.json")):
+        try:
+            d = json.loads(f.read_text())
+            if d.get("rays") == N and d.get("pol") == pol:
+                best = (2 * float(np.median(d["FETCH_SIZE"])) + float(np.median(d["WRITE_SIZE"]))) * 1024
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -184,7 +199,7 @@ def main():
                                    f"{N} rays per GPU, polarisation {'on' if pol else 'off'}, on-device generation",
                        "rays_per_gpu": N, "surfaces": M, "sections": nt, "parallelism": f"ray-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(pol, N),
                          "kernel": "trace_kernel (ot_generate_and_trace)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": b_trace},
             "detector": {"rays_per_s": N / t_det, "ms": 1e3 * t_det, "allreduce_ms": 1e3 * t_red,
