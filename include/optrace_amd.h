@@ -59,6 +59,7 @@ extern "C" {
 #define OT_SURF_ASPHERE 5 /* AsphericSurface    aspheric_surface.py:9     conic + even polynomial */
 
 #define OT_MAX_ASPH 12 /* even-order coefficients a2 .. a24 */
+#define OT_MAX_LINES 8 /* discrete wavelengths tabulated per scene */
 
 typedef struct ot_surface {
     int32_t kind;   /* OT_SURF_*                                                                 */
@@ -155,8 +156,11 @@ typedef struct ot_scene_desc {
     int32_t n0;       /* ambient medium index (Raytracer.n0)                                         */
     int32_t no_pol;   /* Raytracer.no_pol                                                            */
     int32_t use_hurb; /* Raytracer.use_hurb                                                          */
-    int32_t _pad;
+    int32_t n_lines;  /* > 0: every source has a discrete spectrum; `lines` = the distinct wavelengths       */
     double hurb_factor; /* Raytracer.HURB_FACTOR raytracer.py:33                                     */
+    const double* lines; /* n_lines float32 wavelength values (as doubles) or NULL.  With 1..OT_MAX_LINES lines
+                            ot_generate_and_trace tabulates n(lambda), n1/n2 and filter transmissions per line
+                            once on the host and the kernel reads them from LDS instead of evaluating them per ray */
 } ot_scene_desc;
 
 typedef struct ot_scene ot_scene; /* opaque: device copy of the tables */

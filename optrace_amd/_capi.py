@@ -14,6 +14,7 @@ _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "liboptrace_hip.so"
 
 OT_MAX_ASPH = 12
+OT_MAX_LINES = 8
 
 # --- enums (kept in sync with the header) -------------------------------------------------------
 SURF_CIRCLE, SURF_RING, SURF_RECT, SURF_SLIT, SURF_CONIC, SURF_ASPHERE = range(6)
@@ -68,8 +69,8 @@ class SceneDesc(C.Structure):
                 ("surfaces", C.POINTER(Surface)), ("elements", C.POINTER(Element)),
                 ("media", C.POINTER(Medium)), ("filters", C.POINTER(Filter)),
                 ("table_pool", C.POINTER(C.c_double)), ("table_pool_len", C.c_int64),
-                ("n0", C.c_int32), ("no_pol", C.c_int32), ("use_hurb", C.c_int32), ("_pad", C.c_int32),
-                ("hurb_factor", C.c_double)]
+                ("n0", C.c_int32), ("no_pol", C.c_int32), ("use_hurb", C.c_int32), ("n_lines", C.c_int32),
+                ("hurb_factor", C.c_double), ("lines", C.POINTER(C.c_double))]
 
 
 class Source(C.Structure):

@@ -250,6 +250,36 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
             return fail(OT_ERR_INVALID, "medium table outside the pool");
     }
 
+    // discrete spectra: tabulate n(lambda), n1/n2 and filter T per step and line (IEEE arithmetic on the host, the
+    // same expressions the device evaluates; raytracer.py:305, 327-332, 799, 380)
+    std::vector<double> line_tab;
+    int n_lines = 0;
+    if (desc->n_lines > 0 && desc->n_lines <= OT_MAX_LINES && desc->lines) {
+        n_lines = desc->n_lines;
+        const int rows = 3 * (int)steps.size() + 2;
+        line_tab.assign((size_t)rows * OT_MAX_LINES, 0.0);
+        for (int j = 0; j < n_lines; j++) {
+            const float wl32 = (float)desc->lines[j];
+            line_tab[j] = (double)wl32;
+            double n_cur = medium_n(desc->media[desc->n0], desc->table_pool, wl32);
+            line_tab[(size_t)(1 + 3 * steps.size()) * OT_MAX_LINES + j] = n_cur;  // ambient row
+            for (size_t i = 0; i < steps.size(); i++) {
+                const StepDev& d = steps[i];
+                double n_next = n_cur, Nq = 1.0, T = 1.0;
+                if (d.kind <= OT_STEP_IDEAL) {
+                    n_next = medium_n(desc->media[d.n_next], desc->table_pool, wl32);
+                    Nq = n_cur / n_next;
+                } else if (d.kind == OT_STEP_FILTER) {
+                    T = filter_T(filts[d.filter], desc->table_pool, wl32);
+                }
+                line_tab[(size_t)(1 + 3 * i + 0) * OT_MAX_LINES + j] = n_next;
+                line_tab[(size_t)(1 + 3 * i + 1) * OT_MAX_LINES + j] = Nq;
+                line_tab[(size_t)(1 + 3 * i + 2) * OT_MAX_LINES + j] = T;
+                n_cur = n_next;
+            }
+        }
+    }
+
     // one device blob: header | surfaces | elements | media | filters | pool
     size_t o_hdr = 0;
     size_t o_surf = align_up(o_hdr + sizeof(SceneDev));
@@ -258,7 +288,8 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     size_t o_flt = align_up(o_med + sizeof(ot_medium) * desc->n_media);
     size_t o_pool = align_up(o_flt + sizeof(FilterDev) * filts.size());
     size_t pool_n = desc->table_pool_len > 0 ? (size_t)desc->table_pool_len : 1;
-    size_t o_cnt = align_up(o_pool + sizeof(double) * pool_n);
+    size_t o_lines = align_up(o_pool + sizeof(double) * pool_n);
+    size_t o_cnt = align_up(o_lines + sizeof(double) * (line_tab.size() + 1));
     size_t total = align_up(o_cnt + sizeof(unsigned int) * (size_t)OT_CNT_SLOTS * (OT_N_INFOS * nt + 1));
 
     std::vector<char> host(total, 0);
@@ -284,6 +315,8 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     h.filters = (const FilterDev*)(blob + o_flt);
     h.pool = (const double*)(blob + o_pool);
     h.pool_len = desc->table_pool_len;
+    h.n_lines = n_lines;
+    h.line_tab = (const double*)(blob + o_lines);
 
     std::memcpy(host.data() + o_hdr, &h, sizeof(h));
     std::memcpy(host.data() + o_surf, surfs.data(), sizeof(SurfDev) * surfs.size());
@@ -292,6 +325,7 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     std::memcpy(host.data() + o_flt, filts.data(), sizeof(FilterDev) * filts.size());
     if (desc->table_pool_len > 0)
         std::memcpy(host.data() + o_pool, desc->table_pool, sizeof(double) * desc->table_pool_len);
+    if (!line_tab.empty()) std::memcpy(host.data() + o_lines, line_tab.data(), sizeof(double) * line_tab.size());
     hipError_t e = hipMemcpy(blob, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(blob);
@@ -511,15 +545,20 @@ OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& src) 
 //        flat surfaces and apertures: 98 VGPRs instead of 165
 // Event counters go wave -> LDS (per workgroup) -> one of OT_CNT_SLOTS global slot tables (blockIdx % slots) ->
 // reduce_counters_kernel, so that no two workgroups hammer the same address (see count_event).
-template <bool POL, bool GEN, bool TAB, bool FULL>
+template <bool POL, bool GEN, int SPEC, bool FULL>
 __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
                                                     const SourceDev* __restrict__ sources, RangeArgs rg,
                                                     const double* __restrict__ hurb_normals, uint64_t seed,
                                                     unsigned int* __restrict__ slots) {
-    extern __shared__ unsigned int cnt[];  // (OT_N_INFOS x nt) event counters + 1 timeout flag
+    extern __shared__ double lds[];  // [discrete-spectrum table (SPEC == 2)] [event counters + timeout flag]
     auto& sc = *as_const(scp);
+    const int n_tab = (SPEC == 2) ? (3 * sc.n_steps + 2) * OT_MAX_LINES : 0;
+    double* ltab = lds;
+    unsigned int* cnt = (unsigned int*)(lds + n_tab);  // (OT_N_INFOS x nt) counters + 1 flag
     const int n_cnt = OT_N_INFOS * sc.nt + 1;
     for (int k = threadIdx.x; k < n_cnt; k += blockDim.x) cnt[k] = 0u;
+    if (SPEC == 2)
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) ltab[k] = sc.line_tab[k];
     __syncthreads();
 
     const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -563,7 +602,7 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
         }
     }
     if (have) {
-        bool ok = trace_ray<POL, TAB, FULL>(sc, R, (uint32_t)ray, r, hurb_normals, seed, cnt);
+        bool ok = trace_ray<POL, SPEC, FULL>(sc, R, (uint32_t)ray, r, hurb_normals, seed, cnt, ltab);
         if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)
     }
     __syncthreads();
@@ -755,22 +794,25 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     const SourceDev* sd = src ? src->d : nullptr;
     unsigned long long* m = (unsigned long long*)msgs;
     dim3 grid = grid_for(rays->N), block(256);
-    // kernel variant: polarisation x on-device generation x per-lane table loads x feature set
+    // kernel variant: polarisation x on-device generation x spectrum handling x feature set
     const bool tab = sc->needs_tables || hurb_normals != nullptr;
     const bool full = sc->needs_full;
+    const bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr;  // generated rays only
     const int n_cnt = OT_N_INFOS * sc->h.nt + 1;
-    const size_t lds = sizeof(unsigned int) * (size_t)n_cnt;
+    const size_t lds = sizeof(unsigned int) * (size_t)n_cnt +
+                       (lines ? sizeof(double) * (size_t)(3 * sc->h.n_steps + 2) * OT_MAX_LINES : 0) + 8;
     unsigned int* slots = sc->cnt_slots;
-#define OT_LAUNCH(P, G, T, F) \
-    hipLaunchKernelGGL((trace_kernel<P, G, T, F>), grid, block, lds, st, sc->d, *rays, sd, r, hurb_normals, seed, slots)
-#define OT_LAUNCH_F(P, G, T) do { if (full) OT_LAUNCH(P, G, T, true); else OT_LAUNCH(P, G, T, false); } while (0)
-#define OT_LAUNCH_T(P, G) do { if (tab) OT_LAUNCH_F(P, G, true); else OT_LAUNCH_F(P, G, false); } while (0)
+#define OT_LAUNCH(P, G, S, F) \
+    hipLaunchKernelGGL((trace_kernel<P, G, S, F>), grid, block, lds, st, sc->d, *rays, sd, r, hurb_normals, seed, slots)
+#define OT_LAUNCH_F(P, G, S) do { if (full) OT_LAUNCH(P, G, S, true); else OT_LAUNCH(P, G, S, false); } while (0)
     if (src) {
-        if (pol) OT_LAUNCH_T(true, true); else OT_LAUNCH_T(false, true);
+        if (lines)    { if (pol) OT_LAUNCH_F(true, true, 2); else OT_LAUNCH_F(false, true, 2); }
+        else if (tab) { if (pol) OT_LAUNCH_F(true, true, 1); else OT_LAUNCH_F(false, true, 1); }
+        else          { if (pol) OT_LAUNCH_F(true, true, 0); else OT_LAUNCH_F(false, true, 0); }
     } else {
-        if (pol) OT_LAUNCH_T(true, false); else OT_LAUNCH_T(false, false);
+        if (tab)      { if (pol) OT_LAUNCH_F(true, false, 1); else OT_LAUNCH_F(false, false, 1); }
+        else          { if (pol) OT_LAUNCH_F(true, false, 0); else OT_LAUNCH_F(false, false, 0); }
     }
-#undef OT_LAUNCH_T
 #undef OT_LAUNCH_F
 #undef OT_LAUNCH
     HIP_TRY(hipGetLastError());

@@ -11,6 +11,7 @@
 #include "ot_scene.hpp"
 
 #define OT_DEV __device__ __forceinline__
+#define OT_HD __host__ __device__ __forceinline__  // also used by the host when it tabulates discrete spectra
 
 // Scene tables are read through the CONSTANT address space: with a wave-uniform index the backend then emits
 // scalar loads (s_load_dwordx*) into SGPRs instead of per-lane flat loads into VGPRs.
@@ -310,7 +311,7 @@ OT_DEV void hurb_props(SF& sf, double x, double y, double& a_, double& b_, V3& b
 // numpy.interp on a sorted table (compiled_base.c arr_interp): binary search for the interval, exact value
 // on a node, linear elsewhere; `left`/`right` = 0 outside (spectrum.py:106)
 template <class PL>
-OT_DEV double interp_tab(double x, PL xp, PL fp, int n) {
+OT_HD double interp_tab(double x, PL xp, PL fp, int n) {
     if (isnan(x)) return x;
     if (x < xp[0] || x > xp[n - 1]) return 0.0;
     int lo = 0, hi = n - 1;
@@ -333,15 +334,13 @@ OT_DEV double interp_tab(double x, PL xp, PL fp, int n) {
     return res;
 }
 
-OT_DEV double ipow3(double x) { return pow(x, 3.0); }
-
 // TAB = false compiles the table models (per-lane global loads) out.  That matters far beyond the two cases:
 // vmcnt retires in order, so ANY vector-memory load in the tracing loop makes the compiler wait for all section
 // stores issued before it (and, through control-flow merges, before every write of the register the load might
 // target).  Scenes without tabulated media/filters therefore run a loop that contains no VMEM load at all and
 // never drains its store queue.
 template <bool TAB = true, class MD, class PL>
-OT_DEV double medium_n(MD& md, PL pool, float wl32) {
+OT_HD double medium_n(MD& md, PL pool, float wl32) {
     double wl = (double)wl32;
     auto* c = md.c;
     double um = wl * 1e-3;
@@ -399,7 +398,7 @@ OT_DEV double medium_n(MD& md, PL pool, float wl32) {
 
 // Filter.__call__ filter.py:39 -> transmission_spectrum.py:73-84 -> spectrum.py:81-120
 template <bool TAB = true, class FD, class PL>
-OT_DEV double filter_T(FD& f, PL pool, float wl32) {
+OT_HD double filter_T(FD& f, PL pool, float wl32) {
     double wl = (double)wl32;
     double T;
     switch (f.type) {

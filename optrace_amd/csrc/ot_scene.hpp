@@ -71,6 +71,10 @@ struct SceneDev {
     const FilterDev* filters;
     const double* pool;
     int64_t pool_len;
+    // discrete-spectrum tables (n_lines > 0): lines[OT_MAX_LINES] as float32 values, then per step i the rows
+    // (n_next, n1/n2, filter T) and finally the ambient row n0: doubles at line_tab[row * OT_MAX_LINES + j]
+    int32_t n_lines, _pad2;
+    const double* line_tab;
 };
 
 struct ot_scene {

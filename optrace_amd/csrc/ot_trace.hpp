@@ -96,11 +96,10 @@ OT_DEV double fresnel_T(double n1, double n2, double ns, double W, double A_ts, 
 // Returns true on total internal reflection.
 template <bool POL, class SF>
 OT_DEV bool refract(SF& sf, RayState& r, const V3& pn, float& wn, float& npx, float& npy, float& npz,
-                    double n1, double n2) {
+                    double n1, double n2, double N) {  // N = n1 / n2 (raytracer.py:799)
     V3 n = surf_normal<true>(sf, pn.x, pn.y);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
     V3 s = r.s;
     double ns = dot3(n, s);
-    double N = n1 / n2;
     double W = sqrt(1 - N * N * (1 - ns * ns));
     double q = N * ns - W;
     V3 s_ = {s.x * N - n.x * q, s.y * N - n.y * q, s.z * N - n.z * q};
@@ -216,9 +215,21 @@ OT_DEV void store_section(const ot_rays& R, uint32_t ray, int sec, const V3& p, 
 // The element list is flattened on the host into one STEP per tracing surface (lens front, lens back, ideal
 // lens, filter, aperture), so the loop body contains a single copy of the hit search, the refraction and the
 // outline clip: ~3x less code than walking elements (instruction cache) and lower register pressure.
-template <bool POL, bool TAB, bool FULL, class SC>
+// SPEC selects how wavelength-dependent quantities are obtained:
+//   0  formulas only (no vector-memory load in the loop)      1  formulas + tabulated media / filters (global loads)
+//   2  discrete spectrum: n, n1/n2 and filter T of every step were tabulated per line on the host and staged in
+//      LDS (`ltab`); the lane only carries its line index.  Saves the IEEE division n1/n2 and the dispersion
+//      formula per ray-surface and covers "Function" media exactly.
+template <bool POL, int SPEC, bool FULL, class SC>
 OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const double* __restrict__ hurb_normals,
-                      uint64_t seed, unsigned int* msgs) {
+                      uint64_t seed, unsigned int* msgs, const double* ltab) {
+    constexpr bool TAB = (SPEC == 1);
+    int lj = 0;  // line index of this ray (SPEC == 2)
+    if (SPEC == 2) {
+        for (int j = 1; j < sc.n_lines; j++)
+            if ((float)ltab[j] == r.wl) lj = j;
+    }
+    const double* lrow = ltab + OT_MAX_LINES + lj;  // row 0 of this lane's column
     const int nt = sc.nt;
     const auto surfaces = as_const(sc.surfaces);
     const auto steps = as_const(sc.steps);
@@ -226,7 +237,7 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
     const auto filters = as_const(sc.filters);
     const auto pool = as_const(sc.pool);
     bool ok = true;
-    r.n_cur = medium_n<TAB>(media[sc.n0], pool, r.wl);
+    r.n_cur = (SPEC == 2) ? lrow[(3 * sc.n_steps) * OT_MAX_LINES] : medium_n<TAB>(media[sc.n0], pool, r.wl);
     store_section<POL>(R, ray, 0, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
 
     for (int i = 0; i < sc.n_steps; i++) {  // i = index of the section the ray starts this step in
@@ -254,16 +265,26 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
                 if (kind == OT_STEP_LENS_BACK) pn = r.p;  // absorbed at the front surface, raytracer.py:354
             }
             count_event(msgs, nt, OT_INFO_ABSORB_MISSING, i + 1, hwnh);
-            n_next = medium_n<TAB>(media[st.n_next], pool, r.wl);
+            double Nq;
+            if (SPEC == 2) {
+                n_next = lrow[(3 * i + 0) * OT_MAX_LINES];
+                Nq = lrow[(3 * i + 1) * OT_MAX_LINES];
+            } else {
+                n_next = medium_n<TAB>(media[st.n_next], pool, r.wl);
+                Nq = r.n_cur / n_next;
+            }
             if (hwh) {
                 if (FULL && kind == OT_STEP_IDEAL)
                     refract_ideal<POL>(sf, st, r, pn, npx, npy, npz);
                 else
-                    tir = refract<POL>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next);
+                    tir = refract<POL>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq);
             }
             count_event(msgs, nt, OT_INFO_TIR, i, tir);
         } else if (FULL && kind == OT_STEP_FILTER) {  // raytracer.py:379-380
-            if (hwh) wn = (float)((double)r.w * filter_T<TAB>(filters[st.filter], pool, r.wl));
+            if (hwh) {
+                double T = (SPEC == 2) ? lrow[(3 * i + 2) * OT_MAX_LINES] : filter_T<TAB>(filters[st.filter], pool, r.wl);
+                wn = (float)((double)r.w * T);
+            }
         } else {  // aperture raytracer.py:381-386
             if (hwh) wn = 0.f;
             if (FULL && st.hurb) {

@@ -78,6 +78,13 @@ class CompiledScene:
         d.no_pol = int(rt.no_pol)
         d.use_hurb = int(rt.use_hurb)
         d.hurb_factor = float(rt.HURB_FACTOR)
+        # discrete spectra: the library tabulates n(lambda), n1/n2 and filter values per line (LDS tables)
+        self.lines = None
+        d.n_lines = 0
+        if lines is not None and 1 <= len(lines) <= _capi.OT_MAX_LINES:
+            self.lines = (C.c_double * len(lines))(*[float(v) for v in lines])
+            d.n_lines = len(lines)
+            d.lines = self.lines
         self.desc = d
 
 

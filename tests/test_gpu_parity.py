@@ -254,3 +254,37 @@ def test_full_size_properties_double_gauss():
         RT4 = scenes.double_gauss(ot, seed=12)
         RT4.trace(100000)
         assert not np.array_equal(RT2.rays.p_list, RT4.rays.p_list)
+
+
+@pytest.mark.parametrize("name,no_pol", [("double_gauss", False), ("double_gauss", True), ("c1_single_lens", False),
+                                          ("mixed_lines", False)])
+def test_discrete_spectrum_tables_equal_formula_path(name, no_pol):
+    """Scenes whose sources are all discrete run the SPEC=2 kernel (n, n1/n2, filter T per line from LDS) in
+    ot_generate_and_trace.  It must give bit-identical rays to generating the same rays (same seed) with
+    ot_rays_generate and tracing them with the formula kernel of ot_trace, which the golden tests pin."""
+    import ctypes as C
+    import torch
+    from optrace_amd._device import ptr, stream_ptr
+    lib = _capi.load_library()
+    N = 300_000
+    with ot.global_options.no_warnings():
+        if name == "mixed_lines":  # filters, ideal lens, Function index, conics: everything per line
+            RT = scenes.mixed_geometry(ot, seed=77)
+            RT.ray_sources[1].spectrum = ot.LightSpectrum("Lines", lines=[450., 550., 610., 680.], line_vals=[1, 2, 1, 0.5])
+        else:
+            RT = scenes.SCENES[name][0](ot, no_pol=no_pol, seed=77)
+        RT.trace(N)  # fused: generation + LINES tables
+        assert RT._scene.desc.n_lines >= 1
+        fused = {k: RT.rays._dev[k].clone() for k in ("p", "s", "w", "n", "wl") + (() if no_pol else ("pol",))}
+        msgs_fused = RT._msgs.copy()
+        # same rays again: generate section 0 only, then the injected-ray kernel (formulas, IEEE n1/n2 per ray)
+        rays = RT.rays._rays_struct()
+        tab, rng = RT.rays._source_table(), RT.rays._source_ranges()
+        _capi.check(lib.ot_rays_generate(tab.handle, rng, len(rng), 77, int(no_pol), C.byref(rays), stream_ptr()))
+        msgs = torch.zeros(5 * RT.rays.Nt + 1, dtype=torch.int64, device="cuda")
+        _capi.check(lib.ot_trace(RT._scene_handle, C.byref(rays), None, 77, ptr(msgs), stream_ptr()))
+        torch.cuda.synchronize()
+    assert np.array_equal(msgs.cpu().numpy()[:-1].reshape(5, -1), msgs_fused)
+    for k, t in fused.items():
+        a, b = t.cpu().numpy(), RT.rays._dev[k].cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=True), f"{k} differs between the LINES and the formula kernel"
