@@ -34,6 +34,11 @@ struct RayState {
 // a position, direction or mask, so it is evaluated with fused multiply-adds and one reciprocal square root
 // instead of sqrt + three divisions: agreement with the reference is at the 1e-15 level before the float32
 // rounding of the store (bar: 1e-6 relative).
+// The reference's PROJECTION form (pol' = A_ts ps + A_tp pp') is kept on purpose: the float32-stored pol is only
+// perpendicular to s to ~3e-8, and a rotation form (Rodrigues about ps; 25 % fewer instructions) carries that
+// parallel component along instead of dropping it.  That flips the float32 rounding of pol' in ~17 % of the
+// components, and since T is first order in pol the weights then drift by ~1e-7 per surface (measured 2.6e-6
+// after 15 surfaces) -- outside the 1e-6 bar.
 template <bool POL>
 OT_DEV void compute_polarization(const V3& s, const V3& s_, const RayState& r, float& npx, float& npy, float& npz,
                                  double& A_ts, double& A_tp) {
