@@ -64,6 +64,8 @@ class Raytracer(Group):
         self.fault_pos = np.array([])
         self._scene = None
         self._scene_handle = None
+        self._scene_key = None
+        self._checked_key = None
         super().__init__(None, n0, **kwargs)
         self._new_lock = True
 
@@ -150,11 +152,21 @@ class Raytracer(Group):
         check_type("N", N, int)
         if N < 1:
             raise ValueError(f"Ray number N needs to be at least 1, but is {N}.")
-        self._geometry_checks()
+        # the checks sample every surface pair on a 100 x 100 grid (host NumPy); skip them while nothing that
+        # they depend on changed since they last passed (chunked rendering calls trace() many times)
+        key = self._geometry_key()
+        if self._checked_key is None or key != self._checked_key or self.geometry_error:
+            self._geometry_checks()
+            self._checked_key = key if not self.geometry_error else None
         if self.geometry_error and not self._ignore_geometry_error:
             warning("ABORTED TRACING")
             return True
         return False
+
+    def _geometry_key(self):
+        snap = self.tracing_snapshot()
+        snap.pop("Rays", None)
+        return repr(snap)
 
     def _geometry_checks(self) -> None:
         elements = tracing_elements(self)
@@ -254,18 +266,38 @@ class Raytracer(Group):
 
     # ---- scene upload --------------------------------------------------------------------------------------
     def _compile(self) -> CompiledScene:
+        """Flatten the scene and upload its tables; reused while the tracing-relevant state is unchanged."""
         lib = _capi.load_library()
+        key = self._geometry_key()
+        if self._scene is not None and self._scene_handle is not None and key == self._scene_key:
+            return self._scene
         self._release_scene()
         self._scene = CompiledScene(self)
+        self._check_media()
         handle = C.c_void_p()
         _capi.check(lib.ot_scene_create(C.byref(self._scene.desc), C.byref(handle)))
         self._scene_handle = handle
+        self._scene_key = key
         return self._scene
+
+    def _check_media(self) -> None:
+        """RefractionIndex.__call__ raises for n < 1 (refraction_index.py:165-167) and for wavelengths outside a
+        tabulated range (:152-156); the tracing kernel cannot raise per ray, so every medium is evaluated once per
+        scene over the wavelengths the sources can emit (device evaluation through RefractionIndex.__call__)."""
+        from .scene import discrete_lines
+        lines = discrete_lines(self.ray_sources)
+        wl = lines.astype(np.float64) if lines is not None else np.linspace(*global_options.wavelength_range, 201)
+        seen = set()
+        for n in [self.n0] + [L.n for L in self.lenses] + [L.n2 for L in self.lenses if L.n2 is not None]:
+            if id(n) not in seen:
+                seen.add(id(n))
+                n(wl)
 
     def _release_scene(self) -> None:
         if self._scene_handle is not None and self._scene_handle.value:
             _capi.load_library().ot_scene_destroy(self._scene_handle)
         self._scene_handle = None
+        self._scene_key = None
 
     def __del__(self):
         try:

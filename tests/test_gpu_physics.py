@@ -173,3 +173,32 @@ def test_sharded_trace_single_process_equals_plain():
         RT2.trace(100000)
         ref = RT2.detector_image(extent=[-2, 2, -2, 2])
     assert np.allclose(img._data, ref._data, rtol=1e-12, atol=1e-18)
+
+
+def test_refraction_index_below_one_raises_at_trace():
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -5, 20], seed=1)
+    RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Rectangle", wl0=400., wl1=700.)))
+    bad = ot.RefractionIndex("Cauchy", coeff=[0.9, 0.01, 0, 0])  # n ~ 0.93 < 1 in the visible range
+    RT.add(ot.Lens(ot.SphericalSurface(r=2, R=8), ot.SphericalSurface(r=2, R=-8), n=bad, pos=[0, 0, 5], d=1.0))
+    with pytest.raises(RuntimeError, match="Refraction index below 1"):
+        RT.trace(1000)
+
+
+def test_scene_is_recompiled_only_when_it_changes():
+    import scenes
+    with ot.global_options.no_warnings():
+        RT = scenes.c1_single_lens(ot, seed=2)
+        RT.trace(10000)
+        h1, k1 = RT._scene_handle.value, RT._scene_key
+        RT.trace(20000)
+        assert RT._scene_handle.value == h1 and RT._scene_key == k1
+        RT.lenses[0].move_to([0, 0, 1.0])
+        RT.trace(10000)
+        assert RT._scene_key != k1
+        img1 = RT.detector_image()
+        RT.detectors[0].move_to([0, 0, 25])     # detectors are not part of the traced scene
+        img2 = RT.detector_image()
+    assert img1.power() > 0 and img2.power() > 0
+    RT.no_pol = True
+    with pytest.raises(RuntimeError, match="retrace"):
+        RT.detector_image()
