@@ -345,6 +345,26 @@ int ot_render_accumulate(int64_t n, const double* px, const double* py, const fl
                          const float* wl, const double extent[4], int32_t Nx, int32_t Ny,
                          double* hist, void* stream);
 
+/* ---- image conversion (next row) -------------------------------------------------- */
+#define OT_IMG_IRRADIANCE 0       /* render_image.py:180 */
+#define OT_IMG_ILLUMINANCE 1      /* :184 */
+#define OT_IMG_SRGB_ABSOLUTE 2    /* :189  color.xyz_to_srgb srgb.py:379, rendering intent "Absolute"   */
+#define OT_IMG_SRGB_PERCEPTUAL 3  /* :189  rendering intent "Perceptual" (L_th, chroma_scale)           */
+#define OT_IMG_OUTSIDE_GAMUT 4    /* :197  color.outside_srgb_gamut srgb.py:84                          */
+#define OT_IMG_LIGHTNESS 5        /* :202  CIELUV L   luv.py xyz_to_luv                                 */
+#define OT_IMG_HUE 6              /* :206  luv_hue                                                      */
+#define OT_IMG_CHROMA 7           /* :211  luv_chroma                                                   */
+#define OT_IMG_SATURATION 8       /* :216  luv_saturation                                               */
+
+/* RenderImage.get (render_image.py:131-222): converts the (Ny, Nx, 4) float64 XYZW histogram into a display
+ * quantity.  fact joins fact x fact bins first (the reference's cv2.resize INTER_AREA, :174; must divide Nx and
+ * Ny).  apx = area of one ORIGINAL pixel, K = luminous efficacy.  chroma_scale = NaN selects the automatic value.
+ * out: (Ny/fact, Nx/fact, 3) float64 for the sRGB modes, (Ny/fact, Nx/fact) float64 otherwise.
+ * workspace: device scratch of 4*(Nx/fact)*(Ny/fact) + 8 doubles.  Synchronises the stream for the sRGB modes
+ * (image-wide decisions of srgb.py:318, 209, 250 are taken on the host). */
+int ot_image_convert(const double* hist, int32_t Nx, int32_t Ny, int32_t fact, int32_t mode, double apx, double K,
+                     double L_th, double chroma_scale, double* out, double* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

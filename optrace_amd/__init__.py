@@ -14,7 +14,7 @@ from .spectrum import Spectrum, LightSpectrum, TransmissionSpectrum
 from .geometry import (Surface, CircularSurface, RingSurface, RectangularSurface, SlitSurface, ConicSurface,
                        SphericalSurface, AsphericSurface, Point, Line, Element, Lens, IdealLens, Aperture,
                        Filter, Detector, Group, RaySource)
-from .image import RGBImage, GrayscaleImage
+from .image import RGBImage, GrayscaleImage, ScalarImage
 from .render_image import RenderImage
 from .ray_storage import RayStorage
 from .raytracer import Raytracer

@@ -12,6 +12,7 @@
 #include "ot_detector.hpp"
 #include "ot_device.hpp"
 #include "ot_generate.hpp"
+#include "ot_image.hpp"
 #include "ot_scene.hpp"
 #include "ot_trace.hpp"
 
@@ -968,6 +969,55 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     int64_t blocks = (n + 1023) / 1024;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, n, px, py, w, wl, a, table, hist);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+// ---- image conversion ----------------------------------------------------------------------------------------
+extern "C" int ot_image_convert(const double* hist, int32_t Nx, int32_t Ny, int32_t fact, int32_t mode, double apx,
+                                double K, double L_th, double chroma_scale, double* out, double* workspace, void* stream) {
+    if (!hist || !out || !workspace || Nx < 1 || Ny < 1 || fact < 1 || Nx % fact || Ny % fact)
+        return fail(OT_ERR_INVALID, "ot_image_convert: bad argument");
+    if (mode < OT_IMG_IRRADIANCE || mode > OT_IMG_SATURATION) return fail(OT_ERR_INVALID, "ot_image_convert: unknown mode");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t npx = (int64_t)(Nx / fact) * (Ny / fact);
+    double* img = workspace;            // (ny, nx, 4) down-binned working copy
+    double* red = workspace + npx * 4;  // OT_RED_N reduction slots
+    dim3 grid = grid_for(npx), block(256);
+    hipLaunchKernelGGL(img_downbin_kernel, grid, block, 0, st, hist, Nx, Ny, fact, img);
+    const double inf = INFINITY;
+    double init[OT_RED_N] = {-inf, -inf, 0.0, -inf, 0.0, inf, -inf, 0.0};
+    HIP_TRY(hipMemcpyAsync(red, init, sizeof(init), hipMemcpyHostToDevice, st));
+    if (mode != OT_IMG_IRRADIANCE && mode != OT_IMG_ILLUMINANCE)
+        hipLaunchKernelGGL(img_reduce1_kernel, grid, block, 0, st, img, npx, red);
+    if (mode == OT_IMG_SRGB_ABSOLUTE || mode == OT_IMG_SRGB_PERCEPTUAL) {
+        double h[OT_RED_N];
+        HIP_TRY(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const bool any_inv = h[OT_RED_ANY_INV] != 0.0;
+        const bool cs_given = !std::isnan(chroma_scale);
+        int intent = 0;  // srgb.py:318-319: nothing out of gamut and no fixed chroma scale -> plain conversion
+        int use_ones = 0;
+        double cs = 1.0;
+        if (any_inv || cs_given) {
+            if (mode == OT_IMG_SRGB_ABSOLUTE) {
+                intent = 1;
+            } else {
+                intent = 2;
+                hipLaunchKernelGGL(img_reduce2_kernel, grid, block, 0, st, img, npx, L_th, red);
+                HIP_TRY(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                use_ones = h[OT_RED_ANY_GAMUT] == 0.0;
+                double crmin = (use_ones || !std::isfinite(h[OT_RED_CRMIN])) ? 1.0 : h[OT_RED_CRMIN];
+                double f = std::sqrt(crmin);
+                f = f < 0.32 ? 0.32 : (f > 1.0 ? 1.0 : f);  // srgb.py:252
+                cs = cs_given ? chroma_scale : f;
+            }
+        }
+        hipLaunchKernelGGL(img_correct_kernel, grid, block, 0, st, img, npx, intent, cs, use_ones, red);
+    }
+    hipLaunchKernelGGL(img_final_kernel, grid, block, 0, st, img, npx, mode, apx, K, red, out);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

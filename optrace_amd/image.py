@@ -127,3 +127,20 @@ class RGBImage(_BaseImage):
 class GrayscaleImage(_BaseImage):
     """sRGB-gamma grayscale image with values in [0, 1] (grayscale_image.py:10-60)."""
     _channels = 1
+
+
+class ScalarImage(_BaseImage):
+    """Single-channel image of a physical quantity, non-negative (scalar_image.py:9-60)."""
+    _channels = 1
+
+    def __setattr__(self, key, val):
+        if key == "_data":
+            check_type(key, val, np.ndarray)
+            val = np.asarray_chkfinite(val, dtype=np.float64)
+            if val.ndim != 2:
+                raise ValueError(f"Image needs to have two dimensions but has shape {val.shape}.")
+            if val.size and val.min() < 0:
+                raise ValueError("There is an negative value inside the image")
+            BaseClass.__setattr__(self, key, val)
+            return
+        super().__setattr__(key, val)

@@ -21,7 +21,7 @@ from ._device import require_device, stream_ptr, ptr, to_dev
 class RenderImage(BaseClass):
 
     EPS: float = 1e-9
-    K: float = 683.002  # luminous efficacy [lm/W] (scipy.constants "luminous efficacy", render_image.py:35)
+    K: float = 683.0  # luminous efficacy [lm/W] (scipy.constants "luminous efficacy", render_image.py:35)
     SIZES = [1, 3, 5, 7, 9, 15, 21, 27, 35, 45, 63, 105, 135, 189, 315, 945]
     MAX_IMAGE_SIDE: int = SIZES[-1]
     MAX_IMAGE_RATIO: int = SIZES[2]
@@ -134,6 +134,43 @@ class RenderImage(BaseClass):
             self._data = self._dev.cpu().numpy()
         if not _dont_filter and self._limit is not None:
             self._apply_rayleigh_filter()
+
+    _MODES = {"Irradiance": 0, "Illuminance": 1, "sRGB (Absolute RI)": 2, "sRGB (Perceptual RI)": 3,
+              "Outside sRGB Gamut": 4, "Lightness (CIELUV)": 5, "Hue (CIELUV)": 6, "Chroma (CIELUV)": 7,
+              "Saturation (CIELUV)": 8}
+
+    def get(self, mode: str, N: int = 315, L_th: float = 0, chroma_scale: float = None):
+        """Converted image for display mode `mode` (render_image.py:131-222), computed by `ot_image_convert`.
+
+        N = pixel count of the smaller side; the nearest of SIZES is used and bins are joined (no interpolation).
+        Returns an RGBImage for the sRGB modes, a ScalarImage otherwise."""
+        from .image import RGBImage, ScalarImage
+        self._check_for_image()
+        N = int(N)
+        if not 1 <= N <= self.MAX_IMAGE_SIDE:
+            raise ValueError(f"N needs to be between 1 and {self.MAX_IMAGE_SIDE}")
+        if mode not in self._MODES:
+            raise ValueError(f"Invalid display_mode {mode}, should be one of {self.image_modes}.")
+        lib = _capi.load_library()
+        dev = require_device()
+        Ny, Nx, _ = self._data.shape
+        Na = self.SIZES[int(np.argmin(np.abs(N - np.array(self.SIZES))))]
+        fact = int(self.MAX_IMAGE_SIDE / Na)
+        nx, ny = Nx // fact, Ny // fact
+        hist = self._dev if self._dev is not None else to_dev(self._data, np.float64)
+        hist = hist.reshape(-1)
+        rgb = mode.startswith("sRGB")
+        out = torch.empty(ny * nx * (3 if rgb else 1), dtype=torch.float64, device=dev)
+        ws = torch.empty(4 * nx * ny + 8, dtype=torch.float64, device=dev)
+        cs = float("nan") if chroma_scale is None else float(chroma_scale)
+        _capi.check(lib.ot_image_convert(ptr(hist), Nx, Ny, fact, self._MODES[mode], float(self.Apx), float(self.K),
+                                         float(L_th), cs, ptr(out), ptr(ws), stream_ptr()))
+        iargs = dict(extent=self.extent, projection=self.projection, desc=self.desc, long_desc=self.long_desc,
+                     quantity=mode, limit=self.limit)
+        data = out.cpu().numpy()
+        if rgb:
+            return RGBImage(data.reshape(ny, nx, 3), **iargs)
+        return ScalarImage(data.reshape(ny, nx), **iargs)
 
     def _sync_host(self) -> None:
         self._data = self._dev.cpu().numpy()

@@ -226,6 +226,33 @@ def gen_trace(name: str, builder, N: int, seed: int, **rt_args):
     print(f"trace_{name}.npz N={N} msgs={RT._msgs.sum(axis=1)}")
 
 
+def gen_image_modes():
+    """RenderImage.get at full resolution (N=945: no cv2 resize involved) for two detector images."""
+    out = {}
+    modes = ot.RenderImage.image_modes
+    for name, builder, N, seed in [("double_gauss", scenes.double_gauss, 6000, 400), ("mixed_geometry", scenes.mixed_geometry, 6000, 401)]:
+        refload.reseed(ot, seed)
+        RT = builder(ot)
+        RT.trace(N)
+        img = RT.detector_image(extent=[-25, 25, -35, 5] if name == "double_gauss" else None)
+        nz = np.nonzero(img._data[:, :, 3])
+        out[f"{name}/shape"] = np.array(img._data.shape)
+        out[f"{name}/extent"] = np.array(img.extent)
+        out[f"{name}/iy"], out[f"{name}/ix"] = nz[0].astype(np.int32), nz[1].astype(np.int32)
+        out[f"{name}/xyzw"] = img._data[nz[0], nz[1], :]
+        zero = (0, 0) if img._data[0, 0, 3] == 0 else None
+        assert zero is not None
+        for mode in modes:
+            for tag, kw in [("", {}), ("|Lth", dict(L_th=0.02)), ("|cs", dict(chroma_scale=0.6))]:
+                if tag and mode != "sRGB (Perceptual RI)":
+                    continue
+                res = img.get(mode, 945, **kw)._data
+                out[f"{name}/{mode}{tag}"] = res[nz[0], nz[1]]
+                out[f"{name}/{mode}{tag}/bg"] = res[0, 0]
+    np.savez_compressed(HERE / "image_modes.npz", **out)
+    print("image_modes.npz", len(out))
+
+
 def gen_sources():
     """Distribution fingerprints of RaySource.create_rays for the statistical parity tests (G4)."""
     out = {}
@@ -300,7 +327,7 @@ def gen_sources():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["leaf", "media", "trace", "sources"]
+    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images"]
     if "leaf" in which:
         gen_leaf_surfaces()
     if "media" in which:
@@ -312,3 +339,5 @@ if __name__ == "__main__":
         gen_trace("asphere_nopol", scenes.asphere_scene, 1500, seed=301, no_pol=True)
     if "sources" in which:
         gen_sources()
+    if "images" in which:
+        gen_image_modes()
