@@ -365,6 +365,11 @@ int ot_render_accumulate(int64_t n, const double* px, const double* py, const fl
 int ot_image_convert(const double* hist, int32_t Nx, int32_t Ny, int32_t fact, int32_t mode, double apx, double K,
                      double L_th, double chroma_scale, double* out, double* workspace, void* stream);
 
+/* RenderImage._apply_rayleigh_filter (render_image.py:257-296): out = "same"-size 2-D convolution of each of the
+ * 4 channels of `in` (Ny, Nx, 4) with the (2*ps+1)^2 kernel `psf` (device, row-major), zero padded, negative
+ * results clamped to 0.  in and out must not alias.  next row, SURVEY 8f rank 2. */
+int ot_image_convolve(const double* in, int32_t Nx, int32_t Ny, const double* psf, int32_t ps, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

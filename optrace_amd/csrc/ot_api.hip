@@ -1021,3 +1021,16 @@ extern "C" int ot_image_convert(const double* hist, int32_t Nx, int32_t Ny, int3
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }
+
+extern "C" int ot_image_convolve(const double* in, int32_t Nx, int32_t Ny, const double* psf, int32_t ps, double* out,
+                                 void* stream) {
+    if (!in || !psf || !out || Nx < 1 || Ny < 1 || ps < 0 || in == out) return fail(OT_ERR_INVALID, "ot_image_convolve: bad argument");
+    const size_t lds = sizeof(double) * (size_t)(2 * ps + 1) * (2 * ps + 1);
+    if (lds > 150 * 1024) return fail(OT_ERR_UNSUPPORTED, "ot_image_convolve: kernel larger than 137 x 137 taps");
+    if (int rc = require_device()) return rc;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)img_convolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(img_convolve_kernel, grid_for((int64_t)Nx * Ny), dim3(256), lds, (hipStream_t)stream, in, Nx, Ny, psf, ps, out);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}

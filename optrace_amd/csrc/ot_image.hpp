@@ -293,3 +293,39 @@ __global__ __launch_bounds__(256) void img_final_kernel(const double* __restrict
         }
     }
 }
+
+// RenderImage._apply_rayleigh_filter render_image.py:257-296: "same"-size convolution of every channel with the
+// (2ps+1)^2 Airy kernel.  The reference uses scipy.signal.fftconvolve; the kernel is small against the image, so
+// a direct sum per output pixel (zero-padded borders, zero taps skipped, kernel staged in LDS) gives the same
+// result without FFT round-off (the reference clamps its negative FFT noise to 0 afterwards).
+__global__ __launch_bounds__(256) void img_convolve_kernel(const double* __restrict__ in, int Nx, int Ny,
+                                                           const double* __restrict__ psf, int ps, double* __restrict__ out) {
+    extern __shared__ double kern[];
+    const int side = 2 * ps + 1;
+    for (int k = threadIdx.x; k < side * side; k += blockDim.x) kern[k] = psf[k];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Nx * Ny) return;
+    const int y = (int)(i / Nx), x = (int)(i - (int64_t)y * Nx);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int j = 0; j < side; j++) {
+        const int yy = y + ps - j;  // (f * g)[y] = sum_j g[j] f[y - (j - ps)]
+        if (yy < 0 || yy >= Ny) continue;
+        for (int k = 0; k < side; k++) {
+            const int xx = x + ps - k;
+            if (xx < 0 || xx >= Nx) continue;
+            const double g = kern[j * side + k];
+            if (g == 0.0) continue;
+            const double* h = in + ((int64_t)yy * Nx + xx) * 4;
+            a0 += g * h[0];
+            a1 += g * h[1];
+            a2 += g * h[2];
+            a3 += g * h[3];
+        }
+    }
+    double* o = out + i * 4;
+    o[0] = fmax(a0, 0.0);
+    o[1] = fmax(a1, 0.0);
+    o[2] = fmax(a2, 0.0);
+    o[3] = fmax(a3, 0.0);
+}

@@ -249,6 +249,20 @@ def gen_image_modes():
                 res = img.get(mode, 945, **kw)._data
                 out[f"{name}/{mode}{tag}"] = res[nz[0], nz[1]]
                 out[f"{name}/{mode}{tag}/bg"] = res[0, 0]
+    # Rayleigh resolution filter (render_image.py:257-296) on the mixed-geometry image: limit in micrometres
+    refload.reseed(ot, 402)
+    RT = scenes.mixed_geometry(ot)
+    RT.trace(6000)
+    for limit in (3.0, 12.0):
+        img = RT.detector_image(limit=limit)
+        d = img._data
+        out[f"filter/{limit}/extent"] = np.array(img.extent)
+        out[f"filter/{limit}/shape"] = np.array(d.shape)
+        out[f"filter/{limit}/grid7"] = d[3::7, 2::7, :].astype(np.float64)   # every 7th pixel, all channels
+        out[f"filter/{limit}/power"] = img.power()
+        out[f"filter/{limit}/max"] = d.max(axis=(0, 1))
+    ph, w, wl, ext, _, _, _ = RT._hit_detector("x", 0, None, None, None)
+    out["filter/ph"], out["filter/w"], out["filter/wl"], out["filter/ext0"] = ph, w, wl, ext
     np.savez_compressed(HERE / "image_modes.npz", **out)
     print("image_modes.npz", len(out))
 

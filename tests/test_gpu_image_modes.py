@@ -70,3 +70,25 @@ def test_bin_joining_conserves_power_and_shape(gm):
         img.get("nope")
     rgb = img.get("sRGB (Absolute RI)", 189)
     assert rgb.shape[2] == 3 and rgb._data.min() >= 0 and rgb._data.max() <= 1
+
+
+@pytest.mark.parametrize("limit", [3.0, 12.0])
+def test_rayleigh_filter_matches_reference(gm, limit):
+    """limit= : the Airy-disc convolution (render_image.py:257-296).  The reference convolves by FFT, we sum
+    directly: agreement to FFT round-off relative to the image maximum."""
+    img = ot.RenderImage(extent=gm["filter/ext0"])
+    img.render(gm["filter/ph"], gm["filter/w"], gm["filter/wl"], limit=limit)
+    assert img.limit == limit
+    assert_close(img.extent, gm[f"filter/{limit}/extent"], rtol=1e-12, what="extent incl. the 2.7*limit margin")
+    assert img._data.shape == tuple(gm[f"filter/{limit}/shape"])
+    mx = gm[f"filter/{limit}/max"]
+    got = img._data[3::7, 2::7, :]
+    ref = gm[f"filter/{limit}/grid7"]
+    assert np.max(np.abs(got - ref) / mx) < 1e-11
+    assert abs(img.power() - float(gm[f"filter/{limit}/power"])) < 1e-9 * img.power()
+    assert img._data.min() >= 0
+    # the filter spreads but conserves power away from the borders
+    plain = ot.RenderImage(extent=gm["filter/ext0"])
+    plain.render(gm["filter/ph"], gm["filter/w"], gm["filter/wl"])
+    assert abs(plain.power() - img.power()) < 1e-6 * plain.power()
+    assert img._data[..., 3].max() < plain._data[..., 3].max()
