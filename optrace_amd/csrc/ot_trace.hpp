@@ -96,6 +96,57 @@ OT_DEV double fresnel_T(double n1, double n2, double ns, double W, double A_ts, 
     return T;
 }
 
+// __compute_polarization specialised for refraction, where s' = N s - q n lies in the plane of n and s.
+// With m = n x s (|m| = sin(alpha)) the reference's basis vectors are, by (a x b) x c = b (a.c) - a (b.c):
+//     ps  = +-m / |m|                      (the sign cancels in A_ts ps and in A_ts^2)
+//     pp  = ps x s  = (ns s - n) / |m|
+//     pp' = ps x s' = (W s - (s.s') n) / |m|,      n.s' = W,   s.s' = N - q ns
+// so   A_ts = (m.pol)/|m|,  A_tp = (ns (s.pol) - n.pol)/|m|,  pol' = [(m.pol) m + A_tp|m| (W s - (s.s') n)] / |m|^2.
+// No identity relies on pol being exactly perpendicular to s (the float32-stored pol is not; see above why that
+// matters), so this agrees with the reference's projection to rounding, with one cross product instead of three
+// and a reciprocal instead of a reciprocal square root (~66 instead of ~83 instructions).
+template <bool POL>
+OT_DEV void refraction_polarization(const V3& n, const V3& s, const V3& s_, double ns, double W, double N, double q,
+                                    const RayState& r, float& npx, float& npy, float& npz, double& A_ts2, double& A_tp2) {
+#pragma clang fp contract(fast)
+    if (!POL) {  // (1/np.sqrt(2))**2 each
+        A_ts2 = 0.5;
+        A_tp2 = 0.5;
+        return;
+    }
+    bool mask = (s.x != s_.x) || (s.y != s_.y) || (s.z != s_.z);
+    V3 m = cross3(n, s);
+    V3 pol = {(double)r.polx, (double)r.poly, (double)r.polz};
+    double mm = dot3(m, m), mp = dot3(m, pol), sp = dot3(s, pol), np_ = dot3(n, pol);
+    double inv = fast_rcp(mm);
+    double tp = ns * sp - np_;   // A_tp |m|
+    double ct = N - q * ns;      // s . s'
+    A_ts2 = mp * mp * inv;
+    A_tp2 = tp * tp * inv;
+    if (!mask) {
+        A_ts2 = 0.5;
+        A_tp2 = 0.5;
+    }
+    if (mask) {
+        V3 vec = {W * s.x - ct * n.x, W * s.y - ct * n.y, W * s.z - ct * n.z};
+        npx = (float)((mp * m.x + tp * vec.x) * inv);
+        npy = (float)((mp * m.y + tp * vec.y) * inv);
+        npz = (float)((mp * m.z + tp * vec.z) * inv);
+    }
+}
+
+// Fresnel power transmission from squared amplitudes (see fresnel_T)
+OT_DEV double fresnel_T2(double n1, double n2, double ns, double W, double A_ts2, double A_tp2) {
+#pragma clang fp contract(fast)
+    double n1ca = n1 * ns, n2cb = n2 * W;
+    double d1 = n1ca + n2cb;
+    double d2 = n2 * ns + n1 * W;
+    double den = d1 * d2;
+    double T = 4 * n1ca * n2cb * (A_ts2 * (d2 * d2) + A_tp2 * (d1 * d1)) * fast_rcp(den * den);
+    if (n1ca == 0) T = __builtin_nan("");  // the reference divides by n1*cos(alpha)
+    return T;
+}
+
 // Raytracer.__refraction raytracer.py:761-829 for a lane that has power and hit the surface.
 // The new direction s' is computed in the reference's exact operation order (it feeds the next hit mask).
 // Returns true on total internal reflection.
@@ -109,9 +160,9 @@ OT_DEV bool refract(SF& sf, RayState& r, const V3& pn, float& wn, float& npx, fl
     double q = N * ns - W;
     V3 s_ = {s.x * N - n.x * q, s.y * N - n.y * q, s.z * N - n.z * q};
 
-    double A_ts, A_tp;
-    compute_polarization<POL>(s, s_, r, npx, npy, npz, A_ts, A_tp);
-    double T = fresnel_T(n1, n2, ns, W, A_ts, A_tp);
+    double A_ts2, A_tp2;
+    refraction_polarization<POL>(n, s, s_, ns, W, N, q, r, npx, npy, npz, A_ts2, A_tp2);
+    double T = fresnel_T2(n1, n2, ns, W, A_ts2, A_tp2);
     bool tir = !isfinite(W);
     if (tir) T = 0;
     wn = (float)((double)r.w * T);
