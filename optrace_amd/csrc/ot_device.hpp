@@ -171,16 +171,20 @@ OT_DEV void handle_abnormal(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit)
 template <class SF>
 OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
     double ox = p.x - sf.px, oy = p.y - sf.py, oz = p.z - sf.pz;
-    const bool sphere = (sf.k == 0.0);  // wave-uniform
-    double A = sphere ? 1.0 : 1 + sf.k * (s.z * s.z);
+    const bool sphere = (sf.k == 0.0);  // wave-uniform: a scalar branch, not a select
     double ozk = oz * sf.k1;
     double B = s.x * ox + s.y * oy + s.z * (ozk - sf.inv_rho);
     double C = oy * oy + ox * ox + oz * (ozk - sf.two_inv_rho);
-    double D = sqrt(B * B - C * A);
-    double t1 = -B - D, t2 = -B + D;
-    if (!sphere) {  // x / 1.0 == x exactly, so spheres skip both IEEE divisions
-        t1 = t1 / A;
-        t2 = t2 / A;
+    double A = 1.0, D, t1, t2;
+    if (sphere) {  // A = 1.0: C * 1.0 == C and x / 1.0 == x exactly, so both are skipped
+        D = sqrt(B * B - C);
+        t1 = -B - D;
+        t2 = -B + D;
+    } else {
+        A = 1 + sf.k * (s.z * s.z);
+        D = sqrt(B * B - C * A);
+        t1 = (-B - D) / A;
+        t2 = (-B + D) / A;
     }
     double z = p.z;
     double z1 = z + s.z * t1;
@@ -190,12 +194,12 @@ OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) 
     double t = (c1 && !c2) ? t1 : t2;
     ph = along(p, s, t);
     hit = surf_mask(sf, ph.x, ph.y);
-    if (A == 0 && B != 0) {
+    if (!sphere && A == 0 && B != 0) {
         t = -C / (2 * B);
         ph = along(p, s, t);
         hit = surf_mask(sf, ph.x, ph.y);
     }
-    bool nh = !hit || !isfinite(D) || (A == 0 && B == 0) || (ph.z < sf.z_lo) || (ph.z > sf.z_hi);
+    bool nh = !hit || !isfinite(D) || (!sphere && A == 0 && B == 0) || (ph.z < sf.z_lo) || (ph.z > sf.z_hi);
     if (nh) {
         double tnh = (sf.z_max - p.z) / s.z;
         ph = along(p, s, tnh);

@@ -22,8 +22,9 @@ with ot.global_options.no_warnings():
 rays = RT.rays._rays_struct(); tab = RT.rays._source_table(); rng = RT.rays._source_ranges()
 msgs = torch.zeros(5 * sc.nt + 1, dtype=torch.int64, device="cuda")
 
-def timeit(f, reps=5):
-    f(); torch.cuda.synchronize()
+def timeit(f, reps=30):
+    for _ in range(12): f()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): f()
