@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-pol", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank code path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -100,13 +102,20 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend=args.backend)
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    on_host = world > 1 and args.backend != "nccl"  # gloo rehearsal: collectives on host copies
 
     import optrace_amd as ot
     from optrace_amd import _capi
     from optrace_amd._device import ptr, stream_ptr
+    from optrace_amd import distributed as D
     import scenes
 
     lib = _capi.load_library()
@@ -149,7 +158,7 @@ def main():
     t_local = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
-    t = torch.tensor([t_local], dtype=torch.float64, device=dev)
+    t = torch.tensor([t_local], dtype=torch.float64, device="cpu" if on_host else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_max = float(t.item())
@@ -171,9 +180,16 @@ def main():
     if world > 1:
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        if on_host:
+            h = hist.cpu()
+            D.allreduce_image(h)
+            hist.copy_(h)
+        else:
+            D.allreduce_image(hist)  # the one exchange step: RCCL all-reduce of the (Ny, Nx, 4) f64 histogram
         torch.cuda.synchronize()
         t_red = time.perf_counter() - tr0
+        cnt = D.allreduce_counters(RT._msgs, device=None if on_host else dev)
+        assert cnt.sum() >= RT._msgs.sum()
     total_power = float(hist[..., 3].sum().item())
 
     if rank == 0:
