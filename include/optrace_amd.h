@@ -370,6 +370,18 @@ int ot_image_convert(const double* hist, int32_t Nx, int32_t Ny, int32_t fact, i
  * results clamped to 0.  in and out must not alias.  next row, SURVEY 8f rank 2. */
 int ot_image_convolve(const double* in, int32_t Nx, int32_t Ny, const double* psf, int32_t ps, double* out, void* stream);
 
+/* LightSpectrum.render (spectrum/light_spectrum.py:41-79), the histogram behind Raytracer.detector_spectrum
+ * (raytracer.py:1100-1132) and Raytracer.source_spectrum (raytracer.py:1307-1328).  Rays come dense: weight 0 =
+ * not selected (as ot_detector_hits leaves them).  next row, SURVEY 8f rank 3.
+ * ot_spectrum_range: range2[0..1] (device) = min / max wavelength of the rays with w > 0 (+inf / -inf if none),
+ *   count[0] (device) = number of such rays (np.count_nonzero(w), light_spectrum.py:60).
+ * ot_spectrum_histogram: hist[nbins] (device, f64, accumulated into: zero it first) += weights per bin of the
+ *   float32 edges[nbins + 1] (device; np.linspace(wl0, wl1, nbins + 1) as float32).  Bin search as NumPy's
+ *   uniform-bin path in float32 (numpy/lib/_histograms_impl.py), last bin closed on the right. */
+int ot_spectrum_range(int64_t n, const float* wl, const float* w, double* range2, int64_t* count, void* stream);
+int ot_spectrum_histogram(int64_t n, const float* wl, const float* w, const float* edges, int32_t nbins, double* hist,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

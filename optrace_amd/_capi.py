@@ -126,6 +126,8 @@ SIGNATURES = {
     "ot_image_convert": (C.c_int, [vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]),
     "ot_image_convolve": (C.c_int, [vp, i32, i32, vp, i32, vp, vp]),
     "ot_render_accumulate": (C.c_int, [i64, vp, vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp]),
+    "ot_spectrum_range": (C.c_int, [i64, vp, vp, vp, vp, vp]),
+    "ot_spectrum_histogram": (C.c_int, [i64, vp, vp, vp, i32, vp, vp]),
 }
 
 _lib = None

@@ -14,6 +14,7 @@
 #include "ot_generate.hpp"
 #include "ot_image.hpp"
 #include "ot_scene.hpp"
+#include "ot_spectrum.hpp"
 #include "ot_trace.hpp"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1031,6 +1032,51 @@ extern "C" int ot_image_convolve(const double* in, int32_t Nx, int32_t Ny, const
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)img_convolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(img_convolve_kernel, grid_for((int64_t)Nx * Ny), dim3(256), lds, (hipStream_t)stream, in, Nx, Ny, psf, ps, out);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+// ---- spectrum rendering ---------------------------------------------------------------------------------------
+static int cu_count() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        return prop.multiProcessorCount;
+    return 256;
+}
+
+extern "C" int ot_spectrum_range(int64_t n, const float* wl, const float* w, double* range2, int64_t* count, void* stream) {
+    if (n < 0 || !range2 || !count || (n && (!wl || !w))) return fail(OT_ERR_INVALID, "ot_spectrum_range: bad argument");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const double init[2] = {INFINITY, -INFINITY};
+    HIP_TRY(hipMemcpyAsync(range2, init, sizeof(init), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int64_t), st));
+    if (n == 0) return OT_OK;
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(spectrum_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, wl, w, range2,
+                       (unsigned long long*)count);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_spectrum_histogram(int64_t n, const float* wl, const float* w, const float* edges, int32_t nbins,
+                                     double* hist, void* stream) {
+    if (n < 0 || !edges || !hist || nbins < 1 || (n && (!wl || !w)))
+        return fail(OT_ERR_INVALID, "ot_spectrum_histogram: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return OT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // sums (f64) + edges (f32) per workgroup; 64 KiB keeps two workgroups of LDS per CU free for other work
+    const size_t lds = (size_t)nbins * sizeof(double) + ((size_t)nbins + 2) * sizeof(float);
+    const int lds_bins = lds <= 64 * 1024 ? nbins : 0;
+    int64_t blocks = (n + 1023) / 1024;
+    const int64_t cap = cu_count();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(spectrum_hist_kernel, dim3((unsigned)blocks), dim3(1024), lds_bins ? lds : 0, st, n, wl, w, edges,
+                       nbins, lds_bins, hist);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

@@ -1,0 +1,77 @@
+// Spectrum rendering: LightSpectrum.render (optrace/tracer/spectrum/light_spectrum.py:41-79) on the device.
+// The reference histograms the float32 wavelengths of the selected rays with np.histogram(wl, bins=N, weights=w,
+// range=[wl0, wl1]).  With float32 data and float32 range NumPy keeps the whole bin search in float32
+// (bin_type = result_type(first, last, a)); the kernels below follow that arithmetic so that a ray lands in the
+// same bin.  Rays are given dense (weight 0 = not selected), as ot_detector_hits leaves them.
+#pragma once
+#include "ot_detector.hpp"
+#include "ot_device.hpp"
+
+// pass 1: wavelength range and number of selected rays.  stats = {min wl, max wl} (pre-set to +inf / -inf),
+// count[0] += rays with w > 0 (np.count_nonzero(w) over the selected rays, light_spectrum.py:60,70)
+__global__ __launch_bounds__(256) void spectrum_stats_kernel(int64_t n, const float* __restrict__ wl, const float* __restrict__ w,
+                                                             double* __restrict__ stats, unsigned long long* __restrict__ count) {
+    const double inf = __builtin_inf();
+    double lo = inf, hi = -inf;
+    unsigned long long c = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (w[i] > 0.f) {
+            double l = (double)wl[i];
+            lo = fmin(lo, l);
+            hi = fmax(hi, l);
+            c++;
+        }
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (__lane_id() == 0 && c) {
+        atomic_min_f64(&stats[0], lo);
+        atomic_max_f64(&stats[1], hi);
+        atomicAdd(count, c);
+    }
+}
+
+// pass 2: weighted histogram over the float32 edges `edges` (nbins + 1 values, np.linspace of the reference).
+// Bin search of numpy/lib/_histograms_impl.py (uniform-bin fast path): scaled index in float32, then one-step
+// corrections against the edges; the last bin is closed on the right.  Sums are kept in float64.
+// LDS-privatised when the bins fit (lds_bins > 0), otherwise global atomics.
+__global__ __launch_bounds__(1024) void spectrum_hist_kernel(int64_t n, const float* __restrict__ wl, const float* __restrict__ w,
+                                                             const float* __restrict__ edges, int nbins, int lds_bins,
+                                                             double* __restrict__ hist) {
+    extern __shared__ double sh[];  // [lds_bins] sums, then [lds_bins + 1] edges as float
+    float* sedge = (float*)(sh + lds_bins);
+    if (lds_bins) {
+        for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) sh[i] = 0.0;
+        for (int i = threadIdx.x; i <= lds_bins; i += blockDim.x) sedge[i] = edges[i];
+        __syncthreads();
+    }
+    const float* e = lds_bins ? sedge : edges;
+    const float first = edges[0], last = edges[nbins];
+    const float denom = last - first;
+    const float fn = (float)nbins;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float wi = w[i];
+        if (!(wi > 0.f)) continue;
+        float x = wl[i];
+        if (!(x >= first && x <= last)) continue;
+        int idx = (int)(((x - first) / denom) * fn);
+        if (idx == nbins) idx -= 1;
+        if (x < e[idx]) idx -= 1;
+        if (x >= e[idx + 1] && idx != nbins - 1) idx += 1;
+        if (lds_bins)
+            unsafeAtomicAdd(&sh[idx], (double)wi);
+        else
+            unsafeAtomicAdd(&hist[idx], (double)wi);
+    }
+    if (lds_bins) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) {
+            double v = sh[i];
+            if (v != 0.0) unsafeAtomicAdd(&hist[i], v);
+        }
+    }
+}

@@ -28,6 +28,8 @@ from .options import global_options
 from .ray_storage import RayStorage
 from .refraction_index import RefractionIndex
 from .render_image import RenderImage
+from .spectrum import LightSpectrum
+from .geometry.ray_source import RaySource
 from .scene import CompiledScene, tracing_elements
 from ._device import require_device, stream_ptr, ptr
 from ._warn import warning
@@ -422,6 +424,61 @@ class Raytracer(Group):
             warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
                     f"numerical hit finding at detector {detector_index}. "
                     "Where and whether they intersect might be wrong.")
+        return img
+
+    def detector_spectrum(self, detector_index: int = 0, source_index: int = None, extent=None,
+                          **kwargs) -> LightSpectrum:
+        """Spectrum of the light hitting a detector (raytracer.py:1100-1132); hit search and histogram on the GPU."""
+        _, w, wl, _, _, ill_count = self._hit_detector("Detector Spectrum", detector_index, source_index, extent)
+
+        det = self.detectors[detector_index]
+        pname = f": {det.desc}" if det.desc != "" else ""
+        desc = f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm"
+        desc = (f"Spectrum of RS{source_index} at " if source_index is not None else "Spectrum at ") + desc
+
+        spec = LightSpectrum.render(wl, w, long_desc=desc, **kwargs)
+        if ill_count:
+            warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
+                    f"numerical hit finding at detector {detector_index}. "
+                    "Where and whether they intersect might be wrong.")
+        return spec
+
+    # ---- source side (raytracer.py:1281-1352) ---------------------------------------------------------------
+    def _hit_source(self, info: str, source_index: int = 0):
+        """Section-0 device views of one source's rays: ((x, y), w, wl, extent)  (raytracer.py:1281-1309)."""
+        if not self.ray_sources:
+            raise RuntimeError("Ray Sources Missing.")
+        if not self.rays.N:
+            raise RuntimeError("No rays traced.")
+        if source_index > len(self.ray_sources) - 1 or source_index < 0:
+            raise IndexError("Invalid source_index.")
+        if not self.check_if_rays_are_current():
+            raise RuntimeError("Tracing geometry/properties changed. Please retrace first.")
+
+        extent = self.ray_sources[source_index].extent[:4]
+        Ns, Ne = (int(v) for v in self.rays.B_list[source_index:source_index + 2])
+        N, nt = self.rays.N, self.rays.Nt
+        d = self.rays._dev
+        # element (ray r, section i, component c) of p lives at r + N * (i + nt * c); section 0 here
+        px, py = d["p"][Ns:Ne], d["p"][N * nt + Ns:N * nt + Ne]
+        return (px, py), d["w"][Ns:Ne], d["wl"][Ns:Ne], extent
+
+    def source_spectrum(self, source_index: int = 0, **kwargs) -> LightSpectrum:
+        """Spectrum emitted by a source, from its traced rays (raytracer.py:1311-1329)."""
+        _, w, wl, _ = self._hit_source("Source Spectrum", source_index)
+        rs = self.ray_sources[source_index]
+        pname = f": {rs.desc}" if rs.desc != "" else ""
+        desc = f"Spectrum of {RaySource.abbr}{source_index}{pname} at z = {rs.pos[2]:.5g} mm"
+        return LightSpectrum.render(wl, w, long_desc=desc, **kwargs)
+
+    def source_image(self, source_index: int = 0, limit: float = None, **kwargs) -> RenderImage:
+        """Image of a source's emitting area, from its traced rays (raytracer.py:1331-1352)."""
+        p, w, wl, extent = self._hit_source("Source Image", source_index)
+        rs = self.ray_sources[source_index]
+        pname = f": {rs.desc}" if rs.desc != "" else ""
+        desc = f"{RaySource.abbr}{source_index}{pname} at z = {rs.pos[2]:.5g} mm"
+        img = RenderImage(long_desc=desc, extent=extent, projection=None)
+        img.render(p, w, wl, limit=limit, **kwargs)
         return img
 
     # ---- iterative rendering (raytracer.py:1134-1279) -------------------------------------------------------

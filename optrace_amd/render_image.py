@@ -119,7 +119,9 @@ class RenderImage(BaseClass):
 
         n = 0 if p is None else (int(w.shape[0]))
         if n:
-            if isinstance(p, torch.Tensor):
+            if isinstance(p, tuple):  # (x, y) device tensors
+                (px, py), dw, dwl = p, w, wl
+            elif isinstance(p, torch.Tensor):
                 px, py = p[:n], p[n:2 * n]
                 dw, dwl = w, wl
             else:
@@ -204,7 +206,7 @@ class RenderImage(BaseClass):
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key == "extent" and val is not None:
-            check_type(key, val, (list, np.ndarray))
+            check_type(key, val, (list, tuple, np.ndarray))
             val = np.asarray_chkfinite(val, dtype=np.float64)
             if val.shape[0] != 4 or val[0] > val[1] or val[2] > val[3]:
                 raise ValueError("extent needs to be [x0, x1, y0, y1] with x1 >= x0, y1 >= y0")

@@ -190,6 +190,50 @@ class LightSpectrum(Spectrum):
             return res
         return super()._eval_host(wl)
 
+    @staticmethod
+    def render(wl, w, **kwargs) -> "LightSpectrum":
+        """Histogram spectrum (unit W/nm) of rays with wavelengths `wl` and powers `w`
+        (light_spectrum.py:41-79).  `wl`, `w`: float32 device tensors (or host arrays, uploaded as they are);
+        rays with weight 0 count as not selected, which is how `Raytracer._hit_detector` hands them over.
+        Range search and binning run on the GPU (ot_spectrum_range / ot_spectrum_histogram)."""
+        import torch
+        from ._device import require_device, ptr, stream_ptr
+        lib = _capi.load_library()
+        dev = require_device()
+        wl = torch.as_tensor(np.ascontiguousarray(wl) if isinstance(wl, np.ndarray) else wl).to(dev, torch.float32).contiguous()
+        w = torch.as_tensor(np.ascontiguousarray(w) if isinstance(w, np.ndarray) else w).to(dev, torch.float32).contiguous()
+        if wl.shape != w.shape or wl.ndim != 1:
+            raise ValueError("wl and w need to be one-dimensional arrays of the same length.")
+        spec = LightSpectrum("Histogram", **kwargs)
+        n = int(wl.shape[0])
+
+        rng = torch.empty(2, dtype=torch.float64, device=dev)
+        cnt = torch.empty(1, dtype=torch.int64, device=dev)
+        _capi.check(lib.ot_spectrum_range(n, ptr(wl), ptr(w), ptr(rng), ptr(cnt), stream_ptr()))
+        nz = int(cnt.item())
+
+        # at least 51 bins, growing with sqrt(N) above that; odd, so there is a bin for the range centre
+        N = max(51, np.sqrt(nz) / 2)
+        N = 1 + 2 * (int(N) // 2)
+
+        if not nz:
+            spec._wls = wavelengths(N + 1)
+            spec._vals = np.zeros(N, dtype=np.float64)
+            return spec
+
+        wl0, wl1 = (np.float32(v) for v in rng.cpu().numpy())
+        if np.abs(wl0 - wl1) < 1:  # widen to +-1 nm inside the visible range
+            wl0, wl1 = max(wl0 - 1, go.wavelength_range[0]), min(wl0 + 1, go.wavelength_range[1])
+        # float32 edges exactly as np.histogram builds them for float32 data and range
+        edges = np.linspace(wl0, wl1, N + 1, endpoint=True, dtype=np.float32)
+        d_edges = torch.from_numpy(edges).to(dev)
+        hist = torch.zeros(N, dtype=torch.float64, device=dev)
+        _capi.check(lib.ot_spectrum_histogram(n, ptr(wl), ptr(w), ptr(d_edges), N, ptr(hist), stream_ptr()))
+        spec._wls = edges
+        spec._vals = hist.cpu().numpy()
+        spec._vals *= 1 / (spec._wls[1] - spec._wls[0])  # W -> W/nm
+        return spec
+
     def _source_fields(self) -> dict:
         """Spectrum part of an `ot_source` for LightSpectrum.random_wavelengths (light_spectrum.py:81-138)."""
         st = self.spectrum_type

@@ -145,7 +145,8 @@ def sparse(img: np.ndarray) -> dict:
                 val=img[nz[0], nz[1], :])
 
 
-def gen_trace(name: str, builder, N: int, seed: int, **rt_args):
+def trace_recorded(builder, N: int, seed: int, **rt_args):
+    """Trace with the reference, recording what create_rays and the HURB normal draws hand to the tracer."""
     import optrace.tracer.geometry.ray_source as rsmod
     refload.reseed(ot, seed)
     RT = builder(ot, **rt_args)
@@ -175,7 +176,17 @@ def gen_trace(name: str, builder, N: int, seed: int, **rt_args):
     finally:
         rsmod.RaySource.create_rays = orig_create
         np.random.normal = orig_normal
-    assert not RT.geometry_error, name
+    assert not RT.geometry_error
+    return RT, rec, normals
+
+
+TRACE_CASES = {name: (builder, N, 100 + j, {}) for j, (name, (builder, N)) in enumerate(scenes.SCENES.items())}
+TRACE_CASES["double_gauss_nopol"] = (scenes.double_gauss, 1200, 300, dict(no_pol=True))
+TRACE_CASES["asphere_nopol"] = (scenes.asphere_scene, 1500, 301, dict(no_pol=True))
+
+
+def gen_trace(name: str, builder, N: int, seed: int, **rt_args):
+    RT, rec, normals = trace_recorded(builder, N, seed, **rt_args)
 
     out = dict(N=N, seed=seed)
     out["p0"] = np.vstack([r[0] for r in rec])
@@ -340,18 +351,60 @@ def gen_sources():
     print("sources.npz", len(out))
 
 
+def gen_spectra():
+    """detector_spectrum / source_spectrum / source_image of the reference (raytracer.py:1100-1132, 1311-1352)
+    for every trace case (same seeds as trace_<name>.npz, whose initial rays the tests inject), plus one larger
+    bundle ("big", stored with its initial rays) whose bin count follows sqrt(N)."""
+    out = {}
+
+    def record(prefix, RT):
+        with ot.global_options.no_warnings():
+            for di, det in enumerate(RT.detectors):
+                e0 = np.array(det.extent[:4])
+                cx, cy = (e0[0] + e0[1]) / 2, (e0[2] + e0[3]) / 2
+                uext = [cx - (e0[1] - e0[0]) / 5, cx + (e0[1] - e0[0]) / 4, cy - (e0[3] - e0[2]) / 4, cy + (e0[3] - e0[2]) / 6]
+                cases = {"all": {}, "user": dict(extent=uext, source_index=len(RT.ray_sources) - 1)}
+                for cname, kw in cases.items():
+                    spec = RT.detector_spectrum(detector_index=di, **kw)
+                    out[f"{prefix}/det{di}/{cname}/wls"], out[f"{prefix}/det{di}/{cname}/vals"] = spec._wls, spec._vals
+                out[f"{prefix}/det{di}/uext"] = np.array(uext)
+            for si in range(len(RT.ray_sources)):
+                spec = RT.source_spectrum(si)
+                out[f"{prefix}/src{si}/wls"], out[f"{prefix}/src{si}/vals"] = spec._wls, spec._vals
+                img = RT.source_image(si)
+                for k, v in sparse(img._data).items():
+                    out[f"{prefix}/src{si}/img/{k}"] = v
+                out[f"{prefix}/src{si}/img/extent"] = np.array(img.extent)
+                out[f"{prefix}/src{si}/img/power"] = img.power()
+
+    for name, (builder, N, seed, rt_args) in TRACE_CASES.items():
+        RT, _, _ = trace_recorded(builder, N, seed, **rt_args)
+        record(name, RT)
+
+    RT, rec, _ = trace_recorded(scenes.mixed_geometry, 40000, 410, no_pol=True)
+    out["big/p0"] = np.vstack([r[0] for r in rec])
+    out["big/s0"] = np.vstack([r[1] for r in rec]).astype(np.float32)  # exact: sources emit along +z here
+    assert np.array_equal(out["big/s0"].astype(np.float64), np.vstack([r[1] for r in rec]))
+    out["big/w0"] = np.concatenate([r[3] for r in rec])
+    out["big/wl"] = np.concatenate([r[4] for r in rec]).astype(np.float32)
+    out["big/N_list"] = np.array(RT.rays.N_list)
+    record("big", RT)
+    np.savez_compressed(HERE / "spectra.npz", **out)
+    print("spectra.npz", len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images"]
+    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images", "spectra"]
     if "leaf" in which:
         gen_leaf_surfaces()
     if "media" in which:
         gen_leaf_media()
     if "trace" in which:
-        for j, (name, (builder, N)) in enumerate(scenes.SCENES.items()):
-            gen_trace(name, builder, N, seed=100 + j)
-        gen_trace("double_gauss_nopol", scenes.double_gauss, 1200, seed=300, no_pol=True)
-        gen_trace("asphere_nopol", scenes.asphere_scene, 1500, seed=301, no_pol=True)
+        for name, (builder, N, seed, rt_args) in TRACE_CASES.items():
+            gen_trace(name, builder, N, seed=seed, **rt_args)
     if "sources" in which:
         gen_sources()
     if "images" in which:
         gen_image_modes()
+    if "spectra" in which:
+        gen_spectra()
