@@ -382,6 +382,28 @@ int ot_spectrum_range(int64_t n, const float* wl, const float* w, double* range2
 int ot_spectrum_histogram(int64_t n, const float* wl, const float* w, const float* edges, int32_t nbins, double* hist,
                           void* stream);
 
+/* Raytracer.focus_search (raytracer.py:1463-1640).  next row, SURVEY 8f rank 3.
+ * ot_focus_prepare: for rays [first, first + count) pick the section crossing z (pos = argmax(z < p_z) - 1,
+ *   raytracer.py:1552-1560) and write the hit line ph(z') = pa + sb * z' (raytracer.py:1580-1583):
+ *   pasb[4 * count] (device) = pa_x | pa_y | sb_x | sb_y, w[count] (device) = section weight, -1 for rays
+ *   without such a section; n_use[0] (device) = number of rays kept.
+ * ot_focus_cost: cost function __focus_search_cost_function (raytracer.py:1354-1418) of the kept rays at the nz
+ *   positions z[] (host array), mode OT_FOCUS_*; cost[nz] (device).  n_px = image side for the image methods
+ *   (100 * int(1 + sqrt(N) / 1500), made odd), workspace (device) >= OT_FOCUS_WS + n_px * n_px doubles.
+ * ot_focus_moments: sums[8] (device) for __focus_rms_spot_direct_solution (raytracer.py:1420-1460) and the mean
+ *   position: [0..4] = sum w, w pa_x, w pa_y, w sb_x, w sb_y; [5] = sum w^2 (dtx^2 + dty^2);
+ *   [6] = sum w^2 (dtx dx + dty dy) for the bounds b0 < b1. */
+#define OT_FOCUS_RMS 0
+#define OT_FOCUS_IRR_VAR 1
+#define OT_FOCUS_SHARPNESS 2
+#define OT_FOCUS_CENTER_SHARPNESS 3
+#define OT_FOCUS_WS 16
+int ot_focus_prepare(const ot_rays* rays, int64_t first, int64_t count, double z, double* pasb, float* w, int64_t* n_use,
+                     void* stream);
+int ot_focus_cost(int64_t count, const double* pasb, const float* w, int32_t mode, const double* z, int32_t nz,
+                  int32_t n_px, double* workspace, double* cost, void* stream);
+int ot_focus_moments(int64_t count, const double* pasb, const float* w, double b0, double b1, double* sums, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

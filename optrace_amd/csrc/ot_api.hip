@@ -11,6 +11,7 @@
 
 #include "ot_detector.hpp"
 #include "ot_device.hpp"
+#include "ot_focus.hpp"
 #include "ot_generate.hpp"
 #include "ot_image.hpp"
 #include "ot_scene.hpp"
@@ -1077,6 +1078,70 @@ extern "C" int ot_spectrum_histogram(int64_t n, const float* wl, const float* w,
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(spectrum_hist_kernel, dim3((unsigned)blocks), dim3(1024), lds_bins ? lds : 0, st, n, wl, w, edges,
                        nbins, lds_bins, hist);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+// ---- focus search -------------------------------------------------------------------------------------------
+static unsigned stream_blocks(int64_t n, int threads, int per_cu) {
+    int64_t blocks = (n + threads - 1) / threads;
+    const int64_t cap = (int64_t)cu_count() * per_cu;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int ot_focus_prepare(const ot_rays* rays, int64_t first, int64_t count, double z, double* pasb, float* w,
+                                int64_t* n_use, void* stream) {
+    if (!rays || !rays->p || !rays->w || first < 0 || count < 0 || first + count > rays->N || rays->nt < 2 || !n_use ||
+        (count && (!pasb || !w)))
+        return fail(OT_ERR_INVALID, "ot_focus_prepare: bad argument");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(n_use, 0, sizeof(int64_t), st));
+    if (count == 0) return OT_OK;
+    hipLaunchKernelGGL(focus_prepare_kernel, grid_for(count), dim3(256), 0, st, *rays, first, count, z, pasb, w,
+                       (unsigned long long*)n_use);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_focus_cost(int64_t count, const double* pasb, const float* w, int32_t mode, const double* z, int32_t nz,
+                             int32_t n_px, double* workspace, double* cost, void* stream) {
+    if (count < 1 || !pasb || !w || !z || nz < 1 || !workspace || !cost || mode < OT_FOCUS_RMS ||
+        mode > OT_FOCUS_CENTER_SHARPNESS || (mode != OT_FOCUS_RMS && n_px < 2))
+        return fail(OT_ERR_INVALID, "ot_focus_cost: bad argument");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    double* img = workspace + OT_FOCUS_WS;
+    const int64_t np2 = (int64_t)n_px * n_px;
+    const unsigned gs = stream_blocks(count, 256, 8), gb = stream_blocks(count, 1024, 1);
+    for (int i = 0; i < nz; i++) {
+        hipLaunchKernelGGL(focus_init_kernel, dim3(1), dim3(64), 0, st, workspace);
+        hipLaunchKernelGGL(focus_stats_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, z[i], workspace);
+        if (mode == OT_FOCUS_RMS) {
+            hipLaunchKernelGGL(focus_var_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, z[i], workspace);
+        } else {
+            HIP_TRY(hipMemsetAsync(img, 0, sizeof(double) * np2, st));
+            hipLaunchKernelGGL(focus_bin_kernel, dim3(gb), dim3(1024), 0, st, count, pasb, w, z[i], workspace, n_px, img);
+            hipLaunchKernelGGL(focus_image1_kernel, grid_for(np2), dim3(256), 0, st, img, n_px, mode, workspace);
+            if (mode == OT_FOCUS_IRR_VAR)
+                hipLaunchKernelGGL(focus_image2_kernel, grid_for(np2), dim3(256), 0, st, img, n_px, workspace);
+        }
+        hipLaunchKernelGGL(focus_finalize_kernel, dim3(1), dim3(64), 0, st, mode, n_px, workspace, cost + i);
+    }
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+extern "C" int ot_focus_moments(int64_t count, const double* pasb, const float* w, double b0, double b1, double* sums,
+                                void* stream) {
+    if (count < 1 || !pasb || !w || !sums || !(b1 > b0)) return fail(OT_ERR_INVALID, "ot_focus_moments: bad argument");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 8, st));
+    const unsigned gs = stream_blocks(count, 256, 8);
+    hipLaunchKernelGGL(focus_moments1_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, sums);
+    hipLaunchKernelGGL(focus_moments2_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, b0, b1, sums);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

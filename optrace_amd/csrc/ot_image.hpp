@@ -26,10 +26,6 @@
 #define OT_RED_RGBMAX2 6     // nanmax(M XYZ') of the corrected image
 #define OT_RED_N 8
 
-struct ImgC {  // constants of the colour maths
-    double un, vn;           // WP_D65_LUV[1:]
-};
-
 OT_DEV void to_rgbl(double X, double Y, double Z, double& r, double& g, double& b) {  // srgb.py:124-128
     r = 3.2404542 * X + -1.5371385 * Y + -0.4985314 * Z;
     g = -0.9692660 * X + 1.8760108 * Y + 0.0415560 * Z;

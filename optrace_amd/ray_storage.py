@@ -68,7 +68,8 @@ class RayStorage(BaseClass):
         super().__init__(**kwargs)
 
     # ---- allocation (ray_storage.py:35-90) ---------------------------------------------------------
-    def init(self, ray_source_list: list, N: int, nt: int, no_pol: bool, _single_power: float = None) -> None:
+    def init(self, ray_source_list: list, N: int, nt: int, no_pol: bool, _single_power: float = None,
+             _N_list=None) -> None:
         self._lock = False
         self.no_pol = no_pol
         assert N >= 0 and nt >= 0 and len(ray_source_list)
@@ -81,6 +82,9 @@ class RayStorage(BaseClass):
         dN = N - np.sum(self.N_list)
         index_add = np.random.choice(self.N_list.shape[0], size=dN, p=P_list / P_all)
         np.add.at(self.N_list, index_add, np.ones(index_add.shape))
+        if _N_list is not None:  # parity runs: the split the recorded rays were created with
+            self.N_list = np.asarray(_N_list).astype(int)
+            assert self.N_list.shape[0] == len(ray_source_list) and self.N_list.sum() == N
         if np.any(self.N_list == 0):
             warning("There are RaySources that have no rays assigned. "
                     "Change the power ratio or raise the overall ray number")

@@ -308,12 +308,13 @@ class Raytracer(Group):
             pass
 
     # ---- tracing (raytracer.py:262-415) -----------------------------------------------------------------
-    def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None) -> None:
+    def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None, _N_list=None) -> None:
         """Trace N rays through the current geometry.
 
         Geometry errors are reported as warnings and set `geometry_error` instead of raising, like the
-        reference.  `_initial_rays` = (p, s, pols, w, wl) and `_hurb_normals` (2*n_hurb, N) inject
-        recorded inputs for parity tests; normally rays are generated inside the tracing kernel.
+        reference.  `_initial_rays` = (p, s, pols, w, wl), `_N_list` (rays per source) and `_hurb_normals`
+        (2*n_hurb, N) inject recorded inputs for parity tests; normally rays are generated inside the
+        tracing kernel and the remainder of the per-source split is drawn at random like the reference does.
         """
         if self._pretrace_check(N):
             return
@@ -328,7 +329,7 @@ class Raytracer(Group):
 
         scene = self._compile()
         assert scene.nt == nt
-        self.rays.init(self.ray_sources, N, nt, self.no_pol)
+        self.rays.init(self.ray_sources, N, nt, self.no_pol, _N_list=_N_list)
         rays = self.rays._rays_struct()
         msgs = torch.zeros(len(self.INFOS) * nt + 1, dtype=torch.int64, device=dev)
         seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed)
@@ -480,6 +481,129 @@ class Raytracer(Group):
         img = RenderImage(long_desc=desc, extent=extent, projection=None)
         img.render(p, w, wl, limit=limit, **kwargs)
         return img
+
+    # ---- focus search (raytracer.py:1354-1640) ----------------------------------------------------------------
+    focus_search_methods = ['RMS Spot Size', 'Irradiance Variance', 'Image Sharpness', 'Image Center Sharpness']
+
+    def focus_search(self, method: str, z_start: float, source_index: int = None, return_cost: bool = False,
+                     _z_samples: np.ndarray = None):
+        """Find the focal position around `z_start` (raytracer.py:1463-1640).
+
+        The search region is the gap between the tracing surfaces (or sources / outline) around z_start.
+        Per ray the section crossing that gap is turned into the line ph(z) = pa + sb * z on the device
+        (`ot_focus_prepare`); every cost evaluation -- the 320 samples of the cost curve as well as each step
+        of SciPy's scalar optimisers -- is a chain of streaming kernels over those lines (`ot_focus_cost`).
+        `_z_samples` injects the sample positions of the cost curve (parity runs against recorded reference
+        samples); by default they are stratified draws from NumPy's global RNG like the reference's.
+        Returns (scipy OptimizeResult, dict(pos, bounds, z, cost, N))."""
+        import scipy.optimize
+
+        if not (self.outline[4] <= z_start <= self.outline[5]):
+            raise ValueError(f"Starting position z_start={z_start} outside raytracer"
+                             f" z-outline range {self.outline[4:]}.")
+        if method not in self.focus_search_methods:
+            raise ValueError(f"Invalid method '{method}', should be one of {self.focus_search_methods}.")
+        if not self.rays.N:
+            raise RuntimeError("No rays traced.")
+        if source_index is not None and source_index < 0:
+            raise IndexError(f"source_index needs to be >= 0, but is {source_index}")
+        if (source_index is not None and source_index > len(self.rays.N_list) - 1) or len(self.rays.N_list) == 0:
+            raise IndexError(f"source_index={source_index} larger than number of simulated sources "
+                             f"({len(self.rays.N_list)}. "
+                             "Either the source was not added or the new geometry was not traced.")
+        if not self.check_if_rays_are_current():
+            raise RuntimeError("Tracing geometry/properties changed or last trace had errors. Please retrace first.")
+
+        # search bounds: from the end of all sources (or the surface before z_start) to the next surface / outline
+        b0 = self.N_EPS + np.max([rs.extent[5] for rs in self.ray_sources])
+        b1 = self.outline[5] - self.N_EPS
+        for surf in self.tracing_surfaces:
+            if surf.z_max > z_start:
+                b1 = surf.z_min
+                break
+            b0 = surf.z_max
+        bounds = [float(b0), float(b1)]
+
+        Nt = 320  # cost function sampling points
+        Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
+        Ns, Ne = int(Ns), int(Ne)
+        n = Ne - Ns
+
+        lib = _capi.load_library()
+        dev = require_device()
+        pasb = torch.empty(4 * n, dtype=torch.float64, device=dev)
+        w = torch.empty(n, dtype=torch.float32, device=dev)
+        n_use_d = torch.empty(1, dtype=torch.int64, device=dev)
+        rays = self.rays._rays_struct()
+        _capi.check(lib.ot_focus_prepare(C.byref(rays), Ns, n, bounds[0] + self.N_EPS, ptr(pasb), ptr(w), ptr(n_use_d),
+                                         stream_ptr()))
+        N_use = int(n_use_d.item())
+        if N_use < 1000:
+            warning(f"WARNING: Less than 1000 rays for focus_search ({N_use}).")
+        if N_use <= 1:
+            return scipy.optimize.OptimizeResult(), \
+                dict(pos=[np.nan, np.nan, np.nan], bounds=bounds, z=np.full(Nt, np.nan),
+                     cost=np.full(Nt, np.nan), N=N_use)
+
+        mode = self.focus_search_methods.index(method)
+        # image side grows with sqrt(N) (raytracer.py:1381-1385), odd
+        N_px = 100 * int(1 + np.sqrt(N_use) / 1500)
+        N_px = N_px if N_px % 2 else N_px + 1
+        ws = torch.empty(_capi.FOCUS_WS + N_px * N_px, dtype=torch.float64, device=dev)
+
+        def cost_at(zs: np.ndarray) -> np.ndarray:
+            zs = np.ascontiguousarray(zs, dtype=np.float64)
+            out = torch.empty(zs.shape[0], dtype=torch.float64, device=dev)
+            _capi.check(lib.ot_focus_cost(n, ptr(pasb), ptr(w), mode,
+                                          zs.ctypes.data_as(C.POINTER(C.c_double)), zs.shape[0], N_px, ptr(ws), ptr(out),
+                                          stream_ptr()))
+            return out.cpu().numpy()
+
+        r = vals = None
+        if return_cost or method in ["Image Sharpness", "Image Center Sharpness"]:
+            if _z_samples is not None:
+                r = np.asarray(_z_samples, dtype=np.float64)
+            else:  # random.stratified_interval_sampling(b0, b1, Nt, shuffle=False), random.py:48-67
+                dba = (bounds[1] - bounds[0]) / Nt
+                r = np.linspace(bounds[0], bounds[1] - dba, Nt) + np.random.uniform(0., dba, Nt)
+            vals = cost_at(r)
+
+        sums = torch.empty(8, dtype=torch.float64, device=dev)
+        _capi.check(lib.ot_focus_moments(n, ptr(pasb), ptr(w), bounds[0], bounds[1], ptr(sums), stream_ptr()))
+        sm = sums.cpu().numpy()
+
+        if method == "RMS Spot Size":
+            # direct solution, extended by ray weights (raytracer.py:1420-1460)
+            dnorm = sm[5]
+            d = -sm[6] / dnorm if dnorm else np.mean(bounds)
+            d = float(np.clip(d, bounds[0], bounds[1]))
+            res = scipy.optimize.OptimizeResult()
+            res.x = d
+            res.fun = float(cost_at(np.array([d]))[0])
+        else:
+            def cost_func2(z, *_):
+                return float(cost_at(np.array([z[0]]))[0])
+
+            if method == "Irradiance Variance":
+                res = scipy.optimize.minimize(cost_func2, np.mean(bounds), tol=None, callback=None,
+                                              options={'maxiter': 100}, bounds=[bounds], method="Nelder-Mead")
+            else:
+                pos = int(np.argmin(vals))
+                res = scipy.optimize.minimize(cost_func2, r[pos], tol=None, callback=None,
+                                              options={'maxiter': 30}, bounds=[bounds], method="COBYLA")
+            res.x = res.x[0]
+
+        rrl = (res.x - bounds[0]) < 10 * (bounds[1] - bounds[0]) / Nt
+        rrr = (bounds[1] - res.x) < 10 * (bounds[1] - bounds[0]) / Nt
+        if rrl or rrr:
+            warning("Found minimum near search bounds, "
+                    "this can mean the focus is outside of the search range.")
+
+        # weighted mean ray position at the focus; the z component of pa + sb * z is z itself
+        pos = (float((sm[1] + sm[3] * res.x) / sm[0]), float((sm[2] + sm[4] * res.x) / sm[0]), float(res.x))
+        if not return_cost:
+            r = vals = None
+        return res, dict(pos=pos, bounds=bounds, z=r, cost=vals, N=N_use)
 
     # ---- iterative rendering (raytracer.py:1134-1279) -------------------------------------------------------
     def iterative_render(self, N, detector_index=0, limit=None, projection_method="Equidistant", pos=None,

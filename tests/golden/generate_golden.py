@@ -393,8 +393,47 @@ def gen_spectra():
     print("spectra.npz", len(out))
 
 
+FOCUS_CASES = {  # name -> (trace case, source_index, fraction of the way from the last surface to the outline end)
+    "c1_single_lens": ("c1_single_lens", None, 0.3),
+    "double_gauss_src0": ("double_gauss", 0, 0.5),
+    "double_gauss_all": ("double_gauss", None, 0.5),
+    "asphere": ("asphere", None, 0.4),
+    "mixed_first_gap": ("mixed_geometry", 1, None),  # gap between the first two lenses, two-source bundle
+}
+
+
+def focus_z_start(RT, frac):
+    if frac is None:
+        ts = RT.tracing_surfaces
+        return float((ts[1].z_max + ts[2].z_min) / 2)
+    z_last = max(s.z_max for s in RT.tracing_surfaces)
+    return float(z_last + frac * (RT.outline[5] - z_last))
+
+
+def gen_focus():
+    """Raytracer.focus_search (raytracer.py:1463-1640) of the reference on the rays of the trace cases:
+    sampled cost curve (z, cost), optimiser result, mean position, bounds and ray count per method."""
+    out = {}
+    for cname, (tname, si, frac) in FOCUS_CASES.items():
+        builder, N, seed, rt_args = TRACE_CASES[tname]
+        RT, _, _ = trace_recorded(builder, N, seed, **rt_args)
+        z_start = focus_z_start(RT, frac)
+        out[f"{cname}/z_start"] = z_start
+        with ot.global_options.no_warnings():
+            for mi, method in enumerate(RT.focus_search_methods):
+                refload.reseed(ot, 900 + mi)
+                res, d = RT.focus_search(method, z_start, source_index=si, return_cost=True)
+                k = f"{cname}/{mi}"
+                out[f"{k}/x"], out[f"{k}/fun"] = float(res.x), float(res.fun)
+                out[f"{k}/pos"], out[f"{k}/bounds"] = np.array(d["pos"]), np.array(d["bounds"])
+                out[f"{k}/z"], out[f"{k}/cost"], out[f"{k}/N"] = d["z"], d["cost"], d["N"]
+                print(cname, method, float(res.x), float(res.fun), d["N"])
+    np.savez_compressed(HERE / "focus.npz", **out)
+    print("focus.npz", len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images", "spectra"]
+    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images", "spectra", "focus"]
     if "leaf" in which:
         gen_leaf_surfaces()
     if "media" in which:
@@ -408,3 +447,5 @@ if __name__ == "__main__":
         gen_image_modes()
     if "spectra" in which:
         gen_spectra()
+    if "focus" in which:
+        gen_focus()

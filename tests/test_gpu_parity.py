@@ -113,7 +113,7 @@ def gpu_trace(name):
     hn = g["hurb_normals"] if "hurb_normals" in g else None
     init = (g["p0"], g["s0"], g["pol0"] if not RT.no_pol else None, g["w0"], g["wl"])
     with ot.global_options.no_warnings():
-        RT.trace(int(g["N"]), _initial_rays=init, _hurb_normals=hn)
+        RT.trace(int(g["N"]), _initial_rays=init, _hurb_normals=hn, _N_list=g["N_list"])
     assert not RT.geometry_error
     return g, RT
 

@@ -58,7 +58,7 @@ def test_big_bundle_bin_count():
     with ot.global_options.no_warnings():
         RT = scenes.mixed_geometry(ot, no_pol=True)
         init = (sp["big/p0"], sp["big/s0"].astype(np.float64), None, sp["big/w0"], sp["big/wl"])
-        RT.trace(int(sp["big/p0"].shape[0]), _initial_rays=init)
+        RT.trace(int(sp["big/p0"].shape[0]), _initial_rays=init, _N_list=sp["big/N_list"])
         assert np.array_equal(RT.rays.N_list, sp["big/N_list"])
         for si in range(2):
             spec = RT.source_spectrum(si)
