@@ -177,6 +177,28 @@ class RenderImage(BaseClass):
     def _sync_host(self) -> None:
         self._data = self._dev.cpu().numpy()
 
+    # ---- on-disk format (render_image.py:298-328): same keys, files are interchangeable with the reference ----
+    def save(self, path: str) -> None:
+        """Save as .npz archive (keys _data, extent, limit, desc, long_desc, proj); existing files are replaced."""
+        self._check_for_image()
+        limit = self._limit if self._limit is not None else np.nan
+        sdict = dict(_data=self._data, extent=self.extent, limit=limit,
+                     desc=self.desc, long_desc=self.long_desc, proj=str(self.projection))
+        path_ = path if path[-4:] == ".npz" else path + ".npz"
+        np.savez_compressed(path_, **sdict)
+
+    @staticmethod
+    def load(path: str) -> "RenderImage":
+        """Load a RenderImage archive written by `save` (or by the reference's RenderImage.save)."""
+        io = np.load(path)
+        im = RenderImage(io["extent"], long_desc=str(io["long_desc"][()]), desc=str(io["desc"][()]),
+                         projection=str(io["proj"][()]))
+        im._limit = io["limit"][()] if not np.isnan(io["limit"]) else None
+        im.projection = None if im.projection == "None" else im.projection  # None is stored as a string
+        im._data = np.ascontiguousarray(io["_data"], dtype=np.float64)
+        im._dev = None  # uploaded on first use (get / filter)
+        return im
+
     def _apply_rayleigh_filter(self) -> None:
         """Resolution-limit filter: convolve every channel with an Airy disc whose first zero lies at `limit`
         micrometres (render_image.py:257-296); the convolution runs on the GPU (`ot_image_convolve`)."""

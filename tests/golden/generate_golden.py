@@ -432,8 +432,19 @@ def gen_focus():
     print("focus.npz", len(out))
 
 
+def gen_render_image_file():
+    """A RenderImage archive written by the reference's own RenderImage.save (render_image.py:298-311):
+    the on-disk format the GPU path has to read and write."""
+    builder, N, seed, rt_args = TRACE_CASES["c1_single_lens"]
+    RT, _, _ = trace_recorded(builder, N, seed, **rt_args)
+    with ot.global_options.no_warnings():
+        img = RT.detector_image(limit=3.0, _dont_filter=True)  # unfiltered: sparse, compresses to a small file
+    img.save(str(HERE / "render_image_ref.npz"))
+    print("render_image_ref.npz", img._data.shape, img.power())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images", "spectra", "focus"]
+    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images", "spectra", "focus", "file"]
     if "leaf" in which:
         gen_leaf_surfaces()
     if "media" in which:
@@ -449,3 +460,5 @@ if __name__ == "__main__":
         gen_spectra()
     if "focus" in which:
         gen_focus()
+    if "file" in which:
+        gen_render_image_file()

@@ -225,3 +225,25 @@ def test_spectrum_descriptors():
         ot.LightSpectrum("Lines", lines=[300.], line_vals=[1])
     with pytest.raises(ValueError):
         ot.TransmissionSpectrum("Constant", val=1.5)
+
+
+def test_render_image_archive_round_trip(tmp_path):
+    """On-disk format of RenderImage (render_image.py:298-328): read a file the reference wrote, write it back,
+    read again -- keys and contents are preserved, so archives are interchangeable."""
+    from helpers import GOLDEN
+    ref = np.load(GOLDEN / "render_image_ref.npz")
+    im = ot.RenderImage.load(str(GOLDEN / "render_image_ref.npz"))
+    assert im._data.shape == (945, 945, 4) and im._data.dtype == np.float64
+    assert np.array_equal(im._data, ref["_data"]) and np.array_equal(im.extent, ref["extent"])
+    assert im.limit == 3.0 and im.projection is None
+    assert im.long_desc == str(ref["long_desc"][()]) and "DET0" in im.long_desc
+    assert abs(im.power() - ref["_data"][:, :, 3].sum()) < 1e-12
+    im.save(str(tmp_path / "again"))  # extension is appended
+    back = np.load(tmp_path / "again.npz")
+    assert sorted(back.files) == sorted(ref.files)
+    for k in ref.files:
+        assert np.array_equal(back[k], ref[k]), k
+    im2 = ot.RenderImage.load(str(tmp_path / "again.npz"))
+    assert np.array_equal(im2._data, im._data) and im2.limit == im.limit
+    with pytest.raises(RuntimeError):
+        ot.RenderImage([-1, 1, -1, 1]).save(str(tmp_path / "empty"))
