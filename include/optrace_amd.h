@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 1
+#define OT_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -57,6 +57,11 @@ extern "C" {
 #define OT_SURF_SLIT 3    /* SlitSurface        slit_surface.py:12        rect minus inner rect   */
 #define OT_SURF_CONIC 4   /* ConicSurface / SphericalSurface (k = 0) conic_surface.py:10          */
 #define OT_SURF_ASPHERE 5 /* AsphericSurface    aspheric_surface.py:9     conic + even polynomial */
+#define OT_SURF_TILTED 6  /* TiltedSurface      tilted_surface.py:10      tilted plane inside a disc */
+#define OT_SURF_DATA1D 7  /* DataSurface1D / FunctionSurface1D  data_surface_1d.py:6, function_surface_1d.py:8:
+                             radial profile z(r) as a FITPACK B-spline (knots + coefficients in `tab`)      */
+#define OT_SURF_DATA2D 8  /* DataSurface2D / FunctionSurface2D  data_surface_2d.py:10, function_surface_2d.py:12:
+                             z(x, y) as a tensor-product FITPACK B-spline                                   */
 
 #define OT_MAX_ASPH 12 /* even-order coefficients a2 .. a24 */
 #define OT_MAX_LINES 8 /* discrete wavelengths tabulated per scene */
@@ -75,7 +80,26 @@ typedef struct ot_surface {
     double z_min;   /* absolute z range of the surface (Surface.z_min / z_max)                   */
     double z_max;
     double coeff[OT_MAX_ASPH]; /* ASPHERE: a2, a4, ... [mm^-1, mm^-3, ...]                         */
+    double normal[3]; /* TILTED: unit normal with normal[2] > 0 (TiltedSurface.normal)            */
+    double sign;      /* DATA1D/2D: +1, or -1 after flip() (DataSurface2D._sign)                   */
+    double offset;    /* DATA1D/2D: spline value at the centre, removed from every value (._offset) */
+    /* DATA1D/2D: spline tables (host pointer, caller-owned, copied by the callee).  k = OT_SPL_K = 4.
+     *   DATA1D: t[nknots] | c[nknots] | dc[nknots]: knots, B-spline coefficients (padded with zeros to nknots,
+     *           as FITPACK/SciPy store them) and the coefficients of the first derivative (order k-1 on the
+     *           knots t[1..nknots-2]).  scipy InterpolatedUnivariateSpline(k=4) of the mirrored profile.
+     *   DATA2D: t[nknots] (same knots in x and y) | c[(nknots-5)^2] | cx[(nknots-6)(nknots-5)] |
+     *           cy[(nknots-5)(nknots-6)]: RectBivariateSpline(kx=ky=4) coefficients, row-major with y
+     *           fastest (FITPACK order), and those of d/dx and d/dy.  `angle` = DataSurface2D._angle.     */
+    const double* tab;
+    int64_t tab_len;
+    int32_t nknots;
+    int32_t flags;    /* OT_SURF_FLAG_* */
 } ot_surface;
+/* FunctionSurface2D.normals with a user deriv_func evaluates it at the UNROTATED relative coordinates and only
+ * rotates the resulting gradient (function_surface_2d.py:229-244); without deriv_func normals come from central
+ * differences of the (rotated) surface.  The flag selects the first behaviour so results match the reference. */
+#define OT_SURF_FLAG_DERIV_UNROTATED 1
+#define OT_SPL_K 4
 
 /* ---- media: RefractionIndex.__call__ refraction_index.py:62-169 ----------------------------- */
 #define OT_N_CONSTANT 0    /* c[0] = n                                                            */

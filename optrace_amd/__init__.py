@@ -13,7 +13,8 @@ from .refraction_index import RefractionIndex
 from .spectrum import Spectrum, LightSpectrum, TransmissionSpectrum
 from .geometry import (Surface, CircularSurface, RingSurface, RectangularSurface, SlitSurface, ConicSurface,
                        SphericalSurface, AsphericSurface, Point, Line, Element, Lens, IdealLens, Aperture,
-                       Filter, Detector, Group, RaySource)
+                       Filter, Detector, Group, RaySource, TiltedSurface, DataSurface1D, DataSurface2D,
+                       FunctionSurface1D, FunctionSurface2D)
 from .image import RGBImage, GrayscaleImage, ScalarImage
 from .render_image import RenderImage
 from .ray_storage import RayStorage

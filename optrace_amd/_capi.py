@@ -17,7 +17,9 @@ OT_MAX_ASPH = 12
 OT_MAX_LINES = 8
 
 # --- enums (kept in sync with the header) -------------------------------------------------------
-SURF_CIRCLE, SURF_RING, SURF_RECT, SURF_SLIT, SURF_CONIC, SURF_ASPHERE = range(6)
+SURF_CIRCLE, SURF_RING, SURF_RECT, SURF_SLIT, SURF_CONIC, SURF_ASPHERE, SURF_TILTED, SURF_DATA1D, SURF_DATA2D = range(9)
+SPL_K = 4  # OT_SPL_K
+SURF_FLAG_DERIV_UNROTATED = 1
 (N_CONSTANT, N_ABBE, N_CAUCHY, N_CONRADY, N_SELLMEIER1, N_SELLMEIER2, N_SELLMEIER3, N_SELLMEIER4,
  N_SELLMEIER5, N_SCHOTT, N_HERZBERGER, N_HOO1, N_HOO2, N_EXTENDED, N_EXTENDED2, N_EXTENDED3,
  N_DATA, N_LINES) = range(18)
@@ -42,7 +44,9 @@ class Surface(C.Structure):
     _fields_ = [("kind", C.c_int32), ("ncoeff", C.c_int32), ("pos", d3), ("r", C.c_double),
                 ("ri", C.c_double), ("dim", d2), ("dimi", d2), ("angle", C.c_double),
                 ("R", C.c_double), ("k", C.c_double), ("z_min", C.c_double), ("z_max", C.c_double),
-                ("coeff", C.c_double * OT_MAX_ASPH)]
+                ("coeff", C.c_double * OT_MAX_ASPH),
+                ("normal", d3), ("sign", C.c_double), ("offset", C.c_double),
+                ("tab", C.POINTER(C.c_double)), ("tab_len", C.c_int64), ("nknots", C.c_int32), ("flags", C.c_int32)]
 
 
 class Medium(C.Structure):
@@ -134,6 +138,7 @@ SIGNATURES = {
 }
 
 FOCUS_WS = 16  # OT_FOCUS_WS
+ABI_VERSION = 2  # OT_ABI_VERSION
 
 _lib = None
 
@@ -162,8 +167,9 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.ot_abi_version() != 1:
-        raise BackendError(f"ABI version mismatch: library reports {lib.ot_abi_version()}, binding expects 1")
+    if lib.ot_abi_version() != ABI_VERSION:
+        raise BackendError(f"ABI version mismatch: library reports {lib.ot_abi_version()}, "
+                           f"binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

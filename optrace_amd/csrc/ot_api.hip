@@ -57,6 +57,13 @@ static int require_device() {
 // ---------------------------------------------------------------------------------------------------------
 static double conic_sag(double rho, double k1rho2, double r2) { return rho * r2 / (1 + std::sqrt(1 - k1rho2 * r2)); }
 
+static int64_t surface_table_len(const ot_surface& s) {
+    const int64_t n = s.nknots, nc = n - OT_SPL_K - 1;
+    if (s.kind == OT_SURF_DATA1D) return 3 * n;
+    if (s.kind == OT_SURF_DATA2D) return n + nc * nc + 2 * (nc - 1) * nc;
+    return 0;
+}
+
 static int compile_surface(const ot_surface& s, SurfDev& d) {
     std::memset(&d, 0, sizeof(d));
     const double NE = OT_N_EPS_SURF;
@@ -74,6 +81,7 @@ static int compile_surface(const ot_surface& s, SurfDev& d) {
     d.zt1 = s.z_min - OT_C_EPS / 10;
     d.zt2 = s.z_max + OT_C_EPS / 10;
     d.edge_val = s.z_max;
+    d.r_edge = s.r - NE;
     switch (s.kind) {
         case OT_SURF_CIRCLE:
             d.r_eps2 = std::pow(s.r + NE, 2.0);
@@ -146,11 +154,72 @@ static int compile_surface(const ot_surface& s, SurfDev& d) {
             }
             break;
         }
+        case OT_SURF_TILTED: {
+            const double* nv = s.normal;
+            if (!(nv[2] > 0.0) || !std::isfinite(nv[0]) || !std::isfinite(nv[1]))
+                return fail(OT_ERR_INVALID, "tilted surface: normal[2] must be above 0");
+            d.r_eps2 = std::pow(s.r + NE, 2.0);
+            d.nx = nv[0];
+            d.ny = nv[1];
+            d.nz = nv[2];
+            d.mx = -nv[0] / nv[2];  // tilted_surface.py:69-70
+            d.my = -nv[1] / nv[2];
+            if (!d.flat) d.edge_val = s.pos[2] + ((s.r - NE) * d.mx + 0.0 * d.my);
+            break;
+        }
+        case OT_SURF_DATA1D:
+        case OT_SURF_DATA2D: {
+            const int n = s.nknots, nc = n - OT_SPL_K - 1;
+            if (!s.tab || nc < OT_SPL_K + 1) return fail(OT_ERR_INVALID, "data surface: spline tables missing or too short");
+            if (s.tab_len != surface_table_len(s)) return fail(OT_ERR_INVALID, "data surface: tab_len does not match nknots");
+            if (!(s.sign == 1.0 || s.sign == -1.0)) return fail(OT_ERR_INVALID, "data surface: sign must be +1 or -1");
+            d.r_eps2 = std::pow(s.r + NE, 2.0);
+            d.sgn = s.sign;
+            d.offs = s.offset;
+            d.nk = n;
+            d.deriv_unrot = (s.flags & OT_SURF_FLAG_DERIV_UNROTATED) ? 1 : 0;
+            const double span = s.tab[nc] - s.tab[OT_SPL_K];  // t(nk1 + 1) - t(k1)
+            if (!(span > 0.0)) return fail(OT_ERR_INVALID, "data surface: knots must increase");
+            d.inv_h = (double)(nc - OT_SPL_K - 1 > 0 ? nc - OT_SPL_K - 1 : 1) / span;
+            if (s.kind == OT_SURF_DATA2D) {
+                d.rot = (s.angle != 0.0);
+                d.cna = std::cos(-s.angle);
+                d.sna = std::sin(-s.angle);
+                d.cpa = std::cos(s.angle);
+                d.spa = std::sin(s.angle);
+            }
+            d.tab = s.tab;  // host pointer for the edge value below; the caller swaps in the device copy
+            if (!d.flat) d.edge_val = s.pos[2] + data_values_rel(d, s.r - NE, 0.0);
+            break;
+        }
         default:
             return fail(OT_ERR_INVALID, "surface: unknown kind");
     }
     return OT_OK;
 }
+
+// A compiled surface for the leaf entry points: spline tables (if any) are uploaded for the duration of the call.
+struct LeafSurface {
+    SurfDev d;
+    double* dev_tab = nullptr;
+    hipStream_t st = nullptr;
+    int init(const ot_surface* surf, hipStream_t stream) {
+        st = stream;
+        if (int rc = compile_surface(*surf, d)) return rc;
+        if (d.tab) {
+            HIP_TRY(hipMalloc((void**)&dev_tab, sizeof(double) * surf->tab_len));
+            HIP_TRY(hipMemcpyAsync(dev_tab, surf->tab, sizeof(double) * surf->tab_len, hipMemcpyHostToDevice, st));
+            d.tab = dev_tab;
+        }
+        return OT_OK;
+    }
+    ~LeafSurface() {
+        if (dev_tab) {
+            (void)hipStreamSynchronize(st);  // kernels of this call still read the tables
+            (void)hipFree(dev_tab);
+        }
+    }
+};
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -220,7 +289,7 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     }
     bool needs_full = false;  // anything beyond conic/flat lens surfaces and plain apertures
     for (const StepDev& d : steps)
-        needs_full |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER || d.hurb || surfs[d.surf].kind == OT_SURF_ASPHERE;
+        needs_full |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER || d.hurb || surfs[d.surf].kind >= OT_SURF_ASPHERE;
     const int nt = (int)steps.size() + 1;  // sections = tracing surfaces + 2, the end aperture being a step
 
     std::vector<FilterDev> filts(desc->n_filters > 0 ? desc->n_filters : 1);
@@ -293,7 +362,15 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     size_t pool_n = desc->table_pool_len > 0 ? (size_t)desc->table_pool_len : 1;
     size_t o_lines = align_up(o_pool + sizeof(double) * pool_n);
     size_t o_cnt = align_up(o_lines + sizeof(double) * (line_tab.size() + 1));
-    size_t total = align_up(o_cnt + sizeof(unsigned int) * (size_t)OT_CNT_SLOTS * (OT_N_INFOS * nt + 1));
+    size_t o_stab = align_up(o_cnt + sizeof(unsigned int) * (size_t)OT_CNT_SLOTS * (OT_N_INFOS * nt + 1));
+    std::vector<size_t> stab_off(surfs.size(), 0);  // spline tables of data surfaces
+    size_t total = o_stab;
+    for (size_t i = 0; i < surfs.size(); i++) {
+        if (!surfs[i].tab) continue;
+        stab_off[i] = total;
+        total = align_up(total + sizeof(double) * (size_t)desc->surfaces[i].tab_len);
+    }
+    total = align_up(total + 1);
 
     std::vector<char> host(total, 0);
     char* blob = nullptr;
@@ -321,6 +398,11 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     h.n_lines = n_lines;
     h.line_tab = (const double*)(blob + o_lines);
 
+    for (size_t i = 0; i < surfs.size(); i++) {
+        if (!surfs[i].tab) continue;
+        std::memcpy(host.data() + stab_off[i], desc->surfaces[i].tab, sizeof(double) * (size_t)desc->surfaces[i].tab_len);
+        surfs[i].tab = (const double*)(blob + stab_off[i]);
+    }
     std::memcpy(host.data() + o_hdr, &h, sizeof(h));
     std::memcpy(host.data() + o_surf, surfs.data(), sizeof(SurfDev) * surfs.size());
     std::memcpy(host.data() + o_elem, steps.data(), sizeof(StepDev) * steps.size());
@@ -842,8 +924,9 @@ extern "C" int ot_surface_find_hit(const ot_surface* surf, int64_t n, const doub
                                    uint8_t* is_hit, uint8_t* ill, void* stream) {
     if (!surf || n < 0 || (n && (!p || !s || !p_hit || !is_hit || !ill))) return fail(OT_ERR_INVALID, "ot_surface_find_hit: bad argument");
     if (int rc = require_device()) return rc;
-    SurfDev d;
-    if (int rc = compile_surface(*surf, d)) return rc;
+    LeafSurface ls;
+    if (int rc = ls.init(surf, (hipStream_t)stream)) return rc;
+    const SurfDev& d = ls.d;
     if (n == 0) return OT_OK;
     hipLaunchKernelGGL(find_hit_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, p, s, p_hit, is_hit, ill);
     HIP_TRY(hipGetLastError());
@@ -854,8 +937,9 @@ extern "C" int ot_surface_normals(const ot_surface* surf, int64_t n, const doubl
                                   void* stream) {
     if (!surf || n < 0 || (n && (!x || !y || !normals))) return fail(OT_ERR_INVALID, "ot_surface_normals: bad argument");
     if (int rc = require_device()) return rc;
-    SurfDev d;
-    if (int rc = compile_surface(*surf, d)) return rc;
+    LeafSurface ls;
+    if (int rc = ls.init(surf, (hipStream_t)stream)) return rc;
+    const SurfDev& d = ls.d;
     if (n == 0) return OT_OK;
     hipLaunchKernelGGL(normals_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, normals);
     HIP_TRY(hipGetLastError());
@@ -866,8 +950,9 @@ extern "C" int ot_surface_mask(const ot_surface* surf, int64_t n, const double* 
                                void* stream) {
     if (!surf || n < 0 || (n && (!x || !y || !mask))) return fail(OT_ERR_INVALID, "ot_surface_mask: bad argument");
     if (int rc = require_device()) return rc;
-    SurfDev d;
-    if (int rc = compile_surface(*surf, d)) return rc;
+    LeafSurface ls;
+    if (int rc = ls.init(surf, (hipStream_t)stream)) return rc;
+    const SurfDev& d = ls.d;
     if (n == 0) return OT_OK;
     hipLaunchKernelGGL(mask_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, mask);
     HIP_TRY(hipGetLastError());
@@ -878,8 +963,9 @@ extern "C" int ot_surface_values(const ot_surface* surf, int64_t n, const double
                                  void* stream) {
     if (!surf || n < 0 || (n && (!x || !y || !z))) return fail(OT_ERR_INVALID, "ot_surface_values: bad argument");
     if (int rc = require_device()) return rc;
-    SurfDev d;
-    if (int rc = compile_surface(*surf, d)) return rc;
+    LeafSurface ls;
+    if (int rc = ls.init(surf, (hipStream_t)stream)) return rc;
+    const SurfDev& d = ls.d;
     if (n == 0) return OT_OK;
     hipLaunchKernelGGL(values_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, z);
     HIP_TRY(hipGetLastError());
@@ -893,8 +979,9 @@ extern "C" int ot_surface_hurb_props(const ot_surface* surf, int64_t n, const do
     if (surf->kind != OT_SURF_RING && surf->kind != OT_SURF_SLIT)
         return fail(OT_ERR_UNSUPPORTED, "hurb_props is defined for ring and slit surfaces only");
     if (int rc = require_device()) return rc;
-    SurfDev d;
-    if (int rc = compile_surface(*surf, d)) return rc;
+    LeafSurface ls;
+    if (int rc = ls.init(surf, (hipStream_t)stream)) return rc;
+    const SurfDev& d = ls.d;
     if (n == 0) return OT_OK;
     hipLaunchKernelGGL(hurb_props_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, d, n, x, y, a_, b_, b, inside);
     HIP_TRY(hipGetLastError());
@@ -923,8 +1010,9 @@ extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t coun
     if (first < 0 || count < 0 || first + count > rays->N) return fail(OT_ERR_INVALID, "ot_detector_hits: range outside the storage");
     if (projection < OT_PROJ_NONE || projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
     if (int rc = require_device()) return rc;
-    SurfDev d;
-    if (int rc = compile_surface(*detector, d)) return rc;
+    LeafSurface ls;
+    if (int rc = ls.init(detector, (hipStream_t)stream)) return rc;
+    const SurfDev& d = ls.d;
     if (count == 0) return OT_OK;
     double R = detector->R;
     hipLaunchKernelGGL(detector_kernel, grid_for(count), dim3(256), 0, (hipStream_t)stream, *rays, first, count, d, R,

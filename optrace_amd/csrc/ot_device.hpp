@@ -46,6 +46,59 @@ OT_DEV V3 along(const V3& p, const V3& s, double t) {
     return r;
 }
 
+#include "ot_spline.hpp"
+
+// ---- spline surfaces: DataSurface2D._call / ._values / .normals data_surface_2d.py:126-196 -----------------
+// table layout (include/optrace_amd.h): DATA1D t[n] | c[n] | dc[n];  DATA2D t[n] | c[(n-5)^2] | cx[(n-6)(n-5)] | cy
+template <class SF>
+OT_HD double data_values_rel(SF& sf, double x, double y) {
+    const double* t = sf.tab;
+    const int n = sf.nk;
+    double v;
+    if (sf.kind == OT_SURF_DATA1D) {
+        v = spl1_eval<OT_SPL_K>(t, n, t + n, sf.inv_h, hypot(x, y));
+    } else {
+        double xr = x, yr = y;
+        if (sf.rot) {  // _rotate_rc(x, y, -angle)
+            xr = x * sf.cna - y * sf.sna;
+            yr = x * sf.sna + y * sf.cna;
+        }
+        v = spl2_eval<OT_SPL_K, OT_SPL_K>(t, n, t, n, t + n, sf.inv_h, xr, sf.sgn * yr);
+    }
+    return sf.sgn * (v - sf.offs);
+}
+
+// -(dz/dx), -(dz/dy), 1 normalised; x, y relative to the centre, inside the mask
+template <class SF>
+OT_HD void data_gradient(SF& sf, double x, double y, double& gx, double& gy) {
+    const double* t = sf.tab;
+    const int n = sf.nk;
+    if (sf.kind == OT_SURF_DATA1D) {
+        const double r = hypot(x, y);
+        const double nr = sf.sgn * spl1_eval<OT_SPL_K - 1>(t, n, t + 2 * n, sf.inv_h, r);
+        const double rr = sqrt(x * x + y * y);
+        gx = nr * ((rr > 0.0) ? x / rr : 1.0);  // cos(arctan2(y, x))
+        gy = nr * ((rr > 0.0) ? y / rr : 0.0);
+        return;
+    }
+    double xr = x, yr = y;
+    if (sf.rot && !sf.deriv_unrot) {  // deriv_unrot: OT_SURF_FLAG_DERIV_UNROTATED, function_surface_2d.py:235
+        xr = x * sf.cna - y * sf.sna;
+        yr = x * sf.sna + y * sf.cna;
+    }
+    const int nc = (n - OT_SPL_K - 1), ncx = (n - OT_SPL_K - 2) * nc;
+    const double* c = t + n;
+    double nxn = spl2_eval<OT_SPL_K - 1, OT_SPL_K>(t + 1, n - 2, t, n, c + nc * nc, sf.inv_h, xr, sf.sgn * yr) * sf.sgn;
+    double nyn = spl2_eval<OT_SPL_K, OT_SPL_K - 1>(t, n, t + 1, n - 2, c + nc * nc + ncx, sf.inv_h, xr, sf.sgn * yr);
+    if (sf.rot) {  // _rotate_rc(nxn, nyn, +angle)
+        gx = nxn * sf.cpa - nyn * sf.spa;
+        gy = nxn * sf.spa + nyn * sf.cpa;
+    } else {
+        gx = nxn;
+        gy = nyn;
+    }
+}
+
 // ---- masks: surface.py:235, ring_surface.py:123, rectangular_surface.py:100, slit_surface.py:89 ----------
 template <class SF>
 OT_DEV bool surf_mask(SF& sf, double x, double y) {
@@ -94,6 +147,8 @@ OT_DEV double asph_poly_deriv(SF& sf, double r) {  // polyval(polyder(..)) asphe
 // Surface._values relative to the centre: conic_surface.py:57, aspheric_surface.py:51
 template <class SF>
 OT_DEV double surf_values_rel(SF& sf, double x, double y) {
+    if (sf.kind == OT_SURF_TILTED) return x * sf.mx + y * sf.my;  // tilted_surface.py:60-73
+    if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) return data_values_rel(sf, x, y);
     if (sf.kind == OT_SURF_CONIC) {
         double r2 = x * x + y * y;
         return sf.rho * r2 / (1 + sqrt(1 - sf.k1rho2 * r2));
@@ -110,6 +165,14 @@ template <class SF>
 OT_DEV double surf_values(SF& sf, double x, double y) {
     if (sf.flat) return sf.z_max;
     if (surf_mask(sf, x, y)) return sf.pz + surf_values_rel(sf, x - sf.px, y - sf.py);
+    if (sf.kind == OT_SURF_TILTED || sf.kind == OT_SURF_DATA2D) {
+        // no rotational symmetry: edge value along the direction of (x, y), surface.py:156-159;
+        // cos / sin of arctan2 formed as dx / rr, dy / rr like in surf_normal
+        double dx = x - sf.px, dy = y - sf.py;
+        double rr = sqrt(dx * dx + dy * dy);
+        double c = (rr > 0.0) ? dx / rr : 1.0, sn = (rr > 0.0) ? dy / rr : 0.0;
+        return sf.pz + surf_values_rel(sf, sf.r_edge * c, sf.r_edge * sn);
+    }
     return sf.edge_val;
 }
 
@@ -117,13 +180,25 @@ OT_DEV double surf_values(SF& sf, double x, double y) {
 // FunctionSurface2D.normals (1D branch) function_surface_2d.py:216-251 + AsphericSurface._deriv :67-82.
 // cos(atan2(dy,dx)) and sin(atan2(dy,dx)) are formed as dx/r, dy/r: same value to 1-2 ulp without three
 // transcendental calls per ray (normals never feed a mask directly; tolerance 1e-6).
-template <bool INSIDE = false, class SF>
+template <bool INSIDE = false, bool ALL_KINDS = true, class SF>
 OT_DEV V3 surf_normal(SF& sf, double x, double y) {
     V3 n = {0.0, 0.0, 1.0};
-    if (sf.kind != OT_SURF_CONIC && sf.kind != OT_SURF_ASPHERE) return n;
+    if (sf.kind < OT_SURF_CONIC) return n;
+    if (!ALL_KINDS && sf.kind != OT_SURF_CONIC) return n;  // kernel variant for scenes of flat and conic surfaces
+    if (sf.kind == OT_SURF_TILTED) {  // tilted_surface.py:75-89: constant, also when the plane happens to be flat
+        if (!INSIDE && !surf_mask(sf, x, y)) return n;
+        V3 m = {sf.nx, sf.ny, sf.nz};
+        return m;
+    }
     if (sf.flat) return n;
     if (!INSIDE && !surf_mask(sf, x, y)) return n;  // INSIDE: caller already knows mask(x, y) is true
     double dx = x - sf.px, dy = y - sf.py;
+    if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) {  // data_surface_2d.py:153-196
+        double gx, gy;
+        data_gradient(sf, dx, dy, gx, gy);
+        V3 m = {-gx, -gy, 1.0};
+        return normalize3(m);
+    }
     if (sf.kind == OT_SURF_CONIC) {
         if (sf.k == 0.0) {
             n.x = sf.nrho * dx;
@@ -235,16 +310,30 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         hit = false;
         return true;
     }
+    // TiltedSurface.find_hit tilted_surface.py:91-123: closed-form plane hit first; rays that miss the disc go
+    // through the generic search below (the edge is continued radially), the others sit it out
+    bool pre = false;
+    V3 ph_pre = {0.0, 0.0, 0.0};
+    if (sf.kind == OT_SURF_TILTED) {
+        double td = s.x * sf.nx + s.y * sf.ny + s.z * sf.nz;
+        bool nz0 = td != 0;
+        double t = ((sf.px - p.x) * sf.nx + (sf.py - p.y) * sf.ny + (sf.pz - p.z) * sf.nz) / (nz0 ? td : 1e-12);
+        ph_pre = along(p, s, t);
+        pre = surf_mask(sf, ph_pre.x, ph_pre.y) && nz0;
+    }
     double t1 = (sf.zt1 - p.z) / s.z;
     double t2 = (sf.zt2 - p.z) / s.z;
     if (t1 < 0) t1 = -OT_C_EPS;
     V3 p1 = along(p, s, t1), p2 = along(p, s, t2);
-    double f1 = p1.z - surf_values(sf, p1.x, p1.y);
-    double f2 = p2.z - surf_values(sf, p2.x, p2.y);
-    bool w = isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
+    double f1 = 0.0, f2 = 0.0;
+    if (!pre) {
+        f1 = p1.z - surf_values(sf, p1.x, p1.y);
+        f2 = p2.z - surf_values(sf, p2.x, p2.y);
+    }
+    bool w = !pre && isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
     ph.x = ph.y = ph.z = 0.0;
     if (!w) ph = p1;
-    ill = f1 * f2 > 0;
+    ill = !pre && f1 * f2 > 0;
     bool ok = true;
     int it = 1;
     while (__ballot(w) != 0ull) {
@@ -279,8 +368,17 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         }
         it++;
     }
-    hit = surf_mask(sf, ph.x, ph.y);
-    handle_abnormal(sf, p, s, ph, hit);
+    if (!pre) {
+        hit = surf_mask(sf, ph.x, ph.y);
+        handle_abnormal(sf, p, s, ph, hit);
+    }
+    if (sf.kind == OT_SURF_TILTED) {  // tilted_surface.py:119-120: abnormal handling once more, for all rays
+        if (pre) {
+            ph = ph_pre;
+            hit = true;
+        }
+        handle_abnormal(sf, p, s, ph, hit);
+    }
     return ok;
 }
 

@@ -30,12 +30,20 @@ struct SurfDev {
     double z_beh;             // z_max + N_EPS                          surface.py:460
     double zt1, zt2;          // z_min - C_EPS/10, z_max + C_EPS/10     surface.py:331-332
     double edge_val;          // value outside the mask                 surface.py:162
+    double r_edge;            // r - N_EPS                              surface.py:153
     // hurb
     double ri;                // ring inner radius
     double hdx, hdy;          // dimi[0]/2, dimi[1]/2
     double cpa, spa;          // cos(angle), sin(angle)                 slit_surface.py:83-84
     double coeff[OT_MAX_ASPH];   // a2, a4, ...
     double dcoeff[OT_MAX_ASPH];  // a_j * (2j+2): np.polyder coefficients
+    // tilted plane: unit normal and the slopes -n_x/n_z, -n_y/n_z      tilted_surface.py:69-72
+    double nx, ny, nz, mx, my;
+    // spline surfaces (DATA1D / DATA2D): sign, centre offset, knots per unit length (interval guess),
+    // device pointer to the tables laid out as include/optrace_amd.h describes, knots per dimension
+    double sgn, offs, inv_h;
+    const double* tab;
+    int32_t nk, deriv_unrot;
 };
 
 // One step per tracing surface, in ray order (the element list of raytracer.py:492-508 flattened).

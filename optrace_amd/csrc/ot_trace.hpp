@@ -150,10 +150,10 @@ OT_DEV double fresnel_T2(double n1, double n2, double ns, double W, double A_ts2
 // Raytracer.__refraction raytracer.py:761-829 for a lane that has power and hit the surface.
 // The new direction s' is computed in the reference's exact operation order (it feeds the next hit mask).
 // Returns true on total internal reflection.
-template <bool POL, class SF>
+template <bool POL, bool FULL, class SF>
 OT_DEV bool refract(SF& sf, RayState& r, const V3& pn, float& wn, float& npx, float& npy, float& npz,
                     double n1, double n2, double N) {  // N = n1 / n2 (raytracer.py:799)
-    V3 n = surf_normal<true>(sf, pn.x, pn.y);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
+    V3 n = surf_normal<true, FULL>(sf, pn.x, pn.y);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
     V3 s = r.s;
     double ns = dot3(n, s);
     double W = sqrt(1 - N * N * (1 - ns * ns));
@@ -333,7 +333,7 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
                 if (FULL && kind == OT_STEP_IDEAL)
                     refract_ideal<POL>(sf, st, r, pn, npx, npy, npz);
                 else
-                    tir = refract<POL>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq);
+                    tir = refract<POL, FULL>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq);
             }
             count_event(msgs, nt, OT_INFO_TIR, i, tir);
         } else if (FULL && kind == OT_STEP_FILTER) {  // raytracer.py:379-380

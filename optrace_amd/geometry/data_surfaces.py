@@ -1,0 +1,494 @@
+"""Tilted, data-defined and function-defined surfaces.
+
+Mirror of optrace/tracer/geometry/surface/{tilted_surface,data_surface_1d,data_surface_2d,function_surface_1d,
+function_surface_2d}.py.  Per-ray work (hit search, values, normals, masks) runs in the HIP kernels; this
+module holds the property handling and the one-off set-up: for data surfaces the same SciPy spline fit the
+reference performs in its constructor, handed to the device as knots + B-spline coefficients (value and first
+derivatives) which the kernels evaluate in FITPACK's operation order (csrc/ot_spline.hpp).
+
+Function surfaces are defined by Python callables, which cannot run inside a kernel: they are sampled once at
+construction on a dense grid and carried as the same quartic splines ("tabulated FunctionSurface").
+The sampling density is a class attribute; the measured residual against the callable is checked at
+construction and reported if it exceeds `TAB_TOL`.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Callable
+
+import numpy as np
+import scipy.interpolate
+
+from .. import _capi
+from ..base import check_type, check_above
+from .._warn import warning
+from .surfaces import Surface
+
+_K = _capi.SPL_K
+
+
+# ---- spline tables (layout: include/optrace_amd.h, ot_surface.tab) -------------------------------------------
+def _deriv_coeffs_1d(t: np.ndarray, c: np.ndarray, k: int) -> np.ndarray:
+    """First-derivative coefficients as FITPACK's splder.f builds them: wrk(i) = k (c(i+1) - c(i)) / (t(i+k+1) - t(i+1))."""
+    n = t.shape[0]
+    nk1 = n - k - 1
+    wrk = c[:nk1].copy()
+    fac = t[1 + k:k + nk1] - t[1:nk1]
+    ok = fac > 0
+    wrk[:nk1 - 1][ok] = (k * (c[1:nk1] - c[:nk1 - 1]) / fac)[ok]
+    out = np.zeros(n)
+    out[:nk1] = wrk
+    return out
+
+
+def _table_1d(spl) -> tuple[np.ndarray, int]:
+    t, c, k = spl._eval_args
+    assert k == _K
+    t, c = np.asarray(t, dtype=np.float64), np.asarray(c, dtype=np.float64)
+    n = t.shape[0]
+    cc = np.zeros(n)
+    cc[:c.shape[0]] = c[:n]
+    return np.ascontiguousarray(np.concatenate((t, cc, _deriv_coeffs_1d(t, cc, k)))), n
+
+
+def _table_2d(spl) -> tuple[np.ndarray, int]:
+    tx, ty, c = spl.tck
+    kx, ky = spl.degrees
+    assert kx == _K and ky == _K and np.array_equal(tx, ty)
+    t = np.asarray(tx, dtype=np.float64)
+    n = t.shape[0]
+    nc = n - _K - 1
+    C = np.asarray(c, dtype=np.float64).reshape(nc, nc)
+    # parder.f / pardeu.f: (c(i+1, :) - c(i, :)) * k / (t(i+k+1) - t(i+1)), same along y
+    fac = t[1 + _K:_K + nc] - t[1:nc]
+    ok = fac > 0
+    cx = C[:-1, :].copy()
+    cx[ok, :] = ((C[1:, :] - C[:-1, :]) * _K / fac[:, None])[ok, :]
+    cy = C[:, :-1].copy()
+    cy[:, ok] = ((C[:, 1:] - C[:, :-1]) * _K / fac[None, :])[:, ok]
+    return np.ascontiguousarray(np.concatenate((t, C.ravel(), cx.ravel(), cy.ravel()))), n
+
+
+# ---- TiltedSurface ---------------------------------------------------------------------------------------------
+class TiltedSurface(Surface):
+    """Circular plane section with an arbitrary normal (tilted_surface.py:10-161)."""
+
+    rotational_symmetry = False
+    _kind = _capi.SURF_TILTED
+
+    def __init__(self, r: float, normal=None, normal_sph=None, **kwargs) -> None:
+        self._lock = False
+        super().__init__(r, **kwargs)
+        self.r = r
+        self.parax_roc = None
+        self.z_min = self.z_max = self.pos[2]
+        if normal is not None:
+            self.normal = normal
+        elif normal_sph is not None:
+            check_type("normal_sph", normal_sph, (list, np.ndarray))
+            theta, phi = np.radians(normal_sph[0]), np.radians(normal_sph[1])
+            self.normal = [np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)]
+        else:
+            raise RuntimeError("normal or normal_sph parameter needs to be specified.")
+        # the extreme heights lie on the edge along the projected normal (tilted_surface.py:46-50)
+        phi = np.arctan2(self.normal[1], self.normal[0])
+        R = self.r
+        val1 = self.pos[2] + self._values_rel_host(np.array([R * np.cos(phi)]), np.array([R * np.sin(phi)]))[0]
+        val2 = self.pos[2] + self._values_rel_host(np.array([-R * np.cos(phi)]), np.array([-R * np.sin(phi)]))[0]
+        self.z_min, self.z_max = min(val1, val2), max(val1, val2)
+        self.lock()
+
+    @property
+    def info(self) -> str:
+        return super().info + f", normal = [{self.normal[0]:.4f}, {self.normal[1]:.4f}, {self.normal[2]:.4f}]"
+
+    def _values_rel_host(self, x, y):
+        mx = -self.normal[0] / self.normal[2]
+        my = -self.normal[1] / self.normal[2]
+        return x * mx + y * my
+
+    def flip(self) -> None:
+        """Flip around the x-axis: [x, y, z] -> [x, -y, -z], negated to point towards +z: [-x, y, z]."""
+        self._lock = False
+        self.normal.flags.writeable = True
+        self.normal[0] *= -1
+        self.lock()
+
+    def rotate(self, angle: float) -> None:
+        self._lock = False
+        self.normal.flags.writeable = True
+        self.normal[:2] = self._rotate_rc(self.normal[0], self.normal[1], np.deg2rad(angle))
+        self.lock()
+
+    def _desc(self):
+        d = super()._desc()
+        d.normal[:] = [float(v) for v in self.normal]
+        return d
+
+    def __setattr__(self, key: str, val: Any) -> None:
+        if key == "normal" and val is not None:
+            check_type(key, val, (list, np.ndarray))
+            val2 = np.asarray_chkfinite(val, dtype=np.float64) / np.linalg.norm(val)
+            check_above("normal[2]", val2[2], 0)
+            super().__setattr__(key, val2)
+        else:
+            super().__setattr__(key, val)
+
+
+# ---- data surfaces ---------------------------------------------------------------------------------------------
+class DataSurface2D(Surface):
+    """Surface given by a square grid of heights (data_surface_2d.py:10-227), interpolated by a quartic
+    tensor-product B-spline (RectBivariateSpline(kx=4, ky=4)) that the device evaluates."""
+
+    rotational_symmetry = False
+    _1D = False
+    _kind = _capi.SURF_DATA2D
+
+    def __init__(self, r: float, data: np.ndarray, parax_roc: float = None, **kwargs) -> None:
+        self._lock = False
+        super().__init__(r, **kwargs)
+        self._sign = 1
+        self._angle = 0
+        self._interp, self._offset = None, 0.
+        self._tab = None
+        self.parax_roc = parax_roc
+
+        check_type("data", data, (np.ndarray, list))
+        Z = np.asarray_chkfinite(data, dtype=np.float64).copy()
+        surf_name = f"{type(self).__name__} {self.get_desc(hex(id(self)))}"
+        nx = Z.shape[0]
+        if nx < 50:
+            raise ValueError("For a good surface representation 'data' should have at least 50 values per dimension")
+        if nx < 200:
+            warning(f"{surf_name}: At least 200 values per dimension are advised for a 'data' matrix, "
+                    f"but got {nx} values for surface {self.get_desc(hex(id(self)))}.")
+        z_range0 = self._fit(Z)
+
+        # interpolation can enlarge the z range (data_surface_2d.py:108-119)
+        z_range1 = self.z_max - self.z_min
+        if np.abs(z_range0 - z_range1) > self.N_EPS:
+            z_change = (z_range1 - z_range0) / z_range0
+            add_warning = "WARNING: Deviations this high can be due to noise or abrupt changes in the data."\
+                          " DO NOT USE SUCH SURFACES HERE." if z_change > 0.05 else ""
+            warning(f"{surf_name}: Due to biquadratic interpolation the z_range of the surface"
+                    f" has increased from {z_range0:.9g} to {z_range1:.9g},"
+                    f" a change of {z_change*100:.5g}%. {add_warning}")
+        self.lock()
+
+    def _fit(self, Z: np.ndarray) -> float:
+        """Spline fit + z range (data_surface_2d.py:59-104); returns the z range of the input data."""
+        if self._1D:
+            if Z.ndim != 1:
+                raise ValueError("data array needs to have exactly one dimension.")
+            Z -= Z[0]
+            r0 = np.linspace(0, self.r, Z.shape[0], dtype=np.float64)
+            # mirrored profile: symmetric, centre included (data_surface_2d.py:67-70)
+            r2 = np.concatenate((-np.flip(r0[1:]), r0))
+            z2 = np.concatenate((np.flip(Z[1:]), Z))
+            self._interp = scipy.interpolate.InterpolatedUnivariateSpline(r2, z2, k=_K)
+            self._tab, self._nknots = _table_1d(self._interp)
+            self._offset = float(self._call(0, 0))
+            rn = np.linspace(0, self.r, 10000)
+            zn = self._values_rel_host(rn, np.zeros_like(rn))
+            self.z_min, self.z_max = float(np.min(zn)), float(np.max(zn))
+            return float(np.ptp(Z))
+
+        if Z.ndim != 2:
+            raise ValueError("data array needs to have exactly two dimensions.")
+        ny, nx = Z.shape
+        if nx != ny:
+            raise ValueError("Array 'data' needs to be of square shape.")
+        if nx % 2:  # remove the offset at the centre (data_surface_2d.py:92-95)
+            Z -= np.array([Z[ny//2, nx//2], Z[ny//2+1, nx//2], Z[ny//2, nx//2+1], Z[ny//2+1, nx//2+1]]).mean()
+        else:
+            Z -= Z[ny//2, nx//2]
+        xy = np.linspace(-self.r, self.r, nx)
+        self._interp = scipy.interpolate.RectBivariateSpline(xy, xy, Z, kx=_K, ky=_K)
+        self._tab, self._nknots = _table_2d(self._interp)
+        self._offset = float(self._call(0, 0))
+        self.z_min, self.z_max = self._find_bounds()
+        X, Y = np.meshgrid(xy, xy)
+        M = self._mask_host(X.ravel(), Y.ravel()).reshape(X.shape)
+        return float(np.max(Z[M]) - np.min(Z[M]))
+
+    def _find_bounds(self) -> tuple[float, float]:
+        """z range from sunflower sampling of the disc plus its edge (surface.py:57-93); set-up only."""
+        N = 50000
+        ind = np.arange(0, N, dtype=np.float64)
+        r = np.sqrt(ind / N) * self.r
+        phi = 2 * np.pi * (1 + 5 ** 0.5) / 2 * ind
+        rcos, rsin = r * np.cos(phi), r * np.sin(phi)
+        vals = np.array(self._values_rel_host(rcos, rsin), dtype=np.float64)
+        mask = self._mask_host(rcos - self.pos[0], rsin - self.pos[1])
+        vals[~mask] = np.nan
+        xv, yv, vals2 = self.edge(3001)
+        vals2 = vals2 - self.pos[2]
+        mask = self._mask_host(xv, yv)
+        vals2[~mask] = np.nan
+        return float(min(np.nanmin(vals), np.nanmin(vals2))), float(max(np.nanmax(vals), np.nanmax(vals2)))
+
+    def _call(self, x, y, **kwargs):
+        if self._1D:
+            return self._interp(np.hypot(x, y), **kwargs)
+        return self._interp(x, y, grid=False, **kwargs)
+
+    def _values_rel_host(self, x, y):
+        x_, y_ = self._rotate_rc(x, y, -self._angle) if not self.rotational_symmetry else (x, y)
+        return self._sign * (self._call(x_, self._sign * y_) - self._offset)
+
+    def flip(self) -> None:
+        self._lock = False
+        self._sign *= -1
+        self.parax_roc = self.parax_roc if self.parax_roc is None else -self.parax_roc
+        a = self.pos[2] - (self.z_max - self.pos[2])
+        b = self.pos[2] - (self.z_min - self.pos[2])
+        self.z_min, self.z_max = a, b
+        self.lock()
+
+    def rotate(self, angle: float) -> None:
+        if not self.rotational_symmetry:
+            self._lock = False
+            self._angle += np.deg2rad(angle)
+            self.lock()
+
+    def _desc(self):
+        d = super()._desc()
+        d.sign, d.offset, d.angle = float(self._sign), float(self._offset), float(self._angle)
+        d.tab = self._tab.ctypes.data_as(_capi.C.POINTER(_capi.C.c_double))  # kept alive by this surface
+        d.tab_len, d.nknots = int(self._tab.shape[0]), int(self._nknots)
+        return d
+
+
+class DataSurface1D(DataSurface2D):
+    """Rotationally symmetric surface from an equi-spaced radial profile 0..r (data_surface_1d.py:6-30)."""
+
+    rotational_symmetry = True
+    _1D = True
+    _kind = _capi.SURF_DATA1D
+
+    def __init__(self, r: float, data: np.ndarray, parax_roc: float = None, **kwargs) -> None:
+        self._lock = False
+        super().__init__(r=r, data=data, parax_roc=parax_roc, **kwargs)
+
+
+# ---- function surfaces -------------------------------------------------------------------------------------------
+class FunctionSurface2D(DataSurface2D):
+    """Surface defined by a Python callable z = func(x, y) (function_surface_2d.py:12-309), carried on the
+    device as a quartic spline of `N_SAMPLES` x `N_SAMPLES` samples taken at construction.
+
+    Differences to the reference, which calls the Python function for every ray:
+    * values and normals come from the spline; the residual against `func` on a staggered grid inside the disc
+      is measured at construction and a warning is raised above `TAB_TOL` (relative to r);
+    * `deriv_func` is used only for that check -- normals are the spline's analytic derivative;
+    * samples outside the disc (the square's corners) are filled by a quadratic radial continuation from the
+      edge, so `func` is never evaluated outside r;
+    * `mask_func` is not supported on the device.
+    """
+
+    N_SAMPLES: tuple = (401, 801, 1601)
+    """samples per dimension of the tabulation grid (2D): densities are tried in turn until the residual
+    meets TAB_TOL (smooth surfaces keep small tables that stay in L2)"""
+    N_SAMPLES_1D: int = 4001  #: samples of the radial profile (1D)
+    TAB_TOL: float = 1e-9  #: accepted spline residual relative to r
+    GRAD_TOL: float = 2e-9  #: accepted residual of the spline gradient (2D; against central differences of func)
+
+    rotational_symmetry = False
+    _1D = False
+    _kind = _capi.SURF_DATA2D
+
+    def __init__(self, r: float, func: Callable, mask_func: Callable = None, deriv_func: Callable = None,
+                 func_args: dict = {}, mask_args: dict = {}, deriv_args: dict = {}, z_min: float = None,
+                 z_max: float = None, parax_roc: float = None, **kwargs) -> None:
+        self._lock = False
+        Surface.__init__(self, r, **kwargs)
+        self._sign = 1
+        self._angle = 0
+        self._interp, self._offset, self._tab = None, 0., None
+        self.func = func
+        self.mask_func = mask_func
+        self.deriv_func = deriv_func
+        self._func_args = func_args
+        self._mask_args = mask_args
+        self._deriv_args = deriv_args
+        self.parax_roc = parax_roc
+        if mask_func is not None:
+            raise NotImplementedError("mask_func is not supported by the device kernels; restrict the surface "
+                                      "with r or an aperture instead.")
+        self._f0 = self._eval_func(np.array([0.]), np.array([0.]))[0]  # the reference's _offset (centre value)
+        self._tabulate()
+        self._set_zmin_zmax(z_min, z_max)
+        self.lock()
+
+    # the user function in the surface's own frame, with the reference's return type checks
+    def _eval_func(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        if self._1D:
+            vals = self.func(np.sqrt(x ** 2 + y ** 2), **self._func_args)
+        else:
+            vals = self.func(x, y, **self._func_args)
+        if not isinstance(vals, np.ndarray):
+            raise RuntimeError(f"func must return a np.ndarray, but returns type {type(vals)}.")
+        if vals.shape[0] and not isinstance(vals[0], np.float64):
+            raise RuntimeError("Elements of return value of func must be of type np.float64")
+        return vals
+
+    def _values_rel_host(self, x, y):
+        """Set-up helper (z range, geometry checks): the function itself, as the reference evaluates it
+        (function_surface_2d.py:133-156)."""
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        if self._1D:
+            vals = self._eval_func(x, y)
+        else:
+            x_, y_ = self._rotate_rc(x, y, -self._angle)
+            vals = self._eval_func(x_, self._sign * y_)
+        return self._sign * (vals - self._f0)
+
+    def _tabulate(self) -> None:
+        R = self.r
+        if self._1D:
+            n = self.N_SAMPLES_1D
+            r0 = np.linspace(0, R, n)
+            Z = self._eval_func(r0, np.zeros_like(r0)) - self._f0
+            r2 = np.concatenate((-np.flip(r0[1:]), r0))
+            z2 = np.concatenate((np.flip(Z[1:]), Z))
+            self._interp = scipy.interpolate.InterpolatedUnivariateSpline(r2, z2, k=_K)
+            self._tab, self._nknots = _table_1d(self._interp)
+            # residual at the interval midpoints
+            rm = (r0[1:] + r0[:-1]) / 2
+            res = np.abs(self._interp(rm) - (self._eval_func(rm, np.zeros_like(rm)) - self._f0))
+            self._finish_tabulation(res)
+            return
+        for n in self.N_SAMPLES:
+            res, gres = self._tabulate_2d(n)
+            if res.size == 0 or (res.max() <= self.TAB_TOL * R and gres <= self.GRAD_TOL):
+                break
+        self._grad_residual = gres
+        self._finish_tabulation(res)
+
+    def _tabulate_2d(self, n: int) -> np.ndarray:
+        """Fit the quartic spline to n x n samples; returns the residuals at the cell centres inside the disc
+        and the largest gradient residual there (central differences of func, step as in surface.py:262-266)."""
+        R = self.r
+        xy = np.linspace(-R, R, n)
+        X, Y = np.meshgrid(xy, xy, indexing="ij")
+        rr = np.hypot(X, Y)
+        inside = rr <= R
+        Z = np.zeros_like(X)
+        Z[inside] = self._eval_func(X[inside], Y[inside]) - self._f0
+        # corners of the square (never touched by the reference): the function itself where it is defined there,
+        # otherwise a quadratic radial continuation from three points at the edge
+        out = ~inside
+        if np.any(out):
+            try:
+                with np.errstate(all="ignore"):
+                    Z[out] = self._eval_func(X[out], Y[out]) - self._f0
+            except Exception:
+                Z[out] = np.nan
+            bad = out & ~np.isfinite(Z)
+            if np.any(bad):
+                ux, uy, d = X[bad] / rr[bad], Y[bad] / rr[bad], rr[bad] - R
+                h = R / (n - 1)
+                f0 = self._eval_func(ux * R, uy * R) - self._f0
+                f1 = self._eval_func(ux * (R - h), uy * (R - h)) - self._f0
+                f2 = self._eval_func(ux * (R - 2 * h), uy * (R - 2 * h)) - self._f0
+                d1 = (3 * f0 - 4 * f1 + f2) / (2 * h)
+                d2 = (f0 - 2 * f1 + f2) / h ** 2
+                Z[bad] = f0 + d1 * d + d2 / 2 * d ** 2
+        self._interp = scipy.interpolate.RectBivariateSpline(xy, xy, Z, kx=_K, ky=_K)
+        self._tab, self._nknots = _table_2d(self._interp)
+        xm = (xy[1:] + xy[:-1]) / 2
+        Xm, Ym = np.meshgrid(xm, xm, indexing="ij")
+        sel = np.hypot(Xm, Ym) <= R
+        xs, ys = Xm[sel], Ym[sel]
+        res = np.abs(self._interp(xs, ys, grid=False) - (self._eval_func(xs, ys) - self._f0))
+        keep = np.hypot(xs, ys) <= R - 2 * h_c if (h_c := R / (n - 1)) else slice(None)
+        xs, ys = xs[keep][::7], ys[keep][::7]  # a subset is enough for the gradient
+        eps = (3 * np.finfo(np.float64).eps * 50) ** (1 / 3)
+        gx = (self._eval_func(xs + eps, ys) - self._eval_func(xs - eps, ys)) / (2 * eps)
+        gy = (self._eval_func(xs, ys + eps) - self._eval_func(xs, ys - eps)) / (2 * eps)
+        gres = max(np.abs(self._interp(xs, ys, dx=1, grid=False) - gx).max(initial=0.),
+                   np.abs(self._interp(xs, ys, dy=1, grid=False) - gy).max(initial=0.))
+        return res, float(gres)
+
+    def _finish_tabulation(self, res: np.ndarray) -> None:
+        R = self.r
+        self._offset = 0.  # the samples already have the centre value removed
+        self._tab_residual = float(res.max()) if res.size else 0.
+        if self._tab_residual > self.TAB_TOL * R:
+            warning(f"{type(self).__name__}: the spline tabulation of func deviates by up to "
+                    f"{self._tab_residual:.3g} mm from the function; raise N_SAMPLES or smooth the function.")
+
+    def _set_zmin_zmax(self, z_min: float, z_max: float) -> None:
+        """z range: measured from the tabulated surface, or the user's values if plausible
+        (function_surface_2d.py:76-128)."""
+        if self._1D:
+            rn = np.linspace(0, self.r, 10000)
+            zn = self._values_rel_host(rn, np.zeros_like(rn))
+            self.z_min, self.z_max = float(zn.min()), float(zn.max())
+        else:
+            self.z_min, self.z_max = self._find_bounds()
+        surf_name = f"{type(self).__name__} {self.get_desc(hex(id(self)))}"
+        off = self._f0
+        if z_max is not None and z_min is not None:
+            z_range_probed = self.z_max - self.z_min
+            z_range_provided = z_max - z_min
+            if z_range_probed and z_range_provided + self.N_EPS < z_range_probed:
+                warning(f"{surf_name}: Provided a z-extent of {z_range_provided},"
+                        f"but measured range is at least {z_range_probed}, an increase of at "
+                        f"least {100*(z_range_probed - z_range_provided)/z_range_probed:.5g}."
+                        f" I will use the measured values for now.")
+            else:
+                range_factor = 1.2
+                if z_range_provided > range_factor * z_range_probed:
+                    warning(f"{surf_name}: Provided z-range is more than {(range_factor-1)*100:.5g}% "
+                            f"larger than measured z-range")
+                z_max_, z_min_ = self.z_max + off, self.z_min + off
+                if z_max + self.N_EPS < z_max_:
+                    warning(f"{surf_name}: Provided z_max={z_max} lower than measured value of {z_max_}."
+                            f" Using the measured values for now")
+                elif z_min - self.N_EPS > z_min_:
+                    warning(f"{surf_name}: Provided z_min={z_min} higher than measured value of {z_min_}."
+                            f" Using the measured values for now")
+                else:
+                    self.z_min, self.z_max = z_min - off, z_max - off
+        elif z_max is None and z_min is None:
+            warning(f"Estimated z-bounds of {surf_name}: [{off+self.z_min:.9g}, "
+                    f"{off+self.z_max:.9g}], provide actual values for higher precision.")
+        else:
+            raise ValueError("z_max and z_min need to be both None or both need a value")
+
+    def rotate(self, angle: float) -> None:
+        if not self._1D:
+            self._lock = False
+            self._angle += np.deg2rad(angle)
+            self.lock()
+
+    def _desc(self):
+        d = super()._desc()
+        if self.deriv_func is not None and not self._1D:
+            # the reference calls deriv_func at the unrotated coordinates (function_surface_2d.py:235)
+            d.flags |= _capi.SURF_FLAG_DERIV_UNROTATED
+        return d
+
+    def __setattr__(self, key: str, val: Any) -> None:
+        if key in ("z_max", "z_min"):
+            check_type(key, val, (float, int))
+            val = float(val)
+        elif key in ("deriv_func", "mask_func"):
+            if val is not None and not callable(val):
+                raise TypeError(f"{key} needs to be callable or None.")
+        elif key == "func":
+            if not callable(val):
+                raise TypeError("func needs to be callable.")
+        elif key in ("_deriv_args", "_func_args", "_mask_args"):
+            check_type(key, val, dict)
+            Surface.__setattr__(self, key, copy.deepcopy(val))
+            return
+        super().__setattr__(key, val)
+
+
+class FunctionSurface1D(FunctionSurface2D):
+    """Rotationally symmetric surface z = func(r) (function_surface_1d.py:8-50), tabulated like FunctionSurface2D."""
+
+    rotational_symmetry = True
+    _1D = True
+    _kind = _capi.SURF_DATA1D

@@ -127,7 +127,7 @@ class Surface(BaseClass):
         from .. import ops
         p_hit, is_hit, ill = ops.surface_find_hit(self._desc(), p, s)
         w = where if where is not None else slice(None)
-        numeric = not self.is_flat() and self._kind == _capi.SURF_ASPHERE
+        numeric = not self.is_flat() and self._kind >= _capi.SURF_ASPHERE
         return p_hit[w], is_hit[w], (ill[w] if numeric else np.array([]))
 
     def normals(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:

@@ -89,7 +89,7 @@ int orc_mask1(const ot_surface* sf, double x, double y) {
             int inside = (xsi + N_EPS <= xr) && (xr <= xei - N_EPS) && (ysi + N_EPS <= yr) && (yr <= yei - N_EPS);
             return outer && !inside;
         }
-        default: { /* CIRCLE, CONIC, ASPHERE */
+        default: { /* CIRCLE, CONIC, ASPHERE, TILTED, DATA1D, DATA2D */
             double dx = x - sf->pos[0], dy = y - sf->pos[1];
             return dx * dx + dy * dy <= pow(sf->r + N_EPS, 2.0);
         }
@@ -121,10 +121,130 @@ static double asph_poly_deriv(const ot_surface* sf, double r) {
     return y;
 }
 
+/* ---- FITPACK B-spline evaluation as SciPy runs it for DataSurface1D/2D (data_surface_2d.py:72,101,126-135):
+ * InterpolatedUnivariateSpline.__call__ -> splev.f / splder.f, RectBivariateSpline.__call__(grid=False) ->
+ * bispeu.f / pardeu.f -> fpbisp.f, all on top of fpbspl.f.  FITPACK (netlib dierckx, as vendored by SciPy
+ * 1.15.3) is not part of /root/reference; its published algorithms are restated here with 1-based indices
+ * written as t[i - 1].  Table layout: include/optrace_amd.h (ot_surface.tab). */
+
+/* fpbspl.f: the k+1 non-zero B-splines of degree k at x in knot interval l (t(l) <= x < t(l+1)) */
+static void fpbspl(const double* t, int k, double x, int l, double* h) {
+    double hh[8];
+    h[0] = 1.0;
+    for (int j = 1; j <= k; j++) {
+        for (int i = 1; i <= j; i++) hh[i - 1] = h[i - 1];
+        h[0] = 0.0;
+        for (int i = 1; i <= j; i++) {
+            int li = l + i, lj = li - j;
+            if (t[li - 1] == t[lj - 1]) {
+                h[i] = 0.0;
+                continue;
+            }
+            double f = hh[i - 1] / (t[li - 1] - t[lj - 1]);
+            h[i - 1] = h[i - 1] + f * (t[li - 1] - x);
+            h[i] = f * (x - t[lj - 1]);
+        }
+    }
+}
+
+/* splev.f (der = 0: kk = k, coefficients c) / splder.f (der = 1: kk = k - 1, coefficients wrk); ext = 0 */
+static double splev1(const double* t, int n, const double* c, int k, int kk, double arg) {
+    int k1 = k + 1, k2 = k1 + 1, nk1 = n - k1;
+    int l = k1, l1 = l + 1;
+    while (!(arg >= t[l - 1] || l1 == k2)) {
+        l1 = l;
+        l = l - 1;
+    }
+    while (!(arg < t[l1 - 1] || l == nk1)) {
+        l = l1;
+        l1 = l + 1;
+    }
+    double h[8];
+    fpbspl(t, kk, arg, l, h);
+    double sp = 0.0;
+    int ll = l - k1;
+    for (int j = 1; j <= kk + 1; j++) {
+        ll = ll + 1;
+        sp = sp + c[ll - 1] * h[j - 1];
+    }
+    return sp;
+}
+
+/* fpbisp.f for a single point (mx = my = 1) */
+static double fpbisp1(const double* tx, int nx, const double* ty, int ny, const double* c, int kx, int ky, double x,
+                      double y) {
+    double hx[8], hy[8];
+    int kx1 = kx + 1, nkx1 = nx - kx1;
+    double tb = tx[kx1 - 1], te = tx[nkx1];
+    int l = kx1, l1 = l + 1;
+    double arg = x;
+    if (arg < tb) arg = tb;
+    if (arg > te) arg = te;
+    while (!(arg < tx[l1 - 1] || l == nkx1)) {
+        l = l1;
+        l1 = l + 1;
+    }
+    fpbspl(tx, kx, arg, l, hx);
+    int lx = l - kx1;
+    int ky1 = ky + 1, nky1 = ny - ky1;
+    tb = ty[ky1 - 1];
+    te = ty[nky1];
+    l = ky1;
+    l1 = l + 1;
+    arg = y;
+    if (arg < tb) arg = tb;
+    if (arg > te) arg = te;
+    while (!(arg < ty[l1 - 1] || l == nky1)) {
+        l = l1;
+        l1 = l + 1;
+    }
+    fpbspl(ty, ky, arg, l, hy);
+    int ly = l - ky1;
+    double sp = 0.0;
+    int l1c = lx * nky1 + ly;
+    for (int i1 = 1; i1 <= kx1; i1++) {
+        int l2 = l1c;
+        for (int j1 = 1; j1 <= ky1; j1++) {
+            l2 = l2 + 1;
+            sp = sp + c[l2 - 1] * hx[i1 - 1] * hy[j1 - 1];
+        }
+        l1c = l1c + nky1;
+    }
+    return sp;
+}
+
+/* DataSurface2D._call data_surface_2d.py:126-135 with optional derivative (dx, dy) / nu */
+static double data_call(const ot_surface* sf, double x, double y, int dx, int dy) {
+    const double* t = sf->tab;
+    int n = sf->nknots, k = OT_SPL_K;
+    if (sf->kind == OT_SURF_DATA1D) {
+        double r = hypot(x, y);
+        if (dx) return splev1(t, n, t + 2 * n, k, k - 1, r); /* nu = 1 */
+        return splev1(t, n, t + n, k, k, r);
+    }
+    int nc = n - k - 1;
+    const double* c = t + n;
+    if (dx) return fpbisp1(t + 1, n - 2, t, n, c + nc * nc, k - 1, k, x, y);                 /* pardeu nux = 1 */
+    if (dy) return fpbisp1(t, n, t + 1, n - 2, c + nc * nc + (nc - 1) * nc, k, k - 1, x, y); /* pardeu nuy = 1 */
+    return fpbisp1(t, n, t, n, c, k, k, x, y);
+}
+
 /* Surface._values in coordinates relative to the centre:
  * ConicSurface._values conic_surface.py:57-68; AsphericSurface._asph aspheric_surface.py:51-65 through
  * FunctionSurface2D._values function_surface_2d.py:133-156 (1D branch, _sign = 1, _offset = 0) */
 static double surf_values_rel(const ot_surface* sf, double x, double y) {
+    if (sf->kind == OT_SURF_TILTED) { /* TiltedSurface._values tilted_surface.py:60-73 */
+        double mx = -sf->normal[0] / sf->normal[2];
+        double my = -sf->normal[1] / sf->normal[2];
+        return x * mx + y * my;
+    }
+    if (sf->kind == OT_SURF_DATA1D) /* DataSurface2D._values data_surface_2d.py:137-151, rotational symmetry */
+        return sf->sign * (data_call(sf, x, y, 0, 0) - sf->offset);
+    if (sf->kind == OT_SURF_DATA2D) {
+        double x_, y_;
+        rotate_rc(x, y, -sf->angle, &x_, &y_);
+        return sf->sign * (data_call(sf, x_, sf->sign * y_, 0, 0) - sf->offset);
+    }
     double rho = 1 / sf->R, k = sf->k;
     if (sf->kind == OT_SURF_CONIC) {
         double r2 = x * x + y * y;
@@ -143,8 +263,12 @@ static double surf_values_rel(const ot_surface* sf, double x, double y) {
 double orc_values1(const ot_surface* sf, double x, double y) {
     if (surf_is_flat(sf)) return sf->z_max;
     if (orc_mask1(sf, x, y)) return sf->pos[2] + surf_values_rel(sf, x - sf->pos[0], y - sf->pos[1]);
-    /* rotationally symmetric surfaces only (CONIC / ASPHERE): constant edge value, surface.py:162 */
+    /* outside the mask the edge value is continued radially, surface.py:153-162 */
     double r = sf->r - N_EPS;
+    if (sf->kind == OT_SURF_TILTED || sf->kind == OT_SURF_DATA2D) { /* rotational_symmetry == False */
+        double phi = atan2(y - sf->pos[1], x - sf->pos[0]);
+        return sf->pos[2] + surf_values_rel(sf, r * cos(phi), r * sin(phi));
+    }
     return sf->pos[2] + surf_values_rel(sf, r, 0.0);
 }
 
@@ -155,6 +279,37 @@ void orc_normals1(const ot_surface* sf, double x, double y, double n[3]) {
     n[0] = 0.0;
     n[1] = 0.0;
     n[2] = 1.0;
+    if (sf->kind == OT_SURF_TILTED) { /* TiltedSurface.normals tilted_surface.py:75-89 */
+        if (orc_mask1(sf, x, y))
+            for (int c = 0; c < 3; c++) n[c] = sf->normal[c];
+        return;
+    }
+    if (sf->kind == OT_SURF_DATA1D || sf->kind == OT_SURF_DATA2D) { /* DataSurface2D.normals :153-196 */
+        if (!orc_mask1(sf, x, y)) return;
+        double xm = x - sf->pos[0], ym = y - sf->pos[1];
+        double nxn, nyn;
+        if (sf->kind == OT_SURF_DATA2D) {
+            double x_, y_, a, b;
+            rotate_rc(xm, ym, -sf->angle, &x_, &y_);
+            if (sf->flags & OT_SURF_FLAG_DERIV_UNROTATED) { /* function_surface_2d.py:235: deriv_func(xm, sign*ym) */
+                x_ = xm;
+                y_ = ym;
+            }
+            a = data_call(sf, x_, sf->sign * y_, 1, 0) * sf->sign;
+            b = data_call(sf, x_, sf->sign * y_, 0, 1);
+            rotate_rc(a, b, sf->angle, &nxn, &nyn);
+        } else {
+            double phi = atan2(ym, xm);
+            double nr = sf->sign * data_call(sf, xm, ym, 1, 0);
+            nxn = nr * cos(phi);
+            nyn = nr * sin(phi);
+        }
+        n[0] = -nxn;
+        n[1] = -nyn;
+        n[2] = 1.0;
+        normalize3(n);
+        return;
+    }
     if (sf->kind != OT_SURF_CONIC && sf->kind != OT_SURF_ASPHERE) return;
     if (sf->kind == OT_SURF_ASPHERE && surf_is_flat(sf)) return;
 
@@ -265,7 +420,29 @@ static void find_hit_conic(const ot_surface* sf, const double p[3], const double
 
 /* Surface.find_hit surface.py:307-414: flat branch :319-327, Illinois regula falsi :329-414.
  * Returns 0, or -1 if the iteration timed out (reference raises TimeoutError, surface.py:403). */
+static int find_hit_generic(const ot_surface* sf, const double p[3], const double s[3], double ph[3], int* is_hit,
+                            int* ill);
+
+/* dispatch: ConicSurface.find_hit, TiltedSurface.find_hit tilted_surface.py:91-123, Surface.find_hit */
 int orc_find_hit1(const ot_surface* sf, const double p[3], const double s[3], double ph[3], int* is_hit, int* ill) {
+    if (sf->kind == OT_SURF_TILTED && !surf_is_flat(sf)) {
+        *ill = 0;
+        double t_denom = rdot3(s, sf->normal);
+        int nz = t_denom != 0;
+        double d[3] = {sf->pos[0] - p[0], sf->pos[1] - p[1], sf->pos[2] - p[2]};
+        double t = rdot3(d, sf->normal) / (nz ? t_denom : 1e-12);
+        for (int c = 0; c < 3; c++) ph[c] = p[c] + s[c] * t;
+        *is_hit = orc_mask1(sf, ph[0], ph[1]) && nz;
+        int status = 0;
+        if (!*is_hit) status = find_hit_generic(sf, p, s, ph, is_hit, ill); /* edge continued radially */
+        handle_abnormal(sf, p, s, ph, is_hit);
+        return status;
+    }
+    return find_hit_generic(sf, p, s, ph, is_hit, ill);
+}
+
+static int find_hit_generic(const ot_surface* sf, const double p[3], const double s[3], double ph[3], int* is_hit,
+                            int* ill) {
     *ill = 0;
     if (sf->kind == OT_SURF_CONIC) {
         find_hit_conic(sf, p, s, ph, is_hit);

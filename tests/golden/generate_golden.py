@@ -46,10 +46,11 @@ def surface_params(s) -> dict:
     return d
 
 
-def gen_leaf_surfaces():
-    rng = np.random.default_rng(1234)
+def gen_leaf_surfaces(which: int = 1):
+    rng = np.random.default_rng(1234 if which == 1 else 4321)
     out = {}
-    zoo = scenes.surface_zoo(ot)
+    with ot.global_options.no_warnings():
+        zoo = scenes.surface_zoo(ot) if which == 1 else scenes.surface_zoo2(ot)
     for name, sf in zoo.items():
         n = 1500
         ext = np.array(sf.extent)
@@ -92,8 +93,9 @@ def gen_leaf_surfaces():
         for k, v in surface_params(sf).items():
             out[f"{name}/param/{k}"] = v
     out["names"] = np.array(list(zoo.keys()))
-    np.savez_compressed(HERE / "leaf_surfaces.npz", **out)
-    print("leaf_surfaces.npz", len(out))
+    fname = "leaf_surfaces.npz" if which == 1 else "leaf_surfaces2.npz"
+    np.savez_compressed(HERE / fname, **out)
+    print(fname, len(out))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -183,6 +185,7 @@ def trace_recorded(builder, N: int, seed: int, **rt_args):
 TRACE_CASES = {name: (builder, N, 100 + j, {}) for j, (name, (builder, N)) in enumerate(scenes.SCENES.items())}
 TRACE_CASES["double_gauss_nopol"] = (scenes.double_gauss, 1200, 300, dict(no_pol=True))
 TRACE_CASES["asphere_nopol"] = (scenes.asphere_scene, 1500, 301, dict(no_pol=True))
+TRACE_CASES2 = {name: (builder, N, 500 + j, {}) for j, (name, (builder, N)) in enumerate(scenes.SCENES2.items())}
 
 
 def gen_trace(name: str, builder, N: int, seed: int, **rt_args):
@@ -444,13 +447,18 @@ def gen_render_image_file():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["leaf", "media", "trace", "sources", "images", "spectra", "focus", "file"]
+    which = sys.argv[1:] or ["leaf", "leaf2", "media", "trace", "trace2", "sources", "images", "spectra", "focus", "file"]
     if "leaf" in which:
         gen_leaf_surfaces()
+    if "leaf2" in which:
+        gen_leaf_surfaces(2)
     if "media" in which:
         gen_leaf_media()
     if "trace" in which:
         for name, (builder, N, seed, rt_args) in TRACE_CASES.items():
+            gen_trace(name, builder, N, seed=seed, **rt_args)
+    if "trace2" in which:
+        for name, (builder, N, seed, rt_args) in TRACE_CASES2.items():
             gen_trace(name, builder, N, seed=seed, **rt_args)
     if "sources" in which:
         gen_sources()

@@ -146,6 +146,62 @@ def asphere_scene(ot, **rt_args):
     return RT
 
 
+def prism_scene(ot, **rt_args):
+    """Geometry of examples/prism.py:16-36: thin D65 beam through a prism made of two tilted circles
+    (N-LAK8 as Sellmeier1 coefficients), flat detector."""
+    n = ot.RefractionIndex("Sellmeier1", coeff=[1.33183167, 0.00620023871, 0.546623206, 0.0216465439,
+                                                1.19084015, 82.5827736])
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, -5, 25], **rt_args)
+    RT.add(ot.RaySource(ot.CircularSurface(r=0.05), divergence="None", spectrum=ot.presets.light_spectrum.d65,
+                        pos=[0, -2.5, 0], s=[0, 0.3, 0.7]))
+    front = ot.TiltedSurface(r=3, normal=[0, -0.45, np.sqrt(1 - 0.45 ** 2)])
+    back = front.copy()
+    back.rotate(180)
+    RT.add(ot.Lens(front, back, de=0.5, pos=[0, 0, 10], n=n))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[10, 10]), pos=[0, 0, 20]))
+    return RT
+
+
+def _cosine_surface(x, y):
+    return 0.1 * np.cos(2 * np.pi * x / 2)
+
+
+def freeform_scene(ot, **rt_args):
+    """Function, data and tilted surfaces in one beam path: the cosine-modulated lens of
+    examples/cosine_surfaces.py:20-32 (FunctionSurface2D, back side flipped and rotated by 90 deg), a lens
+    from a 1-D data profile against a 2-D data grid, a tilted window and an ideal lens."""
+    RT = ot.Raytracer(outline=[-15, 15, -15, 15, 0, 80], **rt_args)
+    RT.add(ot.RaySource(ot.CircularSurface(r=3), divergence="None", s=[0, 0, 1], pos=[0, 0, 0],
+                        spectrum=ot.LightSpectrum("Rectangle", wl0=450., wl1=650.)))
+    front = ot.FunctionSurface2D(func=_cosine_surface, r=5)
+    back = front.copy()
+    back.flip()
+    back.rotate(90)
+    nL1 = ot.RefractionIndex("Sellmeier1", coeff=[1.52481889, 0.011254756, 0.187085527, 0.0588995392,
+                                                  1.42729015, 129.141675])
+    RT.add(ot.Lens(front, back, de=2, pos=[0, 0, 12], n=nL1))
+    r = np.linspace(0, 6.0, 400)
+    d1 = ot.DataSurface1D(r=6.0, data=25 - np.sqrt(625 - r ** 2))
+    xy = np.linspace(-6.0, 6.0, 240)
+    X, Y = np.meshgrid(xy, xy)
+    d2 = ot.DataSurface2D(r=6.0, data=-(X ** 2 / 60 + Y ** 2 / 45) + 0.01 * np.sin(X) * np.cos(0.7 * Y))
+    d2.rotate(30)
+    RT.add(ot.Lens(d1, d2, de=0.4, pos=[0, 0, 20], n=ot.RefractionIndex("Constant", n=1.55)))
+    t1 = ot.TiltedSurface(r=7, normal_sph=[8., 35.])
+    t2 = ot.TiltedSurface(r=7, normal_sph=[5., 200.])
+    RT.add(ot.Lens(t1, t2, de=0.3, pos=[0, 0, 30], n=ot.RefractionIndex("Cauchy", coeff=[1.49, 0.00354, 0, 0])))
+    RT.add(ot.IdealLens(r=9, D=50, pos=[0, 0, 40]))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[14, 14]), pos=[0, 0, 24.4]))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[14, 14]), pos=[0, 0, 60]))
+    return RT
+
+
+SCENES2 = {  # SURVEY 8f rank 4 surfaces; kept apart from SCENES so that the seeds of the older fixtures stay put
+    "prism": (prism_scene, 2000),
+    "freeform": (freeform_scene, 2500),
+}
+
+
 SCENES = {
     "c1_single_lens": (c1_single_lens, 2000),
     "double_gauss": (double_gauss, 1500),
@@ -178,6 +234,49 @@ def surface_zoo(ot):
     z["conic_parab"] = ot.ConicSurface(r=3.0, R=6.0, k=-1.0)
     z["asphere_a"] = ot.AsphericSurface(r=4, R=12, k=-0.8, coeff=[2e-3, -4e-5, 3e-7])
     z["asphere_b"] = ot.AsphericSurface(r=3, R=-15, k=0.3, coeff=[-1e-3, 2e-5])
+    for j, (name, s) in enumerate(z.items()):
+        s.move_to([0.1 * j - 0.5, 0.3 - 0.07 * j, 2.0 + 0.5 * j])
+    return z
+
+
+def _func2d(x, y, a=10.):
+    return (x ** 2 + y ** 2 / 3) / a + 0.05 * np.cos(x)
+
+
+def _func2d_deriv(x, y, a=10.):
+    return 2 * x / a - 0.05 * np.sin(x), 2 * y / 3 / a
+
+
+def surface_zoo2(ot):
+    """Tilted, data and function surfaces; same role as surface_zoo."""
+    z = {}
+    z["tilted"] = ot.TiltedSurface(r=3.0, normal=[0, -0.45, np.sqrt(1 - 0.45 ** 2)])
+    t2 = ot.TiltedSurface(r=2.0, normal_sph=[20., 70.])
+    t2.rotate(15.0)
+    t2.flip()
+    z["tilted_sph"] = t2
+    r = np.linspace(0, 3.0, 220)
+    z["data1d"] = ot.DataSurface1D(r=3.0, data=10 - np.sqrt(100 - r ** 2))
+    d1f = ot.DataSurface1D(r=2.0, data=0.02 * np.linspace(0, 2.0, 300) ** 3 + 1.0)
+    d1f.flip()
+    z["data1d_flip"] = d1f
+    xy = np.linspace(-2.5, 2.5, 120)
+    X, Y = np.meshgrid(xy, xy)
+    z["data2d"] = ot.DataSurface2D(r=2.5, data=X ** 2 / 20 + Y ** 2 / 14 + 0.02 * np.sin(2 * X))
+    xy = np.linspace(-2.0, 2.0, 101)
+    X, Y = np.meshgrid(xy, xy)
+    d2 = ot.DataSurface2D(r=2.0, data=0.3 - (X - 0.3) ** 2 / 9 - Y ** 2 / 30 + 0.01 * X * Y)
+    d2.rotate(25.0)
+    d2.flip()
+    z["data2d_rot_flip"] = d2
+    z["func1d"] = ot.FunctionSurface1D(r=3.0, func=lambda r: r ** 2 / 16 + 0.001 * r ** 4,
+                                       deriv_func=lambda r: r / 8 + 0.004 * r ** 3)
+    z["func2d"] = ot.FunctionSurface2D(r=3.0, func=_func2d, deriv_func=_func2d_deriv)
+    f2 = ot.FunctionSurface2D(r=2.5, func=_func2d, func_args=dict(a=7.), deriv_func=_func2d_deriv,
+                              deriv_args=dict(a=7.), z_min=0.05, z_max=0.05 + 1.0)
+    f2.rotate(-40.0)
+    z["func2d_rot"] = f2
+    z["func2d_noderiv"] = ot.FunctionSurface2D(r=2.0, func=lambda x, y: 0.1 * np.sin(x) * y + x ** 2 / 12)
     for j, (name, s) in enumerate(z.items()):
         s.move_to([0.1 * j - 0.5, 0.3 - 0.07 * j, 2.0 + 0.5 * j])
     return z

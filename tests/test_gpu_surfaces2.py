@@ -1,0 +1,95 @@
+"""GPU parity of the tilted / data / function surfaces: leaf operators against the reference's
+fixtures (tests/golden/leaf_surfaces2.npz) and the oracle, scene traces in test_gpu_parity (prism, freeform)."""
+import numpy as np
+import pytest
+
+import optrace_amd as ot
+
+import oracle_bridge as ob
+import scenes
+from helpers import load, assert_close
+from test_gpu_parity import gpu_trace
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["tilted", "tilted_sph", "data1d", "data1d_flip", "data2d", "data2d_rot_flip", "func1d", "func2d",
+         "func2d_rot", "func2d_noderiv"]
+EXACT = [n for n in NAMES if not n.startswith("func")]
+
+
+@pytest.fixture(scope="module")
+def zoo():
+    with ot.global_options.no_warnings():
+        return scenes.surface_zoo2(ot)
+
+
+@pytest.fixture(scope="module")
+def leaf():
+    return load("leaf_surfaces2.npz")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_find_hit(zoo, leaf, name):
+    sf = zoo[name]
+    ph, hit, ill = sf.find_hit(leaf[f"{name}/p"], leaf[f"{name}/s"])
+    ph_o, hit_o, ill_o, st = ob.find_hit(sf._desc(), leaf[f"{name}/p"], leaf[f"{name}/s"])
+    assert st == 0
+    # device against the oracle: same tables, same algorithm
+    assert np.array_equal(hit, hit_o) and np.array_equal(ill, ill_o)
+    assert_close(ph, ph_o, rtol=1e-11, atol=1e-11, what=f"{name} p_hit vs oracle")
+    if name in EXACT:
+        assert np.array_equal(hit, leaf[f"{name}/is_hit"]), "hit mask must be bit-exact"
+        assert np.array_equal(ill, leaf[f"{name}/ill"])
+        assert_close(ph, leaf[f"{name}/p_hit"], rtol=1e-11, atol=1e-11, what=f"{name} p_hit")
+    else:
+        assert np.count_nonzero(hit != leaf[f"{name}/is_hit"]) <= 2
+        same = hit == leaf[f"{name}/is_hit"]
+        assert_close(ph[same], leaf[f"{name}/p_hit"][same], rtol=0, atol=2e-8, what=f"{name} p_hit")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_mask_values_normals(zoo, leaf, name):
+    sf = zoo[name]
+    x, y = leaf[f"{name}/x"], leaf[f"{name}/y"]
+    assert np.array_equal(sf.mask(x, y), leaf[f"{name}/mask"])
+    sd = sf._desc()
+    assert_close(sf.values(x, y), ob.values(sd, x, y), rtol=1e-13, atol=1e-14, what=f"{name} values vs oracle")
+    assert_close(sf.normals(x, y), ob.normals(sd, x, y), rtol=1e-11, atol=1e-13, what=f"{name} normals vs oracle")
+    if name in EXACT:
+        assert_close(sf.values(x, y), leaf[f"{name}/values"], rtol=1e-13, atol=1e-14, what=f"{name} values")
+        assert_close(sf.normals(x, y), leaf[f"{name}/normals"], rtol=1e-11, atol=1e-13, what=f"{name} normals")
+    else:
+        assert_close(sf.values(x, y), leaf[f"{name}/values"], rtol=0, atol=3e-9, what=f"{name} values")
+        atol = 1e-6 if name == "func2d_noderiv" else 2e-7
+        assert_close(sf.normals(x, y), leaf[f"{name}/normals"], rtol=0, atol=atol, what=f"{name} normals")
+
+
+@pytest.mark.parametrize("name", ["prism", "freeform"])
+def test_detector_images(name):
+    from helpers import sparse_to_dense, image_rel_l1
+    g, RT = gpu_trace(name)
+    with ot.global_options.no_warnings():
+        for di in range(len(RT.detectors)):
+            key = f"det{di}/None"
+            ph, hw, wl, ext, projection, ill = RT._hit_detector("x", di, None, None, None)
+            sel = hw.cpu().numpy() > 0
+            assert np.count_nonzero(sel) == g[f"{key}/w"].shape[0]
+            img = RT.detector_image(detector_index=di)
+            ref = sparse_to_dense(g, f"{key}/img")
+            pw = float(g[f"{key}/img/power"])
+            assert abs(img.power() - pw) <= 1e-6 * pw
+            assert_close(img.extent, g[f"{key}/img/extent"], rtol=1e-7, atol=1e-7, what="extent")
+            assert np.all(image_rel_l1(img._data, ref) < (2e-3 if name == "freeform" else 1e-4))
+
+
+def test_spline_tables_survive_scene_lifetime_and_large_bundle():
+    """1 M rays through the freeform scene: finite, energy conserving, and repeatable (tables live in the scene)."""
+    with ot.global_options.no_warnings():
+        RT = scenes.freeform_scene(ot, seed=5)
+        RT.trace(1_000_000)
+        w = RT.rays.w_list
+        assert np.all(np.isfinite(RT.rays.p_list)) and np.all(w[:, 1:] <= w[:, :-1] + 1e-12)
+        assert RT._msgs[RT.INFOS.ILL_COND].sum() < 1e-4 * RT.rays.N  # a few bracket failures at the data grid's rim
+        p1 = RT.rays.p_list[:1000].copy()
+        RT.trace(1_000_000)
+        assert np.array_equal(p1, RT.rays.p_list[:1000])
