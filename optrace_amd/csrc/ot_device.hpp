@@ -41,6 +41,24 @@ OT_DEV V3 normalize3(const V3& a) {  // misc.py:136 (zero vectors -> NaN)
     return r;
 }
 
+// sqrt for the three roots per ray-surface of the tracing loop (discriminant, normal z, refraction W).
+// Same rsq + Goldschmidt/Newton sequence the compiler emits for an IEEE f64 sqrt, minus its 2^+-256 range
+// scaling (5 of 17 instructions): bit-identical for 2^-767 <= x < 2^1023, and x = 0, inf, NaN, x < 0 behave
+// as sqrt does.  Arguments here are mm^2-scale or O(1) quantities.
+OT_DEV double ot_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x == 0.0 || x == __builtin_inf()) ? x : g;
+}
+
 OT_DEV V3 along(const V3& p, const V3& s, double t) {
     V3 r = {p.x + s.x * t, p.y + s.y * t, p.z + s.z * t};
     return r;
@@ -203,7 +221,7 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y) {
         if (sf.k == 0.0) {
             n.x = sf.nrho * dx;
             n.y = sf.nrho * dy;
-            n.z = sqrt(1 - sf.rho2 * (dx * dx) - sf.rho2 * (dy * dy));
+            n.z = ot_sqrt(1 - sf.rho2 * (dx * dx) - sf.rho2 * (dy * dy));
             return n;
         }
         double r = sqrt(dx * dx + dy * dy);
@@ -252,12 +270,12 @@ OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) 
     double C = oy * oy + ox * ox + oz * (ozk - sf.two_inv_rho);
     double A = 1.0, D, t1, t2;
     if (sphere) {  // A = 1.0: C * 1.0 == C and x / 1.0 == x exactly, so both are skipped
-        D = sqrt(B * B - C);
+        D = ot_sqrt(B * B - C);
         t1 = -B - D;
         t2 = -B + D;
     } else {
         A = 1 + sf.k * (s.z * s.z);
-        D = sqrt(B * B - C * A);
+        D = ot_sqrt(B * B - C * A);
         t1 = (-B - D) / A;
         t2 = (-B + D) / A;
     }

@@ -156,7 +156,7 @@ OT_DEV bool refract(SF& sf, RayState& r, const V3& pn, float& wn, float& npx, fl
     V3 n = surf_normal<true, FULL>(sf, pn.x, pn.y);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
     V3 s = r.s;
     double ns = dot3(n, s);
-    double W = sqrt(1 - N * N * (1 - ns * ns));
+    double W = ot_sqrt(1 - N * N * (1 - ns * ns));
     double q = N * ns - W;
     V3 s_ = {s.x * N - n.x * q, s.y * N - n.y * q, s.z * N - n.z * q};
 
@@ -250,6 +250,8 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
 template <bool POL>
 OT_DEV void store_section(const ot_rays& R, uint32_t ray, int sec, const V3& p, float w, double n, float px, float py,
                           float pz) {
+    // (a workgroup-relative form -- SGPR base + threadIdx offset, no 64-bit vector address add -- was measured
+    // 4 % slower: 1.93 vs 1.86 ms on the bench scene)
     const int64_t N = R.N;
     const int64_t nt = R.nt;
     double* __restrict__ p0 = R.p + N * sec;
