@@ -472,6 +472,25 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
         tabs.insert(tabs.end(), p, p + n);
         return o;
     };
+    // inverse-CDF start hints (CdfGuide): int32 tables behind the double tables in the same blob
+    std::vector<int32_t> guides;
+    struct GuideRef { size_t off; CdfGuide* dst; };
+    std::vector<GuideRef> grefs;
+    auto add_guide = [&](const double* F, size_t n, double x0, CdfGuide* dst) {
+        const double x1 = F[n - 1];
+        size_t K = 16;
+        while (K < n && K < ((size_t)1 << 22)) K <<= 1;
+        dst->K = (int32_t)K;
+        dst->x0 = x0;
+        dst->scale = (x1 > x0) ? (double)K / (x1 - x0) : 0.0;
+        grefs.push_back({guides.size(), dst});
+        size_t j = 0;
+        for (size_t b = 0; b < K; b++) {
+            const double xb = x0 + (double)b / (dst->scale > 0 ? dst->scale : 1.0);
+            while (j + 1 < n && F[j + 1] <= xb) j++;
+            guides.push_back((int32_t)j);
+        }
+    };
     bool any_rgb = false;
     for (int i = 0; i < n_sources; i++) {
         const ot_source& s = sources[i];
@@ -489,6 +508,12 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
         std::memcpy(d.s, s.s, sizeof(d.s));
         std::memcpy(d.conv_pos, s.conv_pos, sizeof(d.conv_pos));
         d.pol_angle = s.pol_angle;
+        d.pol_cos = std::cos(s.pol_angle);
+        d.pol_sin = std::sin(s.pol_angle);
+        d.axis_cos = std::cos(d.div_axis);
+        d.axis_sin = std::sin(d.div_axis);
+        d.px_w = (s.img_w > 0) ? s.dim[0] / (double)s.img_w : 0.0;  // ray_source.py:252-253
+        d.px_h = (s.img_h > 0) ? s.dim[1] / (double)s.img_h : 0.0;
         d.wl = s.wl; d.wl0 = s.wl0; d.wl1 = s.wl1; d.mu = s.mu; d.sig = s.sig;
         d.power = s.power;
         if (s.spectrum == OT_SPEC_GAUSSIAN) {  // light_spectrum.py:117-118
@@ -501,16 +526,21 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             if (!s.spec_tab || s.n_spec < 1) return fail(OT_ERR_INVALID, "source: spectrum table missing");
             offs[i][0] = push(s.spec_tab, 2 * (size_t)s.n_spec);
             d.n_spec = s.n_spec;
+            const double* F = s.spec_tab + s.n_spec;
+            add_guide(F, (size_t)s.n_spec, s.spectrum == OT_SPEC_LINES ? 0.0 : F[0], &d.g_spec);
         }
         if (s.polarization == OT_POL_LIST || s.polarization == OT_POL_TABLE) {
             if (!s.pol_tab || s.n_pol < 1) return fail(OT_ERR_INVALID, "source: polarisation table missing");
             offs[i][1] = push(s.pol_tab, 2 * (size_t)s.n_pol);
             d.n_pol = s.n_pol;
+            const double* F = s.pol_tab + s.n_pol;
+            add_guide(F, (size_t)s.n_pol, s.polarization == OT_POL_LIST ? 0.0 : F[0], &d.g_pol);
         }
         if (s.divergence == OT_DIV_TABLE) {
             if (!s.div_tab || s.n_div < 2) return fail(OT_ERR_INVALID, "source: divergence table missing");
             offs[i][2] = push(s.div_tab, 2 * (size_t)s.n_div);
             d.n_div = s.n_div;
+            add_guide(s.div_tab + s.n_div, (size_t)s.n_div, s.div_tab[s.n_div], &d.g_div);
         }
         if (s.shape == OT_SRC_IMAGE_RGB || s.shape == OT_SRC_IMAGE_GRAY) {
             size_t npx = (size_t)s.img_w * (size_t)s.img_h;
@@ -522,6 +552,7 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
                 cdf[j] = acc;
             }
             offs[i][3] = push(cdf.data(), npx);
+            add_guide(cdf.data(), npx, 0.0, &d.g_img);
             if (s.shape == OT_SRC_IMAGE_RGB) {
                 if (!s.img_rgb) return fail(OT_ERR_INVALID, "RGB image source: pixel colours missing");
                 std::vector<double> mix(2 * npx);
@@ -555,13 +586,21 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             }
         }
         prim_off = push(prim.data(), prim.size());
+        for (int i = 0; i < n_sources; i++)
+            if (sources[i].shape == OT_SRC_IMAGE_RGB)
+                for (int c = 0; c < 3; c++) {
+                    const double* F = prim.data() + (size_t)c * 2 * OT_PRIM_N + OT_PRIM_N;
+                    add_guide(F, OT_PRIM_N, F[0], &devs[i].g_prim[c]);
+                }
     }
 
     size_t o_tab = align_up(sizeof(SourceDev) * n_sources);
-    size_t total = align_up(o_tab + sizeof(double) * (tabs.size() + 1));
+    size_t o_guide = align_up(o_tab + sizeof(double) * (tabs.size() + 1));
+    size_t total = align_up(o_guide + sizeof(int32_t) * (guides.size() + 1));
     char* blob = nullptr;
     HIP_TRY(hipMalloc((void**)&blob, total));
     const double* dtab = (const double*)(blob + o_tab);
+    for (const GuideRef& r : grefs) r.dst->g = (const int32_t*)(blob + o_guide) + r.off;
     for (int i = 0; i < n_sources; i++) {
         SourceDev& d = devs[i];
         if (offs[i][0] != (size_t)-1) d.spec_tab = dtab + offs[i][0];
@@ -574,6 +613,7 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
     std::vector<char> host(total, 0);
     std::memcpy(host.data(), devs.data(), sizeof(SourceDev) * n_sources);
     if (!tabs.empty()) std::memcpy(host.data() + o_tab, tabs.data(), sizeof(double) * tabs.size());
+    if (!guides.empty()) std::memcpy(host.data() + o_guide, guides.data(), sizeof(int32_t) * guides.size());
     hipError_t e = hipMemcpy(blob, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(blob);
@@ -607,19 +647,61 @@ struct RangeArgs {
     int32_t source[OT_MAX_RANGES];
     int64_t first[OT_MAX_RANGES];
     int64_t count[OT_MAX_RANGES];
+    // per-range constants of the stratified samplers, evaluated once on the host: 1 / count,
+    // floor(sqrt(count)) and its reciprocal (random.py:23-31, 62)
+    uint32_t n2[OT_MAX_RANGES];
+    double inv_n[OT_MAX_RANGES];
+    double inv_n2[OT_MAX_RANGES];
 };
 
-OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& src) {
-    for (int k = 0; k < rg.n; k++) {
-        if (ray >= rg.first[k] && ray < rg.first[k] + rg.count[k]) {
-            g.j = (uint32_t)(ray - rg.first[k]);
-            g.n = (uint32_t)rg.count[k];
-            g.range = (uint32_t)k;
-            src = rg.source[k];
+OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& k, int& src) {
+    for (int q = 0; q < rg.n; q++) {
+        if (ray >= rg.first[q] && ray < rg.first[q] + rg.count[q]) {
+            g.j = (uint32_t)(ray - rg.first[q]);
+            g.n = (uint32_t)rg.count[q];
+            g.n2 = rg.n2[q];
+            g.inv_n = rg.inv_n[q];
+            g.inv_n2 = rg.inv_n2[q];
+            k = q;
+            src = rg.source[q];
             return true;
         }
     }
     return false;
+}
+
+// Generates the ray of every lane that has one.  Source ranges span millions of rays, so a wavefront nearly
+// always lies inside one range: then the range index, its ray count and its source record are WAVE-UNIFORM
+// (broadcast from the first lane) -- the source is read with scalar loads, the switches over shape / spectrum /
+// divergence / polarisation are scalar branches, permutation keys come from the scalar ALU.  A wave that
+// straddles a range boundary takes the per-lane path.  (A loop over the ranges of a wave instead of the two
+// paths made the register allocator give up: 256 VGPRs.)
+OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sources, int64_t ray, uint64_t seed,
+                          bool no_pol, NewRay& nr) {
+    GenCtx g;
+    g.seed = seed;
+    g.gidx = (uint64_t)ray;
+    int k = -1, src = 0;
+    const bool have = locate_range(rg, ray, g, k, src);
+    const unsigned long long todo = __ballot(have);
+    if (!todo) return false;
+    const int lead = __builtin_ctzll(todo);
+    const int ku = __builtin_amdgcn_readlane(k, lead);
+    if (__ballot(have && k == ku) == todo) {  // one range in this wave
+        if (have) {
+            g.n = (uint32_t)__builtin_amdgcn_readlane((int)g.n, lead);
+            g.n2 = (uint32_t)__builtin_amdgcn_readlane((int)g.n2, lead);
+            g.range = (uint32_t)ku;
+            const auto& S = as_const(sources)[__builtin_amdgcn_readlane(src, lead)];
+            fill_dither_for(g, S);
+            nr = generate_ray(S, g, no_pol);
+        }
+    } else if (have) {
+        g.range = (uint32_t)k;
+        fill_dither_for(g, sources[src]);
+        nr = generate_ray(sources[src], g, no_pol);
+    }
+    return have;
 }
 
 // Raytracer.trace: optional on-the-fly generation, then all steps.  One ray per lane, 256-thread workgroups
@@ -651,14 +733,9 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
     RayState r;
     if (have) {
         if (GEN) {
-            GenCtx g;
-            g.seed = seed;
-            g.gidx = (uint64_t)ray;
-            int src = 0;
-            have = locate_range(rg, ray, g, src);
+            NewRay nr;
+            have = generate_lane(rg, sources, ray, seed, !POL, nr);
             if (have) {
-                fill_dither(g, sources[src].shape >= OT_SRC_IMAGE_RGB);
-                NewRay nr = generate_ray(sources[src], g, !POL);
                 r.p = nr.p;
                 r.s = nr.s;
                 r.w = nr.w;
@@ -728,13 +805,8 @@ __global__ __launch_bounds__(256) void generate_kernel(ot_rays R, const SourceDe
                                                        uint64_t seed) {
     const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ray >= R.N) return;
-    GenCtx g;
-    g.seed = seed;
-    g.gidx = (uint64_t)ray;
-    int src = 0;
-    if (!locate_range(rg, ray, g, src)) return;
-    fill_dither(g, sources[src].shape >= OT_SRC_IMAGE_RGB);
-    NewRay nr = generate_ray(sources[src], g, !POL);
+    NewRay nr;
+    if (!generate_lane(rg, sources, ray, seed, !POL, nr)) return;
     const int64_t N = R.N, nt = R.nt;
     R.p[ray] = nr.p.x;
     R.p[ray + N * nt] = nr.p.y;
@@ -834,6 +906,13 @@ static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot
         rg.source[k] = ranges[k].source;
         rg.first[k] = ranges[k].first;
         rg.count[k] = ranges[k].count;
+        const uint64_t cnt = (uint64_t)ranges[k].count;
+        uint32_t n2 = (uint32_t)std::sqrt((double)cnt);
+        while ((uint64_t)n2 * n2 > cnt) n2--;
+        while ((uint64_t)(n2 + 1) * (n2 + 1) <= cnt) n2++;
+        rg.n2[k] = n2;
+        rg.inv_n[k] = cnt ? 1.0 / (double)cnt : 0.0;
+        rg.inv_n2[k] = n2 ? 1.0 / (double)n2 : 0.0;
         covered += ranges[k].count;
     }
     if (covered != N) return fail(OT_ERR_INVALID, "source ranges must cover all N rays exactly once");

@@ -47,7 +47,12 @@ OT_DEV uint32_t permute_index(uint32_t i, uint32_t l, uint32_t key) {
         i &= w;
         i ^= i >> 5;
     } while (i >= l);
-    return (i + key) % l;
+    // rotate by a key-dependent offset in [0, l): w < 2 l, so one conditional subtraction each replaces `% l`
+    uint32_t rot = key & w;
+    if (rot >= l) rot -= l;
+    i += rot;
+    if (i >= l) i -= l;
+    return i;
 }
 
 // permutation key of one (seed, range, stream): a 32-bit finaliser-style mix (wave-uniform, a few SALU ops)
@@ -67,46 +72,63 @@ struct GenCtx {
     uint32_t j;      // index inside the source range
     uint32_t n;      // rays in the source range (stratification domain)
     uint32_t range;  // range id (permutation keys differ per range)
-    double u[12];    // dither values in [0,1), 32 random bits each: two Philox-4x32-10 calls per ray,
-                     // a third one for image sources
+    uint32_t n2;     // floor(sqrt(n)): side of the jittered grid of the 2-D samplers
+    double inv_n, inv_n2;  // 1 / n, 1 / n2 (host)
+    double u[12];    // dither values in [0,1), 32 random bits each: one to three Philox-4x32-10 blocks per ray
 };
 
-// stream -> which dither value(s) it uses (consecutive pairs for the 2-D samplers)
+// stream -> which dither value(s) it uses (consecutive pairs for the 2-D samplers).  The slots are grouped so
+// that a source only pays for the Philox blocks it needs: block A (u0-u3) serves every source -- point sources
+// with direction, wavelength and polarisation need nothing else --, block B (u4-u7) extended emitters and 2-D
+// divergence, block C (u8-u11) image sources.
 OT_DEV int dither_slot(uint32_t stream) {
     switch (stream) {
-        case ST_POS: return 0;         // u0, u1
-        case ST_DIV: return 2;         // u2, u3
-        case ST_WL: return 4;
-        case ST_POL: return 5;
+        case ST_DIV: return 0;         // u0, u1
+        case ST_WL: return 2;
+        case ST_RGB_WL: return 2;      // RGB images draw the wavelength from a primary instead of a spectrum
+        case ST_POL: return 3;
+        case ST_POS: return 4;         // u4, u5
         case ST_DIV_ALPHA: return 6;
-        case ST_RGB_WL: return 7;
-        case ST_PIXEL: return 8;       // image sources: third Philox call
+        case ST_PIXEL: return 8;
         case ST_PIX_JITTER: return 9;  // u9, u10
         default: return 11;            // ST_RGB_CHOICE
     }
 }
 
-OT_DEV void fill_dither(GenCtx& g, bool image_source) {
-    Philox a = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e31u, 0, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
-    Philox b = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e32u, 1, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+OT_DEV void fill_dither(GenCtx& g, bool need_b, bool need_c) {
+    const uint32_t i0 = (uint32_t)g.gidx, i1 = (uint32_t)(g.gidx >> 32), k0 = (uint32_t)g.seed, k1 = (uint32_t)(g.seed >> 32);
+    Philox a = philox4x32(i0, i1, 0x67656e31u, 0, k0, k1);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         g.u[k] = ((double)a.c[k] + 0.5) * 0x1.0p-32;
-        g.u[4 + k] = ((double)b.c[k] + 0.5) * 0x1.0p-32;
+        g.u[4 + k] = 0.5;
         g.u[8 + k] = 0.5;
     }
-    if (image_source) {
-        Philox c = philox4x32((uint32_t)g.gidx, (uint32_t)(g.gidx >> 32), 0x67656e33u, 2, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+    if (need_b) {
+        Philox b = philox4x32(i0, i1, 0x67656e32u, 1, k0, k1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) g.u[4 + k] = ((double)b.c[k] + 0.5) * 0x1.0p-32;
+    }
+    if (need_c) {
+        Philox c = philox4x32(i0, i1, 0x67656e33u, 2, k0, k1);
 #pragma unroll
         for (int k = 0; k < 4; k++) g.u[8 + k] = ((double)c.c[k] + 0.5) * 0x1.0p-32;
     }
+}
+
+// which Philox blocks a source needs (see dither_slot)
+template <class SRC>
+OT_DEV void fill_dither_for(GenCtx& g, SRC& src) {
+    const bool image = src.shape >= OT_SRC_IMAGE_RGB;
+    const bool extended = src.shape != OT_SRC_POINT && !image;
+    fill_dither(g, extended || (src.divergence != OT_DIV_NONE && src.div_2d), image);
 }
 
 // random.stratified_interval_sampling random.py:48-67: one of n strata of [a, b), uniformly dithered
 OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double b) {
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
     double u0 = g.u[dither_slot(stream)];
-    double dba = (b - a) / (double)g.n;
+    double dba = (b - a) * g.inv_n;
     return a + ((double)k + u0) * dba;
 }
 
@@ -116,13 +138,11 @@ OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, dou
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
     const int slot = dither_slot(stream);
     double u0 = g.u[slot], u1 = g.u[slot + 1];
-    uint32_t N2 = (uint32_t)sqrt((double)g.n);
-    while ((uint64_t)N2 * N2 > g.n) N2--;
-    while ((uint64_t)(N2 + 1) * (N2 + 1) <= g.n) N2++;
+    const uint32_t N2 = g.n2;
     if (k < N2 * N2) {
         uint32_t iy = k / N2, ix = k - iy * N2;
-        x = a + ((double)ix + u0) * ((b - a) / (double)N2);
-        y = c + ((double)iy + u1) * ((d - c) / (double)N2);
+        x = a + ((double)ix + u0) * ((b - a) * g.inv_n2);
+        y = c + ((double)iy + u1) * ((d - c) * g.inv_n2);
     } else {
         x = a + u0 * (b - a);
         y = c + u1 * (d - c);
@@ -130,18 +150,18 @@ OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, dou
 }
 
 // random.stratified_ring_sampling random.py:70-110: Shirley's equal-area square->disc map, then disc->annulus.
-// polar == false: cartesian (x, y); polar == true: (|r|, theta) with theta shifted by -pi for negative r.
+// polar == false: cartesian (x, y); polar == true: (|r|, theta / pi) with theta shifted by -pi for negative r.
 OT_DEV void strat_ring(const GenCtx& g, uint32_t stream, double ri, double r, bool polar, double& o0, double& o1) {
     double x, y;
     strat_rect(g, stream, -r, r, -r, r, x, y);
     double x2 = x * x, y2 = y * y;
-    double r_ = 0.0, theta = 0.0;
+    double r_ = 0.0, th = 0.0;  // th = theta / pi: sincospi needs no range reduction against an inexact pi
     if (x2 > y2) {
         r_ = x;
-        theta = M_PI / 4 * y / x;
+        th = 0.25 * (y / x);
     } else if (y2 > 0) {
         r_ = y;
-        theta = M_PI / 2 - M_PI / 4 * x / y;
+        th = 0.5 - 0.25 * (x / y);
     }
     if (ri != 0.0) {
         double q = ri / r;
@@ -150,42 +170,47 @@ OT_DEV void strat_ring(const GenCtx& g, uint32_t stream, double ri, double r, bo
     }
     if (!polar) {
         double sn, cs;
-        sincos(theta, &sn, &cs);
+        sincospi(th, &sn, &cs);
         o0 = r_ * cs;
         o1 = r_ * sn;
-    } else {
-        if (r_ < 0) theta -= M_PI;
+    } else {  // (|r|, theta / pi) with theta shifted by -pi for negative r
+        if (r_ < 0) th -= 1.0;
         o0 = fabs(r_);
-        o1 = theta;
+        o1 = th;
     }
+}
+
+template <class GD>
+OT_DEV int guide_start(GD& G, double X) {
+    double t = (X - G.x0) * G.scale;
+    int b = (t > 0.0) ? ((t < (double)(G.K - 1)) ? (int)t : G.K - 1) : 0;
+    return G.g[b];
 }
 
 // random.inverse_transform_sampling random.py:113-159, kind="discrete": first entry whose cumulative weight
-// reaches X (scipy interp1d kind="next"); tab = n values then n cumulative weights
-OT_DEV double inv_cdf_discrete(const double* __restrict__ tab, int n, double X) {
-    const double* F = tab + n;
-    int lo = 0, hi = n - 1;  // smallest j with F[j] >= X
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (F[mid] >= X)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
-    return tab[lo];
+// reaches X (scipy interp1d kind="next"); tab = n values then n cumulative weights.  Returns the index.
+template <class GD>
+OT_DEV int cdf_index_discrete(const double* __restrict__ F, int n, double X, GD& G) {
+    int lo = guide_start(G, X);  // smallest j with F[j] >= X (n - 1 if there is none)
+    while (lo < n - 1 && F[lo] < X) lo++;
+    while (lo > 0 && F[lo - 1] >= X) lo--;
+    return lo;
+}
+
+template <class GD>
+OT_DEV double inv_cdf_discrete(const double* __restrict__ tab, int n, double X, GD& G) {
+    return tab[cdf_index_discrete(tab + n, n, X, G)];
 }
 
 // kind="continuous": linear interpolation of the inverse cumulative-trapezoid table; tab = n x then n F
-OT_DEV double inv_cdf_linear(const double* __restrict__ tab, int n, double X) {
+template <class GD>
+OT_DEV double inv_cdf_linear(const double* __restrict__ tab, int n, double X, GD& G) {
     const double* F = tab + n;
-    int lo = 0, hi = n - 1;  // F[lo] <= X <= F[hi]
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (F[mid] <= X)
-            lo = mid;
-        else
-            hi = mid;
-    }
+    int lo = guide_start(G, X);  // largest j <= n - 2 with F[j] <= X
+    if (lo > n - 2) lo = n - 2;
+    while (lo < n - 2 && F[lo + 1] <= X) lo++;
+    while (lo > 0 && F[lo] > X) lo--;
+    const int hi = lo + 1;
     double dF = F[hi] - F[lo];
     if (!(dF > 0)) return tab[lo];
     return tab[lo] + (X - F[lo]) / dF * (tab[hi] - tab[lo]);
@@ -198,7 +223,8 @@ struct NewRay {
 };
 
 // RaySource.create_rays ray_source.py:204-437 for ray j of a range of n rays of source `src`
-OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
+template <class SRC>
+OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
     NewRay o;
     o.w = (float)(src.power / (double)g.n);  // ray_source.py:220
 
@@ -211,7 +237,7 @@ OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
             case OT_SPEC_LINES: {
                 const double* F = src.spec_tab + src.n_spec;
                 double X = strat_interval(g, ST_WL, 0.0, F[src.n_spec - 1]);
-                wl = inv_cdf_discrete(src.spec_tab, (int)src.n_spec, X);
+                wl = inv_cdf_discrete(src.spec_tab, (int)src.n_spec, X, src.g_spec);
                 break;
             }
             case OT_SPEC_GAUSSIAN: {
@@ -222,7 +248,7 @@ OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
             default: {
                 const double* F = src.spec_tab + src.n_spec;
                 double X = strat_interval(g, ST_WL, F[0], F[src.n_spec - 1]);
-                wl = inv_cdf_linear(src.spec_tab, (int)src.n_spec, X);
+                wl = inv_cdf_linear(src.spec_tab, (int)src.n_spec, X, src.g_spec);
             }
         }
     }
@@ -257,22 +283,14 @@ OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
             uint32_t P = 0;
             if (npx > 1) {
                 double X = strat_interval(g, ST_PIXEL, 0.0, src.img_cdf[npx - 1]);
-                uint32_t lo = 0, hi = npx - 1;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (src.img_cdf[mid] >= X)
-                        hi = mid;
-                    else
-                        lo = mid + 1;
-                }
-                P = lo;
+                P = (uint32_t)cdf_index_discrete(src.img_cdf, (int)npx, X, src.g_img);
             }
             uint32_t PY = P / (uint32_t)src.img_w, PX = P - PY * (uint32_t)src.img_w;
             double rx, ry;
             strat_rect(g, ST_PIX_JITTER, 0.0, 1.0, 0.0, 1.0, rx, ry);
             double xs = src.pos[0] - src.dim[0] / 2, ys = src.pos[1] - src.dim[1] / 2;
-            p.x = src.dim[0] / (double)src.img_w * ((double)PX + rx) + xs;
-            p.y = src.dim[1] / (double)src.img_h * ((double)PY + ry) + ys;
+            p.x = src.px_w * ((double)PX + rx) + xs;
+            p.y = src.px_h * ((double)PY + ry) + ys;
             if (src.shape == OT_SRC_IMAGE_RGB) {  // color.random_wavelengths_from_srgb srgb.py:513-553
                 double choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
                 double c_r = src.img_rgb[2 * (size_t)P], c_rg = src.img_rgb[2 * (size_t)P + 1];
@@ -280,7 +298,7 @@ OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
                 const double* tab = src.prim_tab + (size_t)prim * 2 * OT_PRIM_N;
                 const double* F = tab + OT_PRIM_N;
                 double X = strat_interval(g, ST_RGB_WL, F[0], F[OT_PRIM_N - 1]);
-                wl = inv_cdf_linear(tab, OT_PRIM_N, X);
+                wl = inv_cdf_linear(tab, OT_PRIM_N, X, src.g_prim[prim]);
             }
         }
     }
@@ -291,7 +309,10 @@ OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
     V3 s_or;
     if (src.orientation == OT_OR_CONVERGING) {
         V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
-        s_or = normalize3(d);
+        const double il = 1 / sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+        s_or.x = d.x * il;
+        s_or.y = d.y * il;
+        s_or.z = d.z * il;
     } else {
         s_or.x = src.s[0];
         s_or.y = src.s[1];
@@ -301,38 +322,56 @@ OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
     // ---- divergence (ray_source.py:290-351) ----
     V3 s = s_or;
     if (src.divergence != OT_DIV_NONE) {
-        double theta = 0.0, alpha = 0.0;
+        // sin / cos of the polar angle theta and of the azimuth alpha; where the reference goes through
+        // asin / acos and back (ray_source.py:303-320, 343-351) the pair is formed algebraically
+        double st, ct, sa, ca;
         if (src.div_2d) {
             double X = strat_interval(g, ST_DIV_ALPHA, 0.0, 2.0);
-            alpha = (X <= 1.0) ? src.div_axis : src.div_axis + M_PI;
+            const double sgn = (X <= 1.0) ? 1.0 : -1.0;  // alpha = div_axis or div_axis + pi
+            ca = sgn * src.axis_cos;
+            sa = sgn * src.axis_sin;
+            double theta;
             switch (src.divergence) {
-                case OT_DIV_LAMBERTIAN: theta = asin(strat_interval(g, ST_DIV, 0.0, src.div_sin)); break;
-                case OT_DIV_ISOTROPIC: theta = strat_interval(g, ST_DIV, 0.0, src.div_rad); break;
+                case OT_DIV_LAMBERTIAN: {
+                    st = strat_interval(g, ST_DIV, 0.0, src.div_sin);  // theta = asin(st)
+                    ct = sqrt(1 - st * st);
+                    break;
+                }
+                case OT_DIV_ISOTROPIC:
+                    theta = strat_interval(g, ST_DIV, 0.0, src.div_rad);
+                    sincos(theta, &st, &ct);
+                    break;
                 default: {
                     const double* F = src.div_tab + src.n_div;
                     double X2 = strat_interval(g, ST_DIV, F[0], F[src.n_div - 1]);
-                    theta = inv_cdf_linear(src.div_tab, (int)src.n_div, X2);
+                    theta = inv_cdf_linear(src.div_tab, (int)src.n_div, X2, src.g_div);
+                    sincos(theta, &st, &ct);
                 }
             }
         } else {
-            double r;
-            strat_ring(g, ST_DIV, 0.0, src.div_sin, true, r, alpha);
+            double r, alpha_pi;
+            strat_ring(g, ST_DIV, 0.0, src.div_sin, true, r, alpha_pi);
+            sincospi(alpha_pi, &sa, &ca);
             switch (src.divergence) {
-                case OT_DIV_LAMBERTIAN: theta = asin(r); break;
-                case OT_DIV_ISOTROPIC: theta = acos(1 - r * r); break;
+                case OT_DIV_LAMBERTIAN:  // theta = asin(r)
+                    st = r;
+                    ct = sqrt(1 - r * r);
+                    break;
+                case OT_DIV_ISOTROPIC:  // theta = acos(1 - r^2)
+                    ct = 1 - r * r;
+                    st = r * sqrt(2 - r * r);
+                    break;
                 default: {
                     const double* F = src.div_tab + src.n_div;
                     double X0 = r * r / (src.div_sin * src.div_sin);
-                    theta = inv_cdf_linear(src.div_tab, (int)src.n_div, F[0] + X0 * (F[src.n_div - 1] - F[0]));
+                    double theta = inv_cdf_linear(src.div_tab, (int)src.n_div, F[0] + X0 * (F[src.n_div - 1] - F[0]), src.g_div);
+                    sincos(theta, &st, &ct);
                 }
             }
         }
         double fa = 1 / sqrt(1 - s_or.x * s_or.x);
         V3 sy = {0.0, -s_or.z * fa, s_or.y * fa};
         V3 sx = cross3(s_or, sy);
-        double st, ct, sa, ca;
-        sincos(theta, &st, &ct);
-        sincos(alpha, &sa, &ca);
         s.x = ct * s_or.x + st * (ca * sx.x + sa * sy.x);
         s.y = ct * s_or.y + st * (ca * sx.y + sa * sy.y);
         s.z = ct * s_or.z + st * (ca * sx.z + sa * sy.z);
@@ -342,22 +381,25 @@ OT_DEV NewRay generate_ray(const SourceDev& src, const GenCtx& g, bool no_pol) {
     // ---- polarisation (ray_source.py:359-433) ----
     o.polx = o.poly = o.polz = 0.0;
     if (!no_pol) {
-        double ang;
+        double sn, cs;
         switch (src.polarization) {
-            case OT_POL_CONSTANT: ang = src.pol_angle; break;
-            case OT_POL_UNIFORM: ang = strat_interval(g, ST_POL, 0.0, 2 * M_PI); break;
+            case OT_POL_CONSTANT:
+                cs = src.pol_cos;
+                sn = src.pol_sin;
+                break;
+            case OT_POL_UNIFORM: sincospi(strat_interval(g, ST_POL, 0.0, 2.0), &sn, &cs); break;  // angle in [0, 2 pi)
             case OT_POL_LIST: {
                 const double* F = src.pol_tab + src.n_pol;
-                ang = inv_cdf_discrete(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, 0.0, F[src.n_pol - 1]));
+                double ang = inv_cdf_discrete(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, 0.0, F[src.n_pol - 1]), src.g_pol);
+                sincos(ang, &sn, &cs);
                 break;
             }
             default: {
                 const double* F = src.pol_tab + src.n_pol;
-                ang = inv_cdf_linear(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, F[0], F[src.n_pol - 1]));
+                double ang = inv_cdf_linear(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, F[0], F[src.n_pol - 1]), src.g_pol);
+                sincos(ang, &sn, &cs);
             }
         }
-        double sn, cs;
-        sincos(ang, &sn, &cs);
         double px = cs, py = sn, pz = 0.0;
         if (s.z != 1) {
             double fa = 1 / (sqrt(1 - s.z * s.z) + 1e-16);

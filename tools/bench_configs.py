@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Times Raytracer.trace() (generation + all surfaces + section stores) for BASELINE.json configs C1-C5 at their full
+ray counts on one GPU.  Prints one line per config: ms per trace, ray-surface-intersections/s, algorithmic GB/s."""
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+import numpy as np
+import torch
+
+import optrace_amd as ot
+import scenes
+
+
+def c3(ot_):
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:256, 0:256]
+    rgb = np.stack([(xx // 32 + yy // 32) % 2 * 0.8 + 0.1, xx / 255., yy / 255.], axis=2) * rng.uniform(0.9, 1, (256, 256, 1))
+    RT = ot_.Raytracer(outline=[-10, 10, -10, 10, -610, 28], seed=31)
+    RT.add(ot_.RaySource(ot_.RGBImage(rgb, [8.39, 8.39]), divergence="Isotropic", div_angle=0.25,
+                         orientation="Converging", conv_pos=[0, 0, 0], pos=[0, 0, -600]))
+    RT.add(ot_.presets.geometry.arizona_eye(adaptation=1 / 0.6, pupil=4))
+    return RT
+
+
+def c4(ot_):
+    RT = ot_.Raytracer(outline=[-8, 8, -8, 8, 0, 40], no_pol=True, seed=41)
+    RT.add(ot_.RaySource(ot_.RGBImage(scenes.synthetic_rgb_image(), [4, 3]), divergence="Isotropic",
+                         div_angle=np.rad2deg(np.arctan(3 / 12) * 1.2), s=[0, 0, 1], pos=[0, 0, 0],
+                         orientation="Converging", conv_pos=[0, 0, 12]))
+    RT.add(ot_.Lens(ot_.SphericalSurface(r=3, R=8), ot_.SphericalSurface(r=3, R=-8), de=0.1, pos=[0, 0, 12],
+                    n=ot_.RefractionIndex("Abbe", n=1.5, V=40)))
+    RT.add(ot_.Detector(ot_.RectangularSurface(dim=[16, 16]), pos=[0, 0, 36]))
+    return RT
+
+
+CONFIGS = {
+    "C1 single lens": (lambda o: scenes.c1_single_lens(o, seed=1), 100_000),
+    "C1 single lens (1e7)": (lambda o: scenes.c1_single_lens(o, seed=1), 10_000_000),
+    "C2 double gauss": (lambda o: scenes.double_gauss(o, seed=1), 10_000_000),
+    "C2 double gauss no_pol": (lambda o: scenes.double_gauss(o, seed=1, no_pol=True), 10_000_000),
+    "C3 arizona eye RGB": (c3, 50_000_000),
+    "C4 image render no_pol": (c4, 200_000_000),
+    "C5 HURB slit+lens": (lambda o: scenes.hurb_slit_lens(o, seed=51), 100_000_000),
+    "freeform (spline surfaces)": (lambda o: scenes.freeform_scene(o, seed=5), 10_000_000),
+}
+
+for name, (build, N) in CONFIGS.items():
+    with ot.global_options.no_warnings():
+        RT = build(ot)
+        RT.trace(N)  # warm-up: scene compile, geometry checks, allocation
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            RT.trace(N)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    nt = RT.rays.Nt
+    M = nt - 2
+    b = N * (nt * (36 if RT.no_pol else 48) + 28)
+    print(f"{name:28s} N={N:>11,d} M={M:2d}  {1e3*t:8.2f} ms  {N*M/t:9.3e} ray-surf/s  {b/t/1e9:7.0f} GB/s algorithmic"
+          f"  ({b/1e9:.1f} GB)", flush=True)
+    del RT
+    torch.cuda.empty_cache()
