@@ -26,7 +26,9 @@ def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projec
     rs = rays._rays_struct()
     _capi.check(lib.ot_detector_hits(C.byref(rs), int(first), int(count), C.byref(surf_desc), int(projection),
                                      ptr(ph), ptr(hw), ptr(ext), ptr(ill), stream_ptr()))
-    ill_h = ill.cpu().numpy()
+    # closed-form hits (flat / conic detectors) can neither be ill-conditioned nor time out: no read-back, no sync
+    numeric = surf_desc.kind >= _capi.SURF_ASPHERE and surf_desc.z_min != surf_desc.z_max
+    ill_h = ill.cpu().numpy() if numeric else (0, 0)
     if ill_h[1]:
         raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
     return ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill_h[0])

@@ -43,7 +43,9 @@ class Raytracer(Group):
     MAX_RAY_STORAGE_RAM: int = 200_000_000_000
     """Upper bound for the ray storage of one trace.  The reference guards host RAM with 6 GB
     (raytracer.py:37); here the storage lives in the 288 GB of HBM3E of one MI355X."""
-    ITER_RAYS_STEP: int = 1000000
+    ITER_RAYS_STEP: int = 10_000_000
+    """Rays per chunk of `iterative_render`.  The reference uses 1 M to bound host RAM (raytracer.py:40); a chunk of
+    10 M rays keeps the storage of a 15-surface scene at 8.4 GB of HBM and needs ten times fewer launches."""
 
     class INFOS(IntEnum):
         ABSORB_MISSING = 0
@@ -68,6 +70,7 @@ class Raytracer(Group):
         self._scene_handle = None
         self._scene_key = None
         self._checked_key = None
+        self._rays_known_current = False
         super().__init__(None, n0, **kwargs)
         self._new_lock = True
 
@@ -150,13 +153,13 @@ class Raytracer(Group):
                             + texts[self.INFOS(type_)].format(s=surf, n=name))
 
     # ---- geometry checks (raytracer.py:510-664) ---------------------------------------------------------
-    def _pretrace_check(self, N: int) -> bool:
+    def _pretrace_check(self, N: int, snap: dict = None) -> bool:
         check_type("N", N, int)
         if N < 1:
             raise ValueError(f"Ray number N needs to be at least 1, but is {N}.")
         # the checks sample every surface pair on a 100 x 100 grid (host NumPy); skip them while nothing that
         # they depend on changed since they last passed (chunked rendering calls trace() many times)
-        key = self._geometry_key()
+        key = self._geometry_key(snap)
         if self._checked_key is None or key != self._checked_key or self.geometry_error:
             self._geometry_checks()
             self._checked_key = key if not self.geometry_error else None
@@ -165,8 +168,8 @@ class Raytracer(Group):
             return True
         return False
 
-    def _geometry_key(self):
-        snap = self.tracing_snapshot()
+    def _geometry_key(self, snap: dict = None):
+        snap = dict(self.tracing_snapshot() if snap is None else snap)
         snap.pop("Rays", None)
         return repr(snap)
 
@@ -267,10 +270,10 @@ class Raytracer(Group):
         return bool(np.any(coll)), x2v[where], y2v[where], zfv[where]
 
     # ---- scene upload --------------------------------------------------------------------------------------
-    def _compile(self) -> CompiledScene:
+    def _compile(self, snap: dict = None) -> CompiledScene:
         """Flatten the scene and upload its tables; reused while the tracing-relevant state is unchanged."""
         lib = _capi.load_library()
-        key = self._geometry_key()
+        key = self._geometry_key(snap)
         if self._scene is not None and self._scene_handle is not None and key == self._scene_key:
             return self._scene
         self._release_scene()
@@ -308,7 +311,8 @@ class Raytracer(Group):
             pass
 
     # ---- tracing (raytracer.py:262-415) -----------------------------------------------------------------
-    def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None, _N_list=None) -> None:
+    def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None, _N_list=None,
+              _chunk: int = 0) -> None:
         """Trace N rays through the current geometry.
 
         Geometry errors are reported as warnings and set `geometry_error` instead of raising, like the
@@ -316,7 +320,8 @@ class Raytracer(Group):
         (2*n_hurb, N) inject recorded inputs for parity tests; normally rays are generated inside the
         tracing kernel and the remainder of the per-source split is drawn at random like the reference does.
         """
-        if self._pretrace_check(N):
+        snap = self.tracing_snapshot()  # taken once: geometry-check key, scene key and the post-trace record
+        if self._pretrace_check(N, snap):
             return
         lib = _capi.load_library()
         dev = require_device()
@@ -327,12 +332,13 @@ class Raytracer(Group):
                                " the number of rays, surfaces or do an iterative render. If your system can handle"
                                " more RAM usage, increase the Raytracer.MAX_RAY_STORAGE_RAM parameter.")
 
-        scene = self._compile()
+        scene = self._compile(snap)
         assert scene.nt == nt
         self.rays.init(self.ray_sources, N, nt, self.no_pol, _N_list=_N_list)
         rays = self.rays._rays_struct()
         msgs = torch.zeros(len(self.INFOS) * nt + 1, dtype=torch.int64, device=dev)
-        seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed)
+        # a seeded tracer repeats itself call for call; the chunks of one iterative render must differ
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed) + 1000003 * int(_chunk)
 
         if _initial_rays is None:
             tab = self.rays._source_table()
@@ -353,7 +359,8 @@ class Raytracer(Group):
             raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
         self._msgs = msgs_h[:-1].reshape(len(self.INFOS), nt).astype(int)
         self._show_messages(N)
-        self._last_trace_snapshot = self.tracing_snapshot()
+        snap["Rays"] = [self.rays.N, self.rays.Nt, self.rays.no_pol]
+        self._last_trace_snapshot = snap
 
     # ---- detector (raytracer.py:881-1098) ----------------------------------------------------------------
     def _hit_detector(self, info: str, detector_index: int = 0, source_index: int = None, extent=None,
@@ -368,7 +375,7 @@ class Raytracer(Group):
             raise IndexError("Invalid source_index.")
         if detector_index > len(self.detectors) - 1 or detector_index < 0:
             raise IndexError("Invalid detector_index.")
-        if not self.check_if_rays_are_current():
+        if not self._rays_known_current and not self.check_if_rays_are_current():
             raise RuntimeError("Tracing geometry/properties changed. Please retrace first.")
 
         Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
@@ -649,24 +656,39 @@ class Raytracer(Group):
 
         nt = len(self.tracing_surfaces) + 2
         msgs_cum = np.zeros((len(self.INFOS), nt), dtype=int)
+        scale0, scaled = 1.0, False
 
         for i in range(iterations):
             if i == iterations - 1:
                 rays_step += int(N - iterations * rays_step)
             with global_options.no_warnings():
-                self.trace(N=rays_step)
+                self.trace(N=rays_step, _chunk=i)
                 msgs_cum += self._msgs
-            for j in range(len(pos)):
-                self.detectors[detector_index[j]].move_to(pos[j])
-                img = self.detector_image(detector_index=detector_index[j], extent=extentc[j], limit=limit[j],
-                                          _dont_filter=True, _keep_on_device=True,
-                                          projection_method=projection_method[j])
-                img._dev *= rays_step / N
-                if i == 0:
-                    images.append(img)
-                    extentc[j] = img._extent0
-                else:
-                    images[j]._dev += img._dev
+            self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
+            try:
+                for j in range(len(pos)):
+                    self.detectors[detector_index[j]].move_to(pos[j])
+                    # chunks of equal size are binned straight into the image of the first chunk (their common
+                    # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
+                    # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
+                    direct = 0 < i and rays_step == self.ITER_RAYS_STEP
+                    img = self.detector_image(detector_index=detector_index[j], extent=extentc[j], limit=limit[j],
+                                              _dont_filter=True, _keep_on_device=True,
+                                              _into=images[j]._dev if direct else None,
+                                              projection_method=projection_method[j])
+                    if i == 0:
+                        images.append(img)
+                        extentc[j] = img._extent0
+                        scale0 = rays_step / N
+                    elif not direct:
+                        images[j]._dev *= scale0
+                        images[j]._dev += img._dev * (rays_step / N)
+                        scaled = True
+            finally:
+                self._rays_known_current = False
+        if not scaled:
+            for img in images:
+                img._dev *= scale0
 
         for i, img in enumerate(images):
             img._sync_host()

@@ -104,7 +104,7 @@ class RenderImage(BaseClass):
         return Nx, Ny
 
     def render(self, p=None, w=None, wl=None, limit: float = None, _dont_filter: bool = False,
-               _keep_on_device: bool = False) -> None:
+               _keep_on_device: bool = False, _into: "torch.Tensor" = None) -> None:
         """Bin hit positions into the XYZW image (render_image.py:361-421).
 
         p (n, 3) positions, w (n,) powers, wl (n,) wavelengths: NumPy arrays, or device tensors in the
@@ -115,7 +115,12 @@ class RenderImage(BaseClass):
         Nx, Ny = self._pixel_counts()
         lib = _capi.load_library()
         dev = require_device()
-        hist = torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=dev)
+        if _into is not None:  # accumulate into an existing (Ny, Nx, 4) device histogram (chunked rendering)
+            if tuple(_into.shape) != (Ny, Nx, 4):
+                raise ValueError("histogram to accumulate into has the wrong shape")
+            hist = _into.view(-1)
+        else:
+            hist = torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=dev)
 
         n = 0 if p is None else (int(w.shape[0]))
         if n:

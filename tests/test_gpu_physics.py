@@ -137,6 +137,16 @@ def test_iterative_render_accumulates_chunks():
     with ot.global_options.no_warnings():
         imgs = RT.iterative_render(400000, pos=[[0, 0, 15], [0, 0, 25]], extent=[-3, 3, -3, 3])
     assert len(imgs) == 2 and imgs[0].power() > 0 and imgs[1].power() > 0
+    # equal-sized chunks are binned straight into one histogram and scaled once: same power as a single trace,
+    # and the same at both planes (nothing is lost between them inside this extent)
+    # at z = 15 the whole beam is inside the extent
+    assert abs(imgs[0].power() - ref.power()) < 3e-3 * ref.power()
+    # the chunks of a seeded tracer are different ray sets: two chunks do not just repeat the first one
+    with ot.global_options.no_warnings():
+        one = RT.iterative_render(200000, pos=[0, 0, 15], extent=[-3, 3, -3, 3])[0]
+        two = RT.iterative_render(400000, pos=[0, 0, 15], extent=[-3, 3, -3, 3])[0]
+    assert np.abs(two._data[:, :, 3] - one._data[:, :, 3]).sum() > 0.05 * one._data[:, :, 3].sum()
+    assert abs(one.power() - two.power()) < 3e-3 * two.power()
 
 
 def test_hurb_spread_matches_uncertainty_formula():
