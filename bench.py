@@ -221,7 +221,7 @@ def main():
             "detector": {"rays_per_s": N / t_det, "ms": 1e3 * t_det, "allreduce_ms": 1e3 * t_red,
                          "image_power_all_ranks": total_power},
         }
-        if not args.skip_cpu:
+        if not args.skip_cpu and world == 1:  # CPU leg on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(RT, scene, args.cpu_seconds)
             out["cpu_baseline"]["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
