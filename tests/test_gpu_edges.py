@@ -1,0 +1,116 @@
+"""Edge cases of the hot path on the GPU: empty and ragged inputs (sizes around the 64-lane wavefront and the
+256-thread workgroup), rays that are dead or degenerate on entry, detectors nothing reaches."""
+import numpy as np
+import pytest
+
+import optrace_amd as ot
+from optrace_amd.scene import CompiledScene
+
+import oracle_bridge as ob
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_leaf_operators_accept_empty_arrays():
+    with ot.global_options.no_warnings():
+        zoo = {**scenes.surface_zoo(ot), **scenes.surface_zoo2(ot)}
+    e3, e1 = np.zeros((0, 3)), np.zeros(0)
+    for name in ("circle", "sphere_pos", "asphere_a", "tilted", "data2d"):
+        sf = zoo[name]
+        ph, hit, ill = sf.find_hit(e3, e3)
+        assert ph.shape == (0, 3) and hit.shape == (0,)
+        assert sf.normals(e1, e1).shape == (0, 3) and sf.mask(e1, e1).shape == (0,) and sf.values(e1, e1).shape == (0,)
+    assert ot.RefractionIndex("Abbe", n=1.6, V=40.)(np.zeros(0, dtype=np.float32)).shape == (0,)
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_sizes_match_oracle(N):
+    """On-device generation for N rays, then the same rays through the oracle: every lane of a partial wave /
+    partial workgroup must do exactly what a full one does."""
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, seed=100 + N)
+        RT.trace(N)
+    r = RT.rays
+    assert r.p_list.shape == (N, 17, 3) and r.N_list.sum() == N
+    sc = CompiledScene(RT)
+    rays = ob.HostRays(N, sc.nt, False)
+    p0 = r.p_list[:, 0]
+    d = r.p_list[:, 1] - p0
+    s0 = d / np.linalg.norm(d, axis=1)[:, None]
+    rays.set_initial(p0, s0, r.pol_list[:, 0], r.w_list[:, 0], r.wl_list)
+    msgs, st = ob.trace(sc.desc, rays, None)
+    assert st == 0
+    # directions are regenerated from stored positions (1e-16 off): masks and counters still have to agree
+    assert np.array_equal(rays.w_list > 0, r.w_list > 0)
+    assert np.array_equal(msgs, RT._msgs)
+    assert np.allclose(rays.p_list, r.p_list, rtol=1e-9, atol=1e-7)  # sources sit 50 m away: 1e-16 in s is 1e-11 mm here
+
+
+def test_rays_dead_or_degenerate_on_entry():
+    """Injected bundle with zero-weight rays, rays parallel to the axis far outside every lens, and rays that
+    start behind the first surface: nothing may crash, dead rays stay where they are."""
+    with ot.global_options.no_warnings():
+        RT = scenes.c1_single_lens(ot)
+        N = 300
+        rng = np.random.default_rng(2)
+        p0 = np.zeros((N, 3))
+        p0[:, :2] = rng.uniform(-0.5, 0.5, (N, 2))
+        p0[:, 2] = -20.
+        s0 = np.tile([0., 0., 1.], (N, 1))
+        w0 = np.full(N, 1.0 / N, dtype=np.float32)
+        w0[:50] = 0.0                        # dead on entry
+        p0[50:100, 0] = 9.0                  # pass far outside the lens (r = 3), inside the outline
+        p0[100:150, 2] = 5.0                 # start behind the lens
+        pol0 = np.tile([1., 0., 0.], (N, 1))
+        wl = np.full(N, 550., dtype=np.float32)
+        RT.trace(N, _initial_rays=(p0, s0, pol0, w0, wl))
+        r = RT.rays
+        assert np.all(np.isfinite(r.p_list))
+        assert np.all(r.w_list[:50] == 0) and np.all(r.p_list[:50] == p0[:50, None, :])
+        # rays outside the lens are absorbed at the first surface they miss (raytracer.py:347-357)
+        # (so are the rays that start behind it: find_hit reports no hit for them, surface.py:460-476)
+        assert np.all(r.w_list[50:150, 1] == 0) and RT._msgs[RT.INFOS.ABSORB_MISSING, 1] == 100
+        # same bundle through the oracle
+        sc = CompiledScene(RT)
+        rays = ob.HostRays(N, sc.nt, False)
+        rays.set_initial(p0, s0, pol0, w0, wl)
+        msgs, st = ob.trace(sc.desc, rays, None)
+        assert st == 0 and np.array_equal(msgs, RT._msgs)
+        assert np.array_equal(rays.w_list > 0, r.w_list > 0)
+        assert np.allclose(rays.p_list, r.p_list, rtol=1e-12, atol=1e-12)
+
+
+def test_detector_nothing_reaches():
+    """A detector beside the beam: empty image, zero power, the detector's own position as degenerate extent."""
+    with ot.global_options.no_warnings():
+        RT = scenes.c1_single_lens(ot, seed=3)
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[0.5, 0.5]), pos=[8.5, 8.5, 30]))
+        RT.trace(5000)
+        img = RT.detector_image(detector_index=1)
+        assert img.power() == 0.0 and not np.any(img._data)
+        spec = RT.detector_spectrum(detector_index=1)
+        assert not np.any(spec._vals)
+        # selecting a source range that hits and one user extent that excludes everything
+        img2 = RT.detector_image(detector_index=0, extent=[3.5, 3.9, 3.5, 3.9])
+        assert img2.power() == 0.0
+
+
+def test_many_sources_and_tiny_ranges():
+    """40 sources, 1000 rays: 25 rays per range, several ranges inside every wavefront (per-lane generation path)."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -25, 60], seed=8)
+        for i in range(40):
+            RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=2 + 0.05 * i,
+                                pos=[0.02 * (i - 20), 0, -20], power=1.0,
+                                spectrum=ot.LightSpectrum("Monochromatic", wl=450. + 5 * i)))
+        RT.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1,
+                       n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 0]))
+        RT.trace(1000)
+        r = RT.rays
+        assert np.array_equal(r.N_list, np.full(40, 25))
+        for i in range(40):
+            sl = slice(r.B_list[i], r.B_list[i + 1])
+            assert np.all(r.wl_list[sl] == np.float32(450. + 5 * i))
+            assert np.allclose(r.p_list[sl, 0, 0], 0.02 * (i - 20), atol=1e-15)
+        assert np.all(np.isfinite(r.p_list))
