@@ -34,6 +34,41 @@ OT_HD void fpbspl(TP t, double x, int l, double* h) {
     }
 }
 
+// The same K+1 basis values on UNIFORM knots, as polynomials of u = (x - t(l)) / (t(l+1) - t(l)) in [0, 1): one
+// division and ~20 multiply-adds instead of K(K+1)/2 divisions.  Data on an equidistant grid gives uniform knots
+// everywhere except next to the two ends (FITPACK's interpolating spline: t(6) .. t(n-5) equidistant for k = 4),
+// so nearly every evaluation takes this path; it agrees with the recurrence to the rounding noise of the knot
+// positions (~1e-14 relative).
+template <int K>
+OT_HD void bspl_uniform(double u, double* h) {
+    const double u2 = u * u, u3 = u2 * u;
+    if (K == 4) {
+        const double u4 = u2 * u2, v = 1.0 - u, v2 = v * v;
+        h[0] = v2 * v2 * (1.0 / 24);
+        h[1] = (((-4.0 * u + 12.0) * u - 6.0) * u - 12.0) * u * (1.0 / 24) + 11.0 / 24;
+        h[2] = (((6.0 * u - 12.0) * u - 6.0) * u + 12.0) * u * (1.0 / 24) + 11.0 / 24;
+        h[3] = ((((-4.0 * u + 4.0) * u + 6.0) * u + 4.0) * u + 1.0) * (1.0 / 24);
+        h[4] = u4 * (1.0 / 24);
+    } else {  // K == 3
+        const double v = 1.0 - u;
+        h[0] = v * v * v * (1.0 / 6);
+        h[1] = ((3.0 * u - 6.0) * u2 + 4.0) * (1.0 / 6);
+        h[2] = (((-3.0 * u + 3.0) * u + 3.0) * u + 1.0) * (1.0 / 6);
+        h[3] = u3 * (1.0 / 6);
+    }
+}
+
+// basis values at x in knot interval l of the knot array t (n knots, uniform from index ulo to uhi, 0-based)
+template <int K, class TP>
+OT_HD void bspl_basis(TP t, int ulo, int uhi, double x, int l, double* h) {
+    if (l - K >= ulo && l + K - 1 <= uhi) {
+        const double tl = t[l - 1];
+        bspl_uniform<K>((x - tl) / (t[l] - tl), h);
+    } else {
+        fpbspl<K>(t, x, l, h);
+    }
+}
+
 // knot interval of splev.f / splder.f / fpbisp.f: l in [k1, nk1] with t(l) <= x < t(l+1) (ends clamped).
 // k1 = degree of the *original* spline + 1; inv_h = approximate knots per unit length (first guess only).
 template <class TP>
@@ -53,7 +88,7 @@ OT_HD double spl1_eval(TP t, int n, TP c, double inv_h, double x) {
     const int k1 = OT_SPL_K + 1;
     const int l = spl_interval(t, n, k1, inv_h, x);
     double h[K + 1];
-    fpbspl<K>(t, x, l, h);
+    bspl_basis<K>(t, OT_SPL_K + 1, n - OT_SPL_K - 2, x, l, h);
     double sp = 0.0;
 #pragma unroll
     for (int j = 0; j <= K; j++) sp = sp + c[l - k1 + j] * h[j];
@@ -73,8 +108,10 @@ OT_HD double spl2_eval(TP tx, int nx, TP ty, int ny, TP c, double inv_h, double 
     const int lx = spl_interval(tx, nx, kx1, inv_h, ax);
     const int ly = spl_interval(ty, ny, ky1, inv_h, ay);
     double hx[KX + 1], hy[KY + 1];
-    fpbspl<KX>(tx, ax, lx, hx);
-    fpbspl<KY>(ty, ay, ly, hy);
+    // first / last equidistant knot (0-based) of each array: the derivative's array is the original minus its two
+    // outer knots, i.e. shifted by one
+    bspl_basis<KX>(tx, KX + 1, nx - KX - 2, ax, lx, hx);
+    bspl_basis<KY>(ty, KY + 1, ny - KY - 2, ay, ly, hy);
     double sp = 0.0;
     int l1 = (lx - kx1) * nky1 + (ly - ky1);
 #pragma unroll
