@@ -642,6 +642,13 @@ extern "C" void ot_sources_destroy(ot_sources* s) {
 #define OT_TRACE_MIN_WAVES 1
 #endif
 
+struct RangeRec {  // one source range in device memory (scenes with more than OT_MAX_RANGES ranges)
+    int64_t first, count;
+    int32_t source;
+    uint32_t n2;
+    double inv_n, inv_n2;
+};
+
 struct RangeArgs {
     int32_t n;
     int32_t source[OT_MAX_RANGES];
@@ -652,9 +659,30 @@ struct RangeArgs {
     uint32_t n2[OT_MAX_RANGES];
     double inv_n[OT_MAX_RANGES];
     double inv_n2[OT_MAX_RANGES];
+    const RangeRec* ext;  // n > OT_MAX_RANGES: n records sorted by `first`, contiguous; the arrays above are unused
 };
 
 OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& k, int& src) {
+    if (rg.ext) {  // many ranges: binary search for the last record starting at or before this ray
+        int lo = 0, hi = rg.n - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (rg.ext[mid].first <= ray)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const RangeRec rr = rg.ext[lo];
+        if (ray < rr.first || ray >= rr.first + rr.count) return false;
+        g.j = (uint32_t)(ray - rr.first);
+        g.n = (uint32_t)rr.count;
+        g.n2 = rr.n2;
+        g.inv_n = rr.inv_n;
+        g.inv_n2 = rr.inv_n2;
+        k = lo;
+        src = rr.source;
+        return true;
+    }
     for (int q = 0; q < rg.n; q++) {
         if (ray >= rg.first[q] && ray < rg.first[q] + rg.count[q]) {
             g.j = (uint32_t)(ray - rg.first[q]);
@@ -893,30 +921,60 @@ __global__ __launch_bounds__(256) void refraction_index_kernel(ot_medium md, con
 // ---------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
-static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot_sources* src, int64_t N, RangeArgs& rg) {
-    if (!ranges || n_ranges < 1 || n_ranges > OT_MAX_RANGES)
-        return fail(OT_ERR_INVALID, "between 1 and 64 source ranges are supported per launch");
+// Fills the kernel argument block; with more than OT_MAX_RANGES ranges the records go to device memory
+// (`ext_out`, to be released with release_ranges after the launch has been enqueued).
+static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot_sources* src, int64_t N, RangeArgs& rg,
+                       RangeRec** ext_out) {
+    *ext_out = nullptr;
+    rg.ext = nullptr;
+    if (!ranges || n_ranges < 1) return fail(OT_ERR_INVALID, "at least one source range is needed");
     rg.n = n_ranges;
+    const bool big = n_ranges > OT_MAX_RANGES;
+    std::vector<RangeRec> recs(big ? n_ranges : 0);
     int64_t covered = 0;
     for (int k = 0; k < n_ranges; k++) {
         if (ranges[k].source < 0 || ranges[k].source >= src->n) return fail(OT_ERR_INVALID, "range: source out of range");
         if (ranges[k].first < 0 || ranges[k].count < 0 || ranges[k].first + ranges[k].count > N)
             return fail(OT_ERR_INVALID, "range outside the ray storage");
         if (ranges[k].count > 0xffffffffll) return fail(OT_ERR_UNSUPPORTED, "more than 2^32 rays in one source range");
-        rg.source[k] = ranges[k].source;
-        rg.first[k] = ranges[k].first;
-        rg.count[k] = ranges[k].count;
         const uint64_t cnt = (uint64_t)ranges[k].count;
         uint32_t n2 = (uint32_t)std::sqrt((double)cnt);
         while ((uint64_t)n2 * n2 > cnt) n2--;
         while ((uint64_t)(n2 + 1) * (n2 + 1) <= cnt) n2++;
-        rg.n2[k] = n2;
-        rg.inv_n[k] = cnt ? 1.0 / (double)cnt : 0.0;
-        rg.inv_n2[k] = n2 ? 1.0 / (double)n2 : 0.0;
+        const double inv_n = cnt ? 1.0 / (double)cnt : 0.0, inv_n2 = n2 ? 1.0 / (double)n2 : 0.0;
+        if (big) {
+            if (ranges[k].first != covered)
+                return fail(OT_ERR_INVALID, "more than 64 source ranges must be sorted and contiguous");
+            recs[k] = {ranges[k].first, ranges[k].count, ranges[k].source, n2, inv_n, inv_n2};
+        } else {
+            rg.source[k] = ranges[k].source;
+            rg.first[k] = ranges[k].first;
+            rg.count[k] = ranges[k].count;
+            rg.n2[k] = n2;
+            rg.inv_n[k] = inv_n;
+            rg.inv_n2[k] = inv_n2;
+        }
         covered += ranges[k].count;
     }
     if (covered != N) return fail(OT_ERR_INVALID, "source ranges must cover all N rays exactly once");
+    if (big) {
+        RangeRec* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, sizeof(RangeRec) * recs.size()));
+        hipError_t e = hipMemcpy(d, recs.data(), sizeof(RangeRec) * recs.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return fail(OT_ERR_HIP, std::string("range upload: ") + hipGetErrorString(e));
+        }
+        rg.ext = d;
+        *ext_out = d;
+    }
     return OT_OK;
+}
+
+static void release_ranges(RangeRec* ext, hipStream_t st) {
+    if (!ext) return;
+    (void)hipStreamSynchronize(st);  // the launch that reads the records has to finish first
+    (void)hipFree(ext);
 }
 
 static int check_rays(const ot_rays* r, bool need_pol) {
@@ -931,13 +989,16 @@ extern "C" int ot_rays_generate(const ot_sources* src, const ot_source_range* ra
     if (!src) return fail(OT_ERR_INVALID, "ot_rays_generate: null sources");
     if (int rc = check_rays(rays, !no_pol)) return rc;
     RangeArgs rg;
-    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg)) return rc;
-    if (rays->N == 0) return OT_OK;
+    RangeRec* ext = nullptr;
+    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg, &ext)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (no_pol)
-        hipLaunchKernelGGL(generate_kernel<false>, grid_for(rays->N), dim3(256), 0, st, *rays, src->d, rg, seed);
-    else
-        hipLaunchKernelGGL(generate_kernel<true>, grid_for(rays->N), dim3(256), 0, st, *rays, src->d, rg, seed);
+    if (rays->N > 0) {
+        if (no_pol)
+            hipLaunchKernelGGL(generate_kernel<false>, grid_for(rays->N), dim3(256), 0, st, *rays, src->d, rg, seed);
+        else
+            hipLaunchKernelGGL(generate_kernel<true>, grid_for(rays->N), dim3(256), 0, st, *rays, src->d, rg, seed);
+    }
+    release_ranges(ext, st);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }
@@ -954,6 +1015,7 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     hipStream_t st = (hipStream_t)stream;
     RangeArgs none;
     none.n = 0;
+    none.ext = nullptr;
     const RangeArgs& r = rg ? *rg : none;
     const SourceDev* sd = src ? src->d : nullptr;
     unsigned long long* m = (unsigned long long*)msgs;
@@ -994,8 +1056,11 @@ extern "C" int ot_generate_and_trace(const ot_scene* scene, const ot_sources* sr
                                      int32_t n_ranges, uint64_t seed, const ot_rays* rays, int64_t* msgs, void* stream) {
     if (!src || !rays) return fail(OT_ERR_INVALID, "ot_generate_and_trace: null argument");
     RangeArgs rg;
-    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg)) return rc;
-    return launch_trace(scene, src, &rg, rays, nullptr, seed, msgs, stream);
+    RangeRec* ext = nullptr;
+    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg, &ext)) return rc;
+    const int rc = launch_trace(scene, src, &rg, rays, nullptr, seed, msgs, stream);
+    release_ranges(ext, (hipStream_t)stream);
+    return rc;
 }
 
 // ---- leaf entry points -------------------------------------------------------------------------------------

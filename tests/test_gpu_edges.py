@@ -114,3 +114,23 @@ def test_many_sources_and_tiny_ranges():
             assert np.all(r.wl_list[sl] == np.float32(450. + 5 * i))
             assert np.allclose(r.p_list[sl, 0, 0], 0.02 * (i - 20), atol=1e-15)
         assert np.all(np.isfinite(r.p_list))
+
+
+def test_more_than_64_sources():
+    """100 sources: the range table moves from the kernel arguments to device memory (binary search per ray)."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -25, 60], seed=12)
+        for i in range(100):
+            RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=2, pos=[0.01 * (i - 50), 0, -20],
+                                power=1.0 + (i % 3), spectrum=ot.LightSpectrum("Monochromatic", wl=400. + 3 * i)))
+        RT.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1,
+                       n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 0]))
+        RT.trace(100_000)
+        r = RT.rays
+        assert r.N_list.shape == (100,) and r.N_list.sum() == 100_000
+        for i in (0, 1, 37, 63, 64, 65, 99):
+            sl = slice(r.B_list[i], r.B_list[i + 1])
+            assert np.all(r.wl_list[sl] == np.float32(400. + 3 * i))
+            assert np.allclose(r.p_list[sl, 0, 0], 0.01 * (i - 50), atol=1e-15)
+            assert abs(r.w_list[sl, 0].astype(np.float64).sum() - (1.0 + (i % 3)) / r.N_list[i] * r.N_list[i]) < 1e-4
+        assert np.all(np.isfinite(r.p_list)) and np.all(r.w_list[:, -1] == 0)
