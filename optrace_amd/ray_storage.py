@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from .base import BaseClass
-from ._device import require_device, stream_ptr, ptr
+from ._device import require_device, stream_ptr
 from ._warn import warning
 from . import misc
 

@@ -21,9 +21,8 @@ import torch
 
 from . import _capi
 from .base import check_type
-from .geometry.elements import Group, Lens, Filter, Aperture, Detector
-from .geometry.surfaces import (Surface, Point, Line, RectangularSurface, SphericalSurface, RingSurface,
-                                SlitSurface)
+from .geometry.elements import Group, Aperture, Detector
+from .geometry.surfaces import Surface, Point, Line, SphericalSurface, RingSurface, SlitSurface
 from .options import global_options
 from .ray_storage import RayStorage
 from .refraction_index import RefractionIndex

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from .geometry.elements import Lens, IdealLens, Filter, Aperture
+from .geometry.elements import Lens, Filter, Aperture
 from .geometry.surfaces import RectangularSurface, RingSurface, SlitSurface
 from .spectrum import LightSpectrum
 

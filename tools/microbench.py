@@ -4,7 +4,7 @@ import ctypes as C
 import sys, pathlib
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
-import numpy as np, torch
+import torch
 import optrace_amd as ot
 from optrace_amd import _capi
 from optrace_amd._device import ptr, stream_ptr
