@@ -2,7 +2,7 @@
 
 Mirror of the parts of optrace/tracer/image/{base_image,rgb_image,grayscale_image}.py and
 optrace/tracer/color/srgb.py that feed `RaySource.create_rays` (ray_source.py:120-146, 233-258).
-Only array input is supported (file decoding needs OpenCV, which is not part of this stack).
+Arrays or image files (decoded with Pillow; the reference uses OpenCV, which is not part of this stack).
 """
 from __future__ import annotations
 
@@ -65,7 +65,7 @@ class _BaseImage(BaseClass):
                  limit: float = None, **kwargs) -> None:
         self._new_lock = False
         if isinstance(data, str):
-            raise NotImplementedError("Loading image files needs OpenCV; pass a numpy array instead.")
+            data = self._load_image(data)
         self._data = data
         if extent is None and s is None:
             raise ValueError("Either s or extent need to be provided for Images")
@@ -84,6 +84,18 @@ class _BaseImage(BaseClass):
         self.limit = limit
         super().__init__(**kwargs)
         self._new_lock = True
+
+    def _load_image(self, path: str) -> np.ndarray:
+        """Image file -> array in [0, 1], element [0, 0] in the lower left corner (base_image.py:67-83).
+        Decoded with Pillow (the reference uses OpenCV, which is not part of this stack): RGB values are
+        identical for lossless formats, the grey conversion is the same ITU-R 601 luma to within one 8-bit level."""
+        from PIL import Image
+        try:
+            with Image.open(path) as im:
+                arr = np.asarray(im.convert("RGB" if self._channels == 3 and type(self).__name__ == "RGBImage" else "L"))
+        except (OSError, ValueError) as err:
+            raise IOError(f"Can't find/process file {path}") from err
+        return np.flipud(arr) / 255.0
 
     @property
     def shape(self):

@@ -247,3 +247,17 @@ def test_render_image_archive_round_trip(tmp_path):
     assert np.array_equal(im2._data, im._data) and im2.limit == im.limit
     with pytest.raises(RuntimeError):
         ot.RenderImage([-1, 1, -1, 1]).save(str(tmp_path / "empty"))
+
+
+def test_image_from_file(tmp_path):
+    """Image sources from files (base_image.py:67-83): element [0, 0] is the lower left corner, values in [0, 1]."""
+    from PIL import Image
+    arr = (np.arange(4 * 6 * 3).reshape(4, 6, 3) * 3).astype(np.uint8)
+    Image.fromarray(arr, "RGB").save(tmp_path / "card.png")
+    img = ot.RGBImage(str(tmp_path / "card.png"), [3, 2])
+    assert img.shape == (4, 6, 3) and np.array_equal(img.data, np.flipud(arr) / 255.0)
+    g = ot.GrayscaleImage(str(tmp_path / "card.png"), [3, 2])
+    luma = np.flipud(arr) @ np.array([0.299, 0.587, 0.114]) / 255.0
+    assert g.shape == (4, 6) and np.abs(g.data - luma).max() <= 1.0 / 255
+    with pytest.raises(IOError):
+        ot.RGBImage(str(tmp_path / "missing.png"), [3, 2])
