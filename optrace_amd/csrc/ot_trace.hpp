@@ -250,8 +250,11 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
 template <bool POL>
 OT_DEV void store_section(const ot_rays& R, uint32_t ray, int sec, const V3& p, float w, double n, float px, float py,
                           float pz) {
-    // (a workgroup-relative form -- SGPR base + threadIdx offset, no 64-bit vector address add -- was measured
-    // 4 % slower: 1.93 vs 1.86 ms on the bench scene)
+    // Measured alternatives on the bench scene: a workgroup-relative form (SGPR base + threadIdx offset, no
+    // 64-bit vector address add) was 4 % slower (1.93 vs 1.86 ms); a wave-tiled layout ([tile of 64 rays]
+    // [section][component][lane] inside each array) made no difference (1.750 vs 1.755 ms) although it wins in
+    // the store-only experiment (tools/experiments/store_pattern.hip) -- so the reference's planar Fortran layout
+    // stays, and host views need no re-ordering.
     const int64_t N = R.N;
     const int64_t nt = R.nt;
     double* __restrict__ p0 = R.p + N * sec;
