@@ -287,9 +287,11 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
                 return fail(OT_ERR_INVALID, "element: unknown kind");
         }
     }
-    bool needs_full = false;  // anything beyond conic/flat lens surfaces and plain apertures
-    for (const StepDev& d : steps)
-        needs_full |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER || d.hurb || surfs[d.surf].kind >= OT_SURF_ASPHERE;
+    bool needs_full = false, needs_numeric = false;  // anything beyond conic/flat lens surfaces and plain apertures
+    for (const StepDev& d : steps) {
+        needs_full |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER || d.hurb;
+        needs_numeric |= surfs[d.surf].kind >= OT_SURF_ASPHERE && !surfs[d.surf].flat;
+    }
     const int nt = (int)steps.size() + 1;  // sections = tracing surfaces + 2, the end aperture being a step
 
     std::vector<FilterDev> filts(desc->n_filters > 0 ? desc->n_filters : 1);
@@ -422,6 +424,7 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     sc->needs_tables = needs_tables;
     sc->cnt_slots = (unsigned int*)(blob + o_cnt);
     sc->needs_full = needs_full;
+    sc->needs_numeric = needs_numeric;
     sc->d = (SceneDev*)(blob + o_hdr);
     sc->blob = blob;
     (void)hipGetDevice(&sc->device);
@@ -736,11 +739,11 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
 // (4 wave64); template switches select a kernel that only contains what the scene needs:
 //   POL  polarisation tracked          GEN  rays generated in registers (no section-0 round trip)
 //   TAB  tabulated media/filters or injected HURB normals (per-lane global loads inside the loop)
-//   FULL numeric (aspheric) surfaces, ideal lenses, filters, HURB; without it the kernel holds only conic /
-//        flat surfaces and apertures: 98 VGPRs instead of 165
+//   FEAT 0: conic / flat surfaces and plain apertures only (82 VGPRs)   1: + ideal lenses, filters, HURB (127)
+//        2: + surfaces that need the numeric hit search: aspheres, tilted, spline surfaces (206)
 // Event counters go wave -> LDS (per workgroup) -> one of OT_CNT_SLOTS global slot tables (blockIdx % slots) ->
 // reduce_counters_kernel, so that no two workgroups hammer the same address (see count_event).
-template <bool POL, bool GEN, int SPEC, bool FULL>
+template <bool POL, bool GEN, int SPEC, int FEAT>
 __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
                                                     const SourceDev* __restrict__ sources, RangeArgs rg,
                                                     const double* __restrict__ hurb_normals, uint64_t seed,
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
         }
     }
     if (have) {
-        bool ok = trace_ray<POL, SPEC, FULL>(sc, R, (uint32_t)ray, r, hurb_normals, seed, cnt, ltab);
+        bool ok = trace_ray<POL, SPEC, FEAT>(sc, R, (uint32_t)ray, r, hurb_normals, seed, cnt, ltab);
         if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)
     }
     __syncthreads();
@@ -1022,7 +1025,7 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     dim3 grid = grid_for(rays->N), block(256);
     // kernel variant: polarisation x on-device generation x spectrum handling x feature set
     const bool tab = sc->needs_tables || hurb_normals != nullptr;
-    const bool full = sc->needs_full;
+    const int feat = sc->needs_numeric ? 2 : (sc->needs_full ? 1 : 0);
     const bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr;  // generated rays only
     const int n_cnt = OT_N_INFOS * sc->h.nt + 1;
     const size_t lds = sizeof(unsigned int) * (size_t)n_cnt +
@@ -1030,7 +1033,7 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     unsigned int* slots = sc->cnt_slots;
 #define OT_LAUNCH(P, G, S, F) \
     hipLaunchKernelGGL((trace_kernel<P, G, S, F>), grid, block, lds, st, sc->d, *rays, sd, r, hurb_normals, seed, slots)
-#define OT_LAUNCH_F(P, G, S) do { if (full) OT_LAUNCH(P, G, S, true); else OT_LAUNCH(P, G, S, false); } while (0)
+#define OT_LAUNCH_F(P, G, S) do { if (feat == 2) OT_LAUNCH(P, G, S, 2); else if (feat == 1) OT_LAUNCH(P, G, S, 1); else OT_LAUNCH(P, G, S, 0); } while (0)
     if (src) {
         if (lines)    { if (pol) OT_LAUNCH_F(true, true, 2); else OT_LAUNCH_F(false, true, 2); }
         else if (tab) { if (pol) OT_LAUNCH_F(true, true, 1); else OT_LAUNCH_F(false, true, 1); }

@@ -91,7 +91,8 @@ struct ot_scene {
     void* blob;        // one device allocation holding all tables
     int device;
     unsigned int* cnt_slots;  // OT_CNT_SLOTS x (5*nt+1) counter slot tables (zero between launches)
-    bool needs_full;   // aspheres, ideal lenses, filters or HURB present: full-feature kernel variant
+    bool needs_full;   // ideal lenses, filters or HURB present: feature level 1 of the kernel variants
+    bool needs_numeric; // aspheric / tilted / spline surfaces present: level 2 (numeric hit search)
     bool needs_tables; // some medium / filter is tabulated (DATA / LINES): per-lane global loads in the loop
 };
 

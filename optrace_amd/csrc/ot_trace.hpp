@@ -150,10 +150,10 @@ OT_DEV double fresnel_T2(double n1, double n2, double ns, double W, double A_ts2
 // Raytracer.__refraction raytracer.py:761-829 for a lane that has power and hit the surface.
 // The new direction s' is computed in the reference's exact operation order (it feeds the next hit mask).
 // Returns true on total internal reflection.
-template <bool POL, bool FULL, class SF>
+template <bool POL, bool NUMERIC, class SF>
 OT_DEV bool refract(SF& sf, RayState& r, const V3& pn, float& wn, float& npx, float& npy, float& npz,
                     double n1, double n2, double N) {  // N = n1 / n2 (raytracer.py:799)
-    V3 n = surf_normal<true, FULL>(sf, pn.x, pn.y);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
+    V3 n = surf_normal<true, NUMERIC>(sf, pn.x, pn.y);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
     V3 s = r.s;
     double ns = dot3(n, s);
     double W = ot_sqrt(1 - N * N * (1 - ns * ns));
@@ -281,10 +281,12 @@ OT_DEV void store_section(const ot_rays& R, uint32_t ray, int sec, const V3& p, 
 //   2  discrete spectrum: n, n1/n2 and filter T of every step were tabulated per line on the host and staged in
 //      LDS (`ltab`); the lane only carries its line index.  Saves the IEEE division n1/n2 and the dispersion
 //      formula per ray-surface and covers "Function" media exactly.
-template <bool POL, int SPEC, bool FULL, class SC>
+template <bool POL, int SPEC, int FEAT, class SC>
 OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const double* __restrict__ hurb_normals,
                       uint64_t seed, unsigned int* msgs, const double* ltab) {
     constexpr bool TAB = (SPEC == 1);
+    constexpr bool FULL = FEAT >= 1;     // ideal lenses, filters, HURB
+    constexpr bool NUMERIC = FEAT >= 2;  // surfaces that need the Illinois search (aspheres, tilted, spline)
     int lj = 0;  // line index of this ray (SPEC == 2)
     if (SPEC == 2) {
         for (int j = 1; j < sc.n_lines; j++)
@@ -312,10 +314,10 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
         V3 ph;
         bool hit = false, ill = false;
         if (hw) {
-            ok &= find_hit<FULL>(sf, r.p, r.s, ph, hit, ill);
+            ok &= find_hit<NUMERIC>(sf, r.p, r.s, ph, hit, ill);
             pn = ph;
         }
-        if (FULL) count_event(msgs, nt, OT_INFO_ILL_COND, i + 1, hw && ill);
+        if (NUMERIC) count_event(msgs, nt, OT_INFO_ILL_COND, i + 1, hw && ill);
         const bool hwh = hw && hit, hwnh = hw && !hit;
         bool tir = false, neg = false, clip = false;
         double n_next = r.n_cur;
@@ -338,7 +340,7 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
                 if (FULL && kind == OT_STEP_IDEAL)
                     refract_ideal<POL>(sf, st, r, pn, npx, npy, npz);
                 else
-                    tir = refract<POL, FULL>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq);
+                    tir = refract<POL, NUMERIC>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq);
             }
             count_event(msgs, nt, OT_INFO_TIR, i, tir);
         } else if (FULL && kind == OT_STEP_FILTER) {  // raytracer.py:379-380
