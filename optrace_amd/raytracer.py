@@ -70,6 +70,7 @@ class Raytracer(Group):
         self._scene_key = None
         self._checked_key = None
         self._rays_known_current = False
+        self._source_cache = None  # (key, SourceTable): device copy of the source records, reused while unchanged
         super().__init__(None, n0, **kwargs)
         self._new_lock = True
 
@@ -340,7 +341,10 @@ class Raytracer(Group):
         seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed) + 1000003 * int(_chunk)
 
         if _initial_rays is None:
-            tab = self.rays._source_table()
+            skey = repr(snap["RaySources"]) + repr(self.rays._powers)
+            if self._source_cache is None or self._source_cache[0] != skey:
+                self._source_cache = (skey, self.rays._source_table())
+            tab = self._source_cache[1]
             rng = self.rays._source_ranges()
             _capi.check(lib.ot_generate_and_trace(self._scene_handle, tab.handle, rng, len(rng), seed,
                                                   C.byref(rays), ptr(msgs), stream_ptr()))
