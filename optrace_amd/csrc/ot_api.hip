@@ -469,7 +469,15 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
 
     std::vector<SourceDev> devs(n_sources);
     std::vector<double> tabs;                 // all tables, offsets resolved after upload
-    std::vector<std::vector<size_t>> offs(n_sources, std::vector<size_t>(6, (size_t)-1));
+    std::vector<std::vector<size_t>> offs(n_sources, std::vector<size_t>(9, (size_t)-1));
+    auto push_pairs = [&](const double* tab, size_t n) {  // x[n] | F[n]  ->  (F_j, x_j) pairs
+        size_t o = tabs.size();
+        for (size_t j = 0; j < n; j++) {
+            tabs.push_back(tab[n + j]);
+            tabs.push_back(tab[j]);
+        }
+        return o;
+    };
     auto push = [&](const double* p, size_t n) {
         size_t o = tabs.size();
         tabs.insert(tabs.end(), p, p + n);
@@ -482,7 +490,7 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
     auto add_guide = [&](const double* F, size_t n, double x0, CdfGuide* dst) {
         const double x1 = F[n - 1];
         size_t K = 16;
-        while (K < n && K < ((size_t)1 << 22)) K <<= 1;
+        while (K < 4 * n && K < ((size_t)1 << 22)) K <<= 1;  // ~4 buckets per table node
         dst->K = (int32_t)K;
         dst->x0 = x0;
         dst->scale = (x1 > x0) ? (double)K / (x1 - x0) : 0.0;
@@ -531,6 +539,7 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             d.n_spec = s.n_spec;
             const double* F = s.spec_tab + s.n_spec;
             add_guide(F, (size_t)s.n_spec, s.spectrum == OT_SPEC_LINES ? 0.0 : F[0], &d.g_spec);
+            if (s.spectrum != OT_SPEC_LINES) offs[i][6] = push_pairs(s.spec_tab, (size_t)s.n_spec);
         }
         if (s.polarization == OT_POL_LIST || s.polarization == OT_POL_TABLE) {
             if (!s.pol_tab || s.n_pol < 1) return fail(OT_ERR_INVALID, "source: polarisation table missing");
@@ -538,12 +547,14 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             d.n_pol = s.n_pol;
             const double* F = s.pol_tab + s.n_pol;
             add_guide(F, (size_t)s.n_pol, s.polarization == OT_POL_LIST ? 0.0 : F[0], &d.g_pol);
+            if (s.polarization != OT_POL_LIST) offs[i][7] = push_pairs(s.pol_tab, (size_t)s.n_pol);
         }
         if (s.divergence == OT_DIV_TABLE) {
             if (!s.div_tab || s.n_div < 2) return fail(OT_ERR_INVALID, "source: divergence table missing");
             offs[i][2] = push(s.div_tab, 2 * (size_t)s.n_div);
             d.n_div = s.n_div;
             add_guide(s.div_tab + s.n_div, (size_t)s.n_div, s.div_tab[s.n_div], &d.g_div);
+            offs[i][8] = push_pairs(s.div_tab, (size_t)s.n_div);
         }
         if (s.shape == OT_SRC_IMAGE_RGB || s.shape == OT_SRC_IMAGE_GRAY) {
             size_t npx = (size_t)s.img_w * (size_t)s.img_h;
@@ -574,7 +585,7 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             }
         }
     }
-    size_t prim_off = (size_t)-1;
+    size_t prim_off = (size_t)-1, prim_pairs_off = (size_t)-1;
     if (any_rgb) {  // inverse-CDF tables of the three primaries over wavelengths(5000) (srgb.py:528, 549-551)
         std::vector<double> prim(3 * 2 * OT_PRIM_N);
         for (int c = 0; c < 3; c++) {
@@ -589,6 +600,8 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             }
         }
         prim_off = push(prim.data(), prim.size());
+        prim_pairs_off = tabs.size();
+        for (int c = 0; c < 3; c++) push_pairs(prim.data() + (size_t)c * 2 * OT_PRIM_N, OT_PRIM_N);
         for (int i = 0; i < n_sources; i++)
             if (sources[i].shape == OT_SRC_IMAGE_RGB)
                 for (int c = 0; c < 3; c++) {
@@ -612,6 +625,10 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
         if (offs[i][3] != (size_t)-1) d.img_cdf = dtab + offs[i][3];
         if (offs[i][4] != (size_t)-1) d.img_rgb = dtab + offs[i][4];
         if (prim_off != (size_t)-1) d.prim_tab = dtab + prim_off;
+        if (prim_pairs_off != (size_t)-1) d.prim_pairs = dtab + prim_pairs_off;
+        if (offs[i][6] != (size_t)-1) d.spec_pairs = dtab + offs[i][6];
+        if (offs[i][7] != (size_t)-1) d.pol_pairs = dtab + offs[i][7];
+        if (offs[i][8] != (size_t)-1) d.div_pairs = dtab + offs[i][8];
     }
     std::vector<char> host(total, 0);
     std::memcpy(host.data(), devs.data(), sizeof(SourceDev) * n_sources);

@@ -202,18 +202,31 @@ OT_DEV double inv_cdf_discrete(const double* __restrict__ tab, int n, double X, 
     return tab[cdf_index_discrete(tab + n, n, X, G)];
 }
 
-// kind="continuous": linear interpolation of the inverse cumulative-trapezoid table; tab = n x then n F
+// kind="continuous": linear interpolation of the inverse cumulative-trapezoid table (random.py:150-157).
+// pairs = (F_0, x_0, F_1, x_1, ...): the start hint gives a node at or just before X; its pair and the next one
+// come in with one 32-byte load, stepping is rare with four hint buckets per table node.
 template <class GD>
-OT_DEV double inv_cdf_linear(const double* __restrict__ tab, int n, double X, GD& G) {
-    const double* F = tab + n;
+OT_DEV double inv_cdf_linear(const double* __restrict__ pairs, int n, double X, GD& G) {
     int lo = guide_start(G, X);  // largest j <= n - 2 with F[j] <= X
     if (lo > n - 2) lo = n - 2;
-    while (lo < n - 2 && F[lo + 1] <= X) lo++;
-    while (lo > 0 && F[lo] > X) lo--;
-    const int hi = lo + 1;
-    double dF = F[hi] - F[lo];
-    if (!(dF > 0)) return tab[lo];
-    return tab[lo] + (X - F[lo]) / dF * (tab[hi] - tab[lo]);
+    double F0 = pairs[2 * lo], x0 = pairs[2 * lo + 1], F1 = pairs[2 * lo + 2], x1 = pairs[2 * lo + 3];
+    while (lo < n - 2 && F1 <= X) {
+        lo++;
+        F0 = F1;
+        x0 = x1;
+        F1 = pairs[2 * lo + 2];
+        x1 = pairs[2 * lo + 3];
+    }
+    while (lo > 0 && F0 > X) {
+        lo--;
+        F1 = F0;
+        x1 = x0;
+        F0 = pairs[2 * lo];
+        x0 = pairs[2 * lo + 1];
+    }
+    double dF = F1 - F0;
+    if (!(dF > 0)) return x0;
+    return x0 + (X - F0) / dF * (x1 - x0);
 }
 
 struct NewRay {
@@ -248,7 +261,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
             default: {
                 const double* F = src.spec_tab + src.n_spec;
                 double X = strat_interval(g, ST_WL, F[0], F[src.n_spec - 1]);
-                wl = inv_cdf_linear(src.spec_tab, (int)src.n_spec, X, src.g_spec);
+                wl = inv_cdf_linear(src.spec_pairs, (int)src.n_spec, X, src.g_spec);
             }
         }
     }
@@ -298,7 +311,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 const double* tab = src.prim_tab + (size_t)prim * 2 * OT_PRIM_N;
                 const double* F = tab + OT_PRIM_N;
                 double X = strat_interval(g, ST_RGB_WL, F[0], F[OT_PRIM_N - 1]);
-                wl = inv_cdf_linear(tab, OT_PRIM_N, X, src.g_prim[prim]);
+                wl = inv_cdf_linear(src.prim_pairs + (size_t)prim * 2 * OT_PRIM_N, OT_PRIM_N, X, src.g_prim[prim]);
             }
         }
     }
@@ -344,7 +357,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 default: {
                     const double* F = src.div_tab + src.n_div;
                     double X2 = strat_interval(g, ST_DIV, F[0], F[src.n_div - 1]);
-                    theta = inv_cdf_linear(src.div_tab, (int)src.n_div, X2, src.g_div);
+                    theta = inv_cdf_linear(src.div_pairs, (int)src.n_div, X2, src.g_div);
                     sincos(theta, &st, &ct);
                 }
             }
@@ -364,7 +377,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 default: {
                     const double* F = src.div_tab + src.n_div;
                     double X0 = r * r / (src.div_sin * src.div_sin);
-                    double theta = inv_cdf_linear(src.div_tab, (int)src.n_div, F[0] + X0 * (F[src.n_div - 1] - F[0]), src.g_div);
+                    double theta = inv_cdf_linear(src.div_pairs, (int)src.n_div, F[0] + X0 * (F[src.n_div - 1] - F[0]), src.g_div);
                     sincos(theta, &st, &ct);
                 }
             }
@@ -396,7 +409,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
             }
             default: {
                 const double* F = src.pol_tab + src.n_pol;
-                double ang = inv_cdf_linear(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, F[0], F[src.n_pol - 1]), src.g_pol);
+                double ang = inv_cdf_linear(src.pol_pairs, (int)src.n_pol, strat_interval(g, ST_POL, F[0], F[src.n_pol - 1]), src.g_pol);
                 sincos(ang, &sn, &cs);
             }
         }

@@ -128,6 +128,9 @@ struct SourceDev {
     const double* img_rgb;      // per pixel cumulative primary mix: (r, r+g) / (r+g+b), 2 per pixel
     const double* prim_tab;     // inverse-CDF tables of the three sRGB primaries: 3 x (PRIM_N wl, PRIM_N cdf)
     CdfGuide g_spec, g_pol, g_div, g_img, g_prim[3];
+    // the continuous inverse-CDF tables once more as (F_j, x_j) pairs: the two nodes an interpolation needs sit in
+    // one 32-byte load, which also decides whether the search has to step (see inv_cdf_linear)
+    const double *spec_pairs, *pol_pairs, *div_pairs, *prim_pairs;
 };
 
 struct ot_sources {
