@@ -207,6 +207,7 @@ OT_DEV double inv_cdf_discrete(const double* __restrict__ tab, int n, double X, 
 // come in with one 32-byte load, stepping is rare with four hint buckets per table node.
 template <class GD>
 OT_DEV double inv_cdf_linear(const double* __restrict__ pairs, int n, double X, GD& G) {
+    if (n < 2) return pairs[1];
     int lo = guide_start(G, X);  // largest j <= n - 2 with F[j] <= X
     if (lo > n - 2) lo = n - 2;
     double F0 = pairs[2 * lo], x0 = pairs[2 * lo + 1], F1 = pairs[2 * lo + 2], x1 = pairs[2 * lo + 3];
