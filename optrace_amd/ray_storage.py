@@ -69,7 +69,7 @@ class RayStorage(BaseClass):
 
     # ---- allocation (ray_storage.py:35-90) ---------------------------------------------------------
     def init(self, ray_source_list: list, N: int, nt: int, no_pol: bool, _single_power: float = None,
-             _N_list=None) -> None:
+             _N_list=None, _rng=None) -> None:
         self._lock = False
         self.no_pol = no_pol
         assert N >= 0 and nt >= 0 and len(ray_source_list)
@@ -80,7 +80,8 @@ class RayStorage(BaseClass):
         P_all = np.sum(P_list)
         self.N_list = (N * P_list / P_all).astype(int)
         dN = N - np.sum(self.N_list)
-        index_add = np.random.choice(self.N_list.shape[0], size=dN, p=P_list / P_all)
+        # (a seeded tracer passes its own generator, so that the split repeats with the seed)
+        index_add = (np.random if _rng is None else _rng).choice(self.N_list.shape[0], size=dN, p=P_list / P_all)
         np.add.at(self.N_list, index_add, np.ones(index_add.shape))
         if _N_list is not None:  # parity runs: the split the recorded rays were created with
             self.N_list = np.asarray(_N_list).astype(int)

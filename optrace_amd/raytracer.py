@@ -334,7 +334,8 @@ class Raytracer(Group):
 
         scene = self._compile(snap)
         assert scene.nt == nt
-        self.rays.init(self.ray_sources, N, nt, self.no_pol, _N_list=_N_list)
+        rng = None if self.seed is None else np.random.RandomState((int(self.seed) + 1000003 * int(_chunk)) % 2 ** 32)
+        self.rays.init(self.ray_sources, N, nt, self.no_pol, _N_list=_N_list, _rng=rng)
         rays = self.rays._rays_struct()
         msgs = torch.zeros(len(self.INFOS) * nt + 1, dtype=torch.int64, device=dev)
         # a seeded tracer repeats itself call for call; the chunks of one iterative render must differ

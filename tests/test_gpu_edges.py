@@ -134,3 +134,23 @@ def test_more_than_64_sources():
             assert np.allclose(r.p_list[sl, 0, 0], 0.01 * (i - 50), atol=1e-15)
             assert abs(r.w_list[sl, 0].astype(np.float64).sum() - (1.0 + (i % 3)) / r.N_list[i] * r.N_list[i]) < 1e-4
         assert np.all(np.isfinite(r.p_list)) and np.all(r.w_list[:, -1] == 0)
+
+
+def test_seeded_tracer_repeats_including_the_source_split():
+    """Three sources of unequal power and a ray count that does not divide: the random remainder of the split
+    (ray_storage.py:63-68) follows the tracer's seed as well."""
+    def build(seed):
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -25, 60], seed=seed)
+        for i, pw in enumerate((1.0, 2.5, 0.7)):
+            RT.add(ot.RaySource(ot.CircularSurface(r=0.5), divergence="Lambertian", div_angle=3, pos=[i - 1, 0, -20],
+                                power=pw, spectrum=ot.presets.light_spectrum.d65))
+        RT.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1,
+                       n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 0]))
+        return RT
+    with ot.global_options.no_warnings():
+        a, b, c = build(5), build(5), build(6)
+        for RT in (a, b, c):
+            RT.trace(10007)
+    assert np.array_equal(a.rays.N_list, b.rays.N_list) and a.rays.N_list.sum() == 10007
+    assert np.array_equal(a.rays.p_list, b.rays.p_list) and np.array_equal(a.rays.wl_list, b.rays.wl_list)
+    assert not np.array_equal(a.rays.p_list[:100], c.rays.p_list[:100])
