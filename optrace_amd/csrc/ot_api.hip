@@ -1179,8 +1179,18 @@ extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t coun
     const SurfDev& d = ls.d;
     if (count == 0) return OT_OK;
     double R = detector->R;
-    hipLaunchKernelGGL(detector_kernel, grid_for(count), dim3(256), 0, (hipStream_t)stream, *rays, first, count, d, R,
-                       projection, ph, hw, extent4, (unsigned long long*)ill_count);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* slots = nullptr;
+    if (extent4) {  // stream-ordered scratch for the extent slot tables
+        HIP_TRY(hipMallocAsync((void**)&slots, sizeof(unsigned long long) * 4 * OT_EXT_SLOTS, st));
+        hipLaunchKernelGGL(extent_init_kernel, dim3(1), dim3(4 * OT_EXT_SLOTS), 0, st, slots);
+    }
+    hipLaunchKernelGGL(detector_kernel, grid_for(count), dim3(256), 0, st, *rays, first, count, d, R, projection, ph, hw,
+                       slots, (unsigned long long*)ill_count);
+    if (extent4) {
+        hipLaunchKernelGGL(extent_final_kernel, dim3(1), dim3(64), 0, st, slots, extent4);
+        HIP_TRY(hipFreeAsync(slots, st));
+    }
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

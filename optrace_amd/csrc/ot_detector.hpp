@@ -27,6 +27,42 @@ OT_DEV void atomic_max_f64(double* addr, double v) {
     }
 }
 
+// Order-preserving map double -> uint64 (and back): min / max of doubles become single hardware integer atomics
+// (global_atomic_umin_x2 / umax_x2) instead of compare-and-swap loops on a plain, possibly stale, load.
+OT_HD unsigned long long f64_to_ordered(double d) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &d, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+OT_HD double ordered_to_f64(unsigned long long u) {
+    u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+    double d;
+    __builtin_memcpy(&d, &u, 8);
+    return d;
+}
+
+#define OT_EXT_SLOTS 64  // extent slot tables: workgroup b updates table b % 64 (four ordered values each)
+
+__global__ void extent_init_kernel(unsigned long long* __restrict__ slots) {
+    const int i = threadIdx.x;  // 4 * OT_EXT_SLOTS threads
+    slots[i] = (i & 1) ? 0ull : ~0ull;  // max entries start at the smallest, min entries at the largest code
+}
+
+// extent4 = combine(extent4, all slot tables): x_min, x_max, y_min, y_max
+__global__ void extent_final_kernel(const unsigned long long* __restrict__ slots, double* __restrict__ extent4) {
+    const int c = threadIdx.x;
+    if (c >= 4) return;
+    double v = extent4[c];
+    for (int k = 0; k < OT_EXT_SLOTS; k++) {
+        const unsigned long long u = slots[4 * k + c];
+        if (u == ((c & 1) ? 0ull : ~0ull)) continue;  // untouched
+        const double d = ordered_to_f64(u);
+        v = (c & 1) ? fmax(v, d) : fmin(v, d);
+    }
+    extent4[c] = v;
+}
+
 OT_DEV double wave_min(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
@@ -91,7 +127,8 @@ OT_DEV V3 section_dir(const ot_rays& R, int64_t r, int k) {
 // ill_count[0] += ill-conditioned rays, ill_count[1] += rays whose numeric hit search timed out.
 __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first, int64_t count, SurfDev det, double Rcurv,
                                                        int projection, double* __restrict__ ph_out, float* __restrict__ hw_out,
-                                                       double* __restrict__ extent4, unsigned long long* __restrict__ ill_count) {
+                                                       unsigned long long* __restrict__ ext_slots,
+                                                       unsigned long long* __restrict__ ill_count) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = q < count;
     const int64_t r = first + (active ? q : 0);
@@ -167,15 +204,26 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
         if (m_ill) atomicAdd(&ill_count[0], (unsigned long long)__popcll(m_ill));
         if (m_to) atomicAdd(&ill_count[1], (unsigned long long)__popcll(m_to));
     }
-    if (extent4) {
+    if (ext_slots) {  // extent of the valid hits: wave shuffle -> LDS across the four waves -> one slot table
         const double inf = __builtin_inf();
-        double xmin = wave_min(valid ? ph.x : inf), xmax = wave_max(valid ? ph.x : -inf);
-        double ymin = wave_min(valid ? ph.y : inf), ymax = wave_max(valid ? ph.y : -inf);
-        if (lane == 0 && xmin <= xmax) {
-            atomic_min_f64(&extent4[0], xmin);
-            atomic_max_f64(&extent4[1], xmax);
-            atomic_min_f64(&extent4[2], ymin);
-            atomic_max_f64(&extent4[3], ymax);
+        __shared__ double sext[4][4];
+        double e[4] = {wave_min(valid ? ph.x : inf), wave_max(valid ? ph.x : -inf), wave_min(valid ? ph.y : inf),
+                       wave_max(valid ? ph.y : -inf)};
+        const int wave = threadIdx.x >> 6;
+        if (lane == 0)
+            for (int c = 0; c < 4; c++) sext[wave][c] = e[c];
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int c = threadIdx.x;
+            double v = sext[0][c];
+            for (int k = 1; k < 4; k++) v = (c & 1) ? fmax(v, sext[k][c]) : fmin(v, sext[k][c]);
+            if (v == v && v != ((c & 1) ? -inf : inf)) {
+                unsigned long long* dst = ext_slots + 4 * (blockIdx.x % OT_EXT_SLOTS) + c;
+                if (c & 1)
+                    atomicMax(dst, f64_to_ordered(v));
+                else
+                    atomicMin(dst, f64_to_ordered(v));
+            }
         }
     }
 }
