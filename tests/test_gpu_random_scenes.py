@@ -9,76 +9,12 @@ import optrace_amd as ot
 from optrace_amd.scene import CompiledScene
 
 import oracle_bridge as ob
+import scenes
 
 pytestmark = pytest.mark.gpu
 
 
-def random_surface(rng, r):
-    kind = rng.integers(0, 5)
-    if kind == 0:
-        return ot.CircularSurface(r=r)
-    if kind == 1:
-        R = rng.choice([-1, 1]) * rng.uniform(2.5 * r, 12 * r)
-        return ot.SphericalSurface(r=r, R=R)
-    if kind == 2:
-        R = rng.choice([-1, 1]) * rng.uniform(3 * r, 12 * r)
-        return ot.ConicSurface(r=r, R=R, k=rng.uniform(-3, 0.8))
-    if kind == 3:
-        R = rng.choice([-1, 1]) * rng.uniform(4 * r, 12 * r)
-        return ot.AsphericSurface(r=r, R=R, k=rng.uniform(-1, 0.3),
-                                  coeff=[rng.uniform(-2e-3, 2e-3) / r, rng.uniform(-2e-4, 2e-4) / r ** 3])
-    th, ph = rng.uniform(0, 12), rng.uniform(0, 360)
-    return ot.TiltedSurface(r=r, normal_sph=[th, ph])
-
-
-def random_medium(rng):
-    kind = rng.integers(0, 4)
-    if kind == 0:
-        return ot.RefractionIndex("Constant", n=rng.uniform(1.3, 1.9))
-    if kind == 1:
-        return ot.RefractionIndex("Abbe", n=rng.uniform(1.45, 1.8), V=rng.uniform(25, 70))
-    if kind == 2:
-        return ot.RefractionIndex("Cauchy", coeff=[rng.uniform(1.4, 1.7), rng.uniform(0.002, 0.01), 0, 0])
-    return ot.RefractionIndex("Sellmeier1", coeff=[1.03961212, 0.00600069867, 0.231792344, 0.0200179144, 1.01046945,
-                                                   103.560653])
-
-
-def random_scene(seed):
-    rng = np.random.default_rng(seed)
-    RT = ot.Raytracer(outline=[-12, 12, -12, 12, -30, 120], no_pol=bool(rng.integers(0, 2)),
-                      n0=ot.RefractionIndex("Constant", n=rng.choice([1.0, 1.0, 1.33])), seed=seed)
-    spec = [ot.LightSpectrum("Monochromatic", wl=float(rng.uniform(420, 680))), ot.presets.light_spectrum.d65,
-            ot.LightSpectrum("Lines", lines=[450., 550., 650.], line_vals=[1., 2., 1.]),
-            ot.LightSpectrum("Rectangle", wl0=450., wl1=650.)][rng.integers(0, 4)]
-    if rng.integers(0, 2):
-        RT.add(ot.RaySource(ot.CircularSurface(r=rng.uniform(0.5, 2.5)), divergence="Lambertian",
-                            div_angle=rng.uniform(1, 6), pos=[0, 0, -20], spectrum=spec,
-                            polarization=["x", "y", "Uniform"][rng.integers(0, 3)]))
-    else:
-        RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=rng.uniform(3, 9), pos=[rng.uniform(-1, 1), 0, -25],
-                            spectrum=spec))
-    z = 0.0
-    for _ in range(rng.integers(2, 6)):
-        what = rng.integers(0, 10)
-        r = rng.uniform(2.5, 5.0)
-        if what < 6:
-            RT.add(ot.Lens(random_surface(rng, r), random_surface(rng, r), de=rng.uniform(0.3, 1.0), pos=[0, 0, z],
-                           n=random_medium(rng), n2=random_medium(rng) if rng.integers(0, 4) == 0 else None))
-            z += rng.uniform(9, 16)
-        elif what == 6:
-            RT.add(ot.Aperture(ot.RingSurface(r=r + 1, ri=rng.uniform(0.8, 2.5)), pos=[0, 0, z]))
-            z += rng.uniform(3, 6)
-        elif what == 7:
-            RT.add(ot.Filter(ot.CircularSurface(r=r), pos=[0, 0, z],
-                             spectrum=ot.TransmissionSpectrum("Rectangle", wl0=430., wl1=640., val=0.8)))
-            z += rng.uniform(3, 6)
-        elif what == 8:
-            RT.add(ot.IdealLens(r=r, D=float(rng.choice([-1, 1]) * rng.uniform(15, 60)), pos=[0, 0, z]))
-            z += rng.uniform(6, 12)
-        else:
-            RT.add(ot.Aperture(ot.SlitSurface(dim=[2 * r, 2 * r], dimi=[rng.uniform(0.5, 2), rng.uniform(1, 3)]), pos=[0, 0, z]))
-            z += rng.uniform(3, 6)
-    return RT
+random_scene = lambda seed: scenes.random_scene(ot, seed, seed=seed)
 
 
 @pytest.mark.parametrize("seed", range(24))
