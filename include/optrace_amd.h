@@ -414,9 +414,11 @@ int ot_spectrum_histogram(int64_t n, const float* wl, const float* w, const floa
  * ot_focus_cost: cost function __focus_search_cost_function (raytracer.py:1354-1418) of the kept rays at the nz
  *   positions z[] (host array), mode OT_FOCUS_*; cost[nz] (device).  n_px = image side for the image methods
  *   (100 * int(1 + sqrt(N) / 1500), made odd), workspace (device) >= OT_FOCUS_WS + n_px * n_px doubles.
- * ot_focus_moments: sums[8] (device) for __focus_rms_spot_direct_solution (raytracer.py:1420-1460) and the mean
- *   position: [0..4] = sum w, w pa_x, w pa_y, w sb_x, w sb_y; [5] = sum w^2 (dtx^2 + dty^2);
- *   [6] = sum w^2 (dtx dx + dty dy) for the bounds b0 < b1. */
+ * ot_focus_moments: sums[16] (device) for __focus_rms_spot_direct_solution (raytracer.py:1420-1460), the mean
+ *   position and the RMS cost curve: [0..4] = sum w, w pa_x, w pa_y, w sb_x, w sb_y; [5] = sum w^2 (dtx^2 + dty^2);
+ *   [6] = sum w^2 (dtx dx + dty dy) for the bounds b0 < b1; [7] = sum w^2; [8..10] = sum w x0'^2, w x0' sbx', w sbx'^2
+ *   with x0' = pa_x + sb_x z0 - mean, sbx' = sb_x - mean, z0 = (b0 + b1) / 2, [11..13] the same in y: the weighted
+ *   variance at any z is ([8] + 2 (z - z0) [9] + (z - z0)^2 [10]) / ([0] - [7] / [0]) (np.cov with aweights). */
 #define OT_FOCUS_RMS 0
 #define OT_FOCUS_IRR_VAR 1
 #define OT_FOCUS_SHARPNESS 2

@@ -1400,7 +1400,7 @@ extern "C" int ot_focus_moments(int64_t count, const double* pasb, const float* 
     if (count < 1 || !pasb || !w || !sums || !(b1 > b0)) return fail(OT_ERR_INVALID, "ot_focus_moments: bad argument");
     if (int rc = require_device()) return rc;
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 8, st));
+    HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 16, st));
     const unsigned gs = stream_blocks(count, 256, 8);
     hipLaunchKernelGGL(focus_moments1_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, sums);
     hipLaunchKernelGGL(focus_moments2_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, b0, b1, sums);

@@ -299,7 +299,7 @@ __global__ void focus_finalize_kernel(int mode, int npx, const double* __restric
 // sum w^2 (dtx dx + dty dy) into sums[5], sums[6].
 __global__ __launch_bounds__(256) void focus_moments1_kernel(int64_t n, const double* __restrict__ pasb, const float* __restrict__ w,
                                                              double* __restrict__ sums) {
-    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float wf = w[i];
@@ -310,13 +310,18 @@ __global__ __launch_bounds__(256) void focus_moments1_kernel(int64_t n, const do
         acc[2] += pasb[i + n] * wd;
         acc[3] += pasb[i + 2 * n] * wd;
         acc[4] += pasb[i + 3 * n] * wd;
+        acc[5] += wd * wd;
     }
-    __shared__ int sslot[5];
+    __shared__ int sslot[6];
     if (threadIdx.x < 5) sslot[threadIdx.x] = threadIdx.x;
+    if (threadIdx.x == 5) sslot[5] = 7;
     __syncthreads();
-    block_atomic_add<5>(acc, sums, sslot);
+    block_atomic_add<6>(acc, sums, sslot);
 }
 
+// second pass: the two sums of the direct solution (sums[5], sums[6]) and the centred second moments of the hit
+// line about the weighted mean line, taken at z0 = (b0 + b1) / 2 (sums[8..13]): with x'(z) = x0' + sb' (z - z0),
+// sum w x'^2 = S8 + 2 (z - z0) S9 + (z - z0)^2 S10 for every z -- the whole RMS cost curve from one pass.
 __global__ __launch_bounds__(256) void focus_moments2_kernel(int64_t n, const double* __restrict__ pasb, const float* __restrict__ w,
                                                              double b0, double b1, double* __restrict__ sums) {
     const double sw = sums[0];
@@ -325,22 +330,30 @@ __global__ __launch_bounds__(256) void focus_moments2_kernel(int64_t n, const do
     const double pb0x = mpx + msx * b0, pb0y = mpy + msy * b0;
     const double pb1x = mpx + msx * b1, pb1y = mpy + msy * b1;
     const double vz = b1 - b0, vxz = (pb1x - pb0x) / vz, vyz = (pb1y - pb0y) / vz;
-    double acc[2] = {0.0, 0.0};
+    const double z0 = 0.5 * (b0 + b1);
+    const double m0x = mpx + msx * z0, m0y = mpy + msy * z0;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float wf = w[i];
         if (wf < 0.f) continue;
+        const double pax = pasb[i], pay = pasb[i + n], sbx = pasb[i + 2 * n], sby = pasb[i + 3 * n];
         double wd = (double)wf, w2 = wd * wd;
-        double dx = pasb[i] - pb0x, dy = pasb[i + n] - pb0y;
-        double dtx = pasb[i + 2 * n] - vxz, dty = pasb[i + 3 * n] - vyz;
+        double dx = pax - pb0x, dy = pay - pb0y;
+        double dtx = sbx - vxz, dty = sby - vyz;
         acc[0] += w2 * (dtx * dtx) + w2 * (dty * dty);
         acc[1] += dtx * dx * w2 + dty * dy * w2;
+        const double x0 = (pax + sbx * z0) - m0x, y0 = (pay + sby * z0) - m0y, sx = sbx - msx, sy = sby - msy;
+        acc[2] += wd * (x0 * x0);
+        acc[3] += wd * (x0 * sx);
+        acc[4] += wd * (sx * sx);
+        acc[5] += wd * (y0 * y0);
+        acc[6] += wd * (y0 * sy);
+        acc[7] += wd * (sy * sy);
     }
-    __shared__ int sslot[2];
-    if (threadIdx.x == 0) {
-        sslot[0] = 5;
-        sslot[1] = 6;
-    }
+    __shared__ int sslot[8];
+    if (threadIdx.x < 2) sslot[threadIdx.x] = 5 + threadIdx.x;
+    if (threadIdx.x >= 2 && threadIdx.x < 8) sslot[threadIdx.x] = 6 + threadIdx.x;
     __syncthreads();
-    block_atomic_add<2>(acc, sums, sslot);
+    block_atomic_add<8>(acc, sums, sslot);
 }

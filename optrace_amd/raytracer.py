@@ -562,8 +562,20 @@ class Raytracer(Group):
         N_px = N_px if N_px % 2 else N_px + 1
         ws = torch.empty(_capi.FOCUS_WS + N_px * N_px, dtype=torch.float64, device=dev)
 
+        # weighted moments of the hit lines: mean line, direct RMS solution, and the whole RMS cost curve
+        sums = torch.empty(16, dtype=torch.float64, device=dev)
+        _capi.check(lib.ot_focus_moments(n, ptr(pasb), ptr(w), bounds[0], bounds[1], ptr(sums), stream_ptr()))
+        sm = sums.cpu().numpy()
+
         def cost_at(zs: np.ndarray) -> np.ndarray:
             zs = np.ascontiguousarray(zs, dtype=np.float64)
+            if mode == 0:
+                # RMS spot size sqrt(var_x + var_y) with np.cov(aweights) normalisation (raytracer.py:1376-1379):
+                # the centred second moments are quadratic in z, one pass over the rays serves every z
+                dz = zs - 0.5 * (bounds[0] + bounds[1])
+                fact = sm[0] - sm[7] / sm[0]
+                var = (sm[8] + sm[11] + 2 * dz * (sm[9] + sm[12]) + dz ** 2 * (sm[10] + sm[13])) / fact
+                return np.sqrt(np.maximum(var, 0.0))
             out = torch.empty(zs.shape[0], dtype=torch.float64, device=dev)
             _capi.check(lib.ot_focus_cost(n, ptr(pasb), ptr(w), mode,
                                           zs.ctypes.data_as(C.POINTER(C.c_double)), zs.shape[0], N_px, ptr(ws), ptr(out),
@@ -578,10 +590,6 @@ class Raytracer(Group):
                 dba = (bounds[1] - bounds[0]) / Nt
                 r = np.linspace(bounds[0], bounds[1] - dba, Nt) + np.random.uniform(0., dba, Nt)
             vals = cost_at(r)
-
-        sums = torch.empty(8, dtype=torch.float64, device=dev)
-        _capi.check(lib.ot_focus_moments(n, ptr(pasb), ptr(w), bounds[0], bounds[1], ptr(sums), stream_ptr()))
-        sm = sums.cpu().numpy()
 
         if method == "RMS Spot Size":
             # direct solution, extended by ray weights (raytracer.py:1420-1460)

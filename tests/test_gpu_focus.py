@@ -127,3 +127,31 @@ def test_focus_errors():
         RT2.trace(3000)
         res, d = RT2.focus_search("RMS Spot Size", 20.)
         assert d["N"] == 0 and np.all(np.isnan(d["pos"]))
+
+
+def test_rms_closed_form_equals_per_sample_kernel():
+    """The RMS cost curve from the quadratic moment form against the two-pass kernel evaluation (ot_focus_cost)."""
+    import ctypes as C
+    from optrace_amd import _capi
+    from optrace_amd._device import ptr, stream_ptr
+    lib = _capi.load_library()
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, seed=5)
+        RT.trace(300_000)
+        zs = np.linspace(146., 165., 97)
+        res, d = RT.focus_search("RMS Spot Size", 150., return_cost=True, _z_samples=zs)
+        # the same lines through the per-sample kernels
+        b = d["bounds"]
+        n = RT.rays.N
+        pasb = torch.empty(4 * n, dtype=torch.float64, device="cuda")
+        w = torch.empty(n, dtype=torch.float32, device="cuda")
+        nu = torch.empty(1, dtype=torch.int64, device="cuda")
+        rays = RT.rays._rays_struct()
+        _capi.check(lib.ot_focus_prepare(C.byref(rays), 0, n, b[0] + RT.N_EPS, ptr(pasb), ptr(w), ptr(nu), stream_ptr()))
+        ws = torch.empty(_capi.FOCUS_WS + 4, dtype=torch.float64, device="cuda")
+        out = torch.empty(zs.shape[0], dtype=torch.float64, device="cuda")
+        _capi.check(lib.ot_focus_cost(n, ptr(pasb), ptr(w), 0, zs.ctypes.data_as(C.POINTER(C.c_double)), zs.shape[0], 2,
+                                      ptr(ws), ptr(out), stream_ptr()))
+    ref = out.cpu().numpy()
+    assert np.all(np.abs(d["cost"] - ref) <= 1e-9 * ref), np.abs(d["cost"] / ref - 1).max()
+    assert d["cost"].min() >= res.fun * (1 - 1e-9)
