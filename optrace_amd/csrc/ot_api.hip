@@ -811,6 +811,9 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
             }
         }
     }
+    // RaySource.create_rays raises if any generated direction has s_z <= 0 (ray_source.py:353).  Reported as
+    // counter (HURB_NEG_DIR, section 0), a cell no tracing event can touch; the host turns it into that error.
+    if (GEN) count_event(cnt, sc.nt, OT_INFO_HURB_NEG_DIR, 0, have && !(r.s.z > 0));
     if (have) {
         bool ok = trace_ray<POL, SPEC, FEAT>(sc, R, (uint32_t)ray, r, hurb_normals, seed, cnt, ltab);
         if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)

@@ -118,5 +118,7 @@ def create_rays(source, N: int, no_pol: bool = False, power: float = None):
     st.generate(seed=None)
     p = st.p_list[:, 0]
     s = st.s0_list
+    if np.any(s[:, 2] <= 0):  # ray_source.py:353
+        raise RuntimeError("All ray divergences s need to be in positive z-divergence")
     pols = st.pol_list[:, 0].astype(np.float64) if not no_pol else np.broadcast_to(np.nan, p.shape)
     return p, s, pols, st.w_list[:, 0], st.wl_list.astype(np.float64)

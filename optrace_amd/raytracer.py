@@ -362,6 +362,9 @@ class Raytracer(Group):
         if msgs_h[-1]:
             raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
         self._msgs = msgs_h[:-1].reshape(len(self.INFOS), nt).astype(int)
+        if self._msgs[self.INFOS.HURB_NEG_DIR, 0]:  # generation reports directions with s_z <= 0 in this cell
+            self._msgs[self.INFOS.HURB_NEG_DIR, 0] = 0
+            raise RuntimeError("All ray divergences s need to be in positive z-divergence")
         self._show_messages(N)
         snap["Rays"] = [self.rays.N, self.rays.Nt, self.rays.no_pol]
         self._last_trace_snapshot = snap

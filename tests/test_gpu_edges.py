@@ -154,3 +154,20 @@ def test_seeded_tracer_repeats_including_the_source_split():
     assert np.array_equal(a.rays.N_list, b.rays.N_list) and a.rays.N_list.sum() == 10007
     assert np.array_equal(a.rays.p_list, b.rays.p_list) and np.array_equal(a.rays.wl_list, b.rays.wl_list)
     assert not np.array_equal(a.rays.p_list[:100], c.rays.p_list[:100])
+
+
+def test_backward_directions_raise_like_create_rays():
+    """A cone wide enough to reach s_z <= 0 (ray_source.py:353): RuntimeError from trace() and from create_rays()."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -25, 60], seed=2)
+        rs = ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=80, pos=[0, 0, -20], s=[0.8, 0, 0.6])
+        RT.add(rs)
+        RT.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1,
+                       n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 0]))
+        with pytest.raises(RuntimeError, match="positive z"):
+            RT.trace(20000)
+        with pytest.raises(RuntimeError, match="positive z"):
+            rs.create_rays(20000)
+        rs.div_angle = 20  # inside the forward half space again
+        RT.trace(20000)
+        assert RT._msgs[RT.INFOS.HURB_NEG_DIR, 0] == 0
