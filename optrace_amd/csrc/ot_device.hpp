@@ -224,13 +224,13 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y) {
             n.z = ot_sqrt(1 - sf.rho2 * (dx * dx) - sf.rho2 * (dy * dy));
             return n;
         }
-        double r = sqrt(dx * dx + dy * dy);
-        double n_r = sf.nrho * r / sqrt(1 - sf.krho2 * (r * r));
+        double r = ot_sqrt(dx * dx + dy * dy);
+        double n_r = sf.nrho * r / ot_sqrt(1 - sf.krho2 * (r * r));
         double c = (r > 0.0) ? dx / r : 1.0;
         double s = (r > 0.0) ? dy / r : 0.0;
         n.x = n_r * c;
         n.y = n_r * s;
-        n.z = sqrt(1 - n_r * n_r);
+        n.z = ot_sqrt(1 - n_r * n_r);
         return n;
     }
     double rm = sqrt(dx * dx + dy * dy);
