@@ -334,7 +334,7 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
                 Nq = lrow[(3 * i + 1) * OT_MAX_LINES];
             } else {
                 n_next = medium_n<TAB>(media[st.n_next], pool, r.wl);
-                Nq = r.n_cur / n_next;
+                Nq = ot_div(r.n_cur, n_next);
             }
             if (hwh) {
                 if (FULL && kind == OT_STEP_IDEAL)
