@@ -140,7 +140,11 @@ OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, dou
     double u0 = g.u[slot], u1 = g.u[slot + 1];
     const uint32_t N2 = g.n2;
     if (k < N2 * N2) {
-        uint32_t iy = k / N2, ix = k - iy * N2;
+        // k / N2 through the host's 1 / N2 with an exact fix-up instead of an integer division
+        uint32_t iy = (uint32_t)(((double)k + 0.5) * g.inv_n2);
+        if (iy * N2 > k) iy--;
+        if ((iy + 1) * N2 <= k) iy++;
+        uint32_t ix = k - iy * N2;
         x = a + ((double)ix + u0) * ((b - a) * g.inv_n2);
         y = c + ((double)iy + u1) * ((d - c) * g.inv_n2);
     } else {
@@ -158,14 +162,14 @@ OT_DEV void strat_ring(const GenCtx& g, uint32_t stream, double ri, double r, bo
     double r_ = 0.0, th = 0.0;  // th = theta / pi: sincospi needs no range reduction against an inexact pi
     if (x2 > y2) {
         r_ = x;
-        th = 0.25 * (y / x);
+        th = 0.25 * ot_div(y, x);
     } else if (y2 > 0) {
         r_ = y;
-        th = 0.5 - 0.25 * (x / y);
+        th = 0.5 - 0.25 * ot_div(x, y);
     }
     if (ri != 0.0) {
-        double q = ri / r;
-        double m = sqrt(ri * ri + r_ * r_ * (1 - q * q));
+        double q = ot_div(ri, r);
+        double m = ot_sqrt(ri * ri + r_ * r_ * (1 - q * q));
         r_ = (r_ < 0) ? -m : m;
     }
     if (!polar) {
@@ -227,7 +231,7 @@ OT_DEV double inv_cdf_linear(const double* __restrict__ pairs, int n, double X, 
     }
     double dF = F1 - F0;
     if (!(dF > 0)) return x0;
-    return x0 + (X - F0) / dF * (x1 - x0);
+    return x0 + ot_div(X - F0, dF) * (x1 - x0);
 }
 
 struct NewRay {
@@ -323,7 +327,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
     V3 s_or;
     if (src.orientation == OT_OR_CONVERGING) {
         V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
-        const double il = 1 / sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+        const double il = ot_rcp3(ot_sqrt(d.x * d.x + d.y * d.y + d.z * d.z));
         s_or.x = d.x * il;
         s_or.y = d.y * il;
         s_or.z = d.z * il;
@@ -348,7 +352,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
             switch (src.divergence) {
                 case OT_DIV_LAMBERTIAN: {
                     st = strat_interval(g, ST_DIV, 0.0, src.div_sin);  // theta = asin(st)
-                    ct = sqrt(1 - st * st);
+                    ct = ot_sqrt(1 - st * st);
                     break;
                 }
                 case OT_DIV_ISOTROPIC:
@@ -369,11 +373,11 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
             switch (src.divergence) {
                 case OT_DIV_LAMBERTIAN:  // theta = asin(r)
                     st = r;
-                    ct = sqrt(1 - r * r);
+                    ct = ot_sqrt(1 - r * r);
                     break;
                 case OT_DIV_ISOTROPIC:  // theta = acos(1 - r^2)
                     ct = 1 - r * r;
-                    st = r * sqrt(2 - r * r);
+                    st = r * ot_sqrt(2 - r * r);
                     break;
                 default: {
                     const double* F = src.div_tab + src.n_div;
@@ -383,7 +387,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 }
             }
         }
-        double fa = 1 / sqrt(1 - s_or.x * s_or.x);
+        double fa = ot_rcp3(ot_sqrt(1 - s_or.x * s_or.x));
         V3 sy = {0.0, -s_or.z * fa, s_or.y * fa};
         V3 sx = cross3(s_or, sy);
         s.x = ct * s_or.x + st * (ca * sx.x + sa * sy.x);
@@ -416,7 +420,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         }
         double px = cs, py = sn, pz = 0.0;
         if (s.z != 1) {
-            double fa = 1 / (sqrt(1 - s.z * s.z) + 1e-16);
+            double fa = ot_rcp3(ot_sqrt(1 - s.z * s.z) + 1e-16);
             V3 ps = {s.y * fa, -s.x * fa, 0.0};
             double A_ts = ps.x * px + ps.y * py;
             double A_tp = ps.y * px - ps.x * py;
