@@ -271,8 +271,12 @@ __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* _
     for (int i = threadIdx.x; i < OT_HASH_N; i += blockDim.x) hkey[i] = OT_HASH_EMPTY;
     for (int i = threadIdx.x; i < OT_HASH_N * 4; i += blockDim.x) hval[i] = 0.0;
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    // every workgroup takes one contiguous piece of the ray range: rays of one source are neighbours in the
+    // storage and land in the same part of the image, so the LDS table of a workgroup sees fewer distinct pixels
+    // and fewer workgroups fight over the same global addresses than with an interleaved assignment
+    const int64_t chunk = ((n + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+    const int64_t i_end = ((int64_t)(blockIdx.x + 1) * chunk < n) ? (int64_t)(blockIdx.x + 1) * chunk : n;
+    for (int64_t i = (int64_t)blockIdx.x * chunk + threadIdx.x; i < i_end; i += blockDim.x) {
         float wi = w[i];
         if (!(wi > 0.f || wi < 0.f)) continue;  // w == 0: adds nothing (and NaN weights are dropped)
         double x = px[i], y = py[i];
