@@ -176,8 +176,10 @@ __global__ __launch_bounds__(1024) void focus_bin_kernel(int64_t n, const double
     __syncthreads();
     const double x0 = ws[OT_FS_XMIN], x1 = ws[OT_FS_XMAX], y0 = ws[OT_FS_YMIN], y1 = ws[OT_FS_YMAX];
     const double fx = (double)npx / (x1 - x0), fy = (double)npx / (y1 - y0);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    // contiguous piece of the rays per workgroup, as in render_kernel (neighbouring rays share their source)
+    const int64_t chunk = ((n + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+    const int64_t i_end = ((int64_t)(blockIdx.x + 1) * chunk < n) ? (int64_t)(blockIdx.x + 1) * chunk : n;
+    for (int64_t i = (int64_t)blockIdx.x * chunk + threadIdx.x; i < i_end; i += blockDim.x) {
         float wf = w[i];
         if (!(wf > 0.f)) continue;  // left out, or weight 0: adds nothing
         double x = pasb[i] + pasb[i + 2 * n] * z, y = pasb[i + n] + pasb[i + 3 * n] * z;
