@@ -261,3 +261,64 @@ def test_image_from_file(tmp_path):
     assert g.shape == (4, 6) and np.abs(g.data - luma).max() <= 1.0 / 255
     with pytest.raises(IOError):
         ot.RGBImage(str(tmp_path / "missing.png"), [3, 2])
+
+
+def test_tilted_data_function_surfaces_host_logic():
+    """Constructors, validation and bookkeeping of the rank-4 surfaces (tilted_surface.py, data_surface_2d.py,
+    function_surface_2d.py); the device descriptors carry consistent spline tables."""
+    from optrace_amd import _capi
+    with ot.global_options.no_warnings():
+        t = ot.TiltedSurface(r=3, normal=[0, -0.45, np.sqrt(1 - 0.45 ** 2)])
+        assert t.z_max == -t.z_min and abs(t.z_max - 3 * 0.45 / np.sqrt(1 - 0.45 ** 2)) < 1e-14
+        t2 = t.copy()
+        t2.rotate(180)
+        assert np.allclose(t2.normal, [0, 0.45, np.sqrt(1 - 0.45 ** 2)])
+        t2.flip()
+        assert np.allclose(t2.normal[0], 0)
+        with pytest.raises(ValueError):
+            ot.TiltedSurface(r=3, normal=[0, 1, 0])  # normal[2] must be above 0
+        with pytest.raises(RuntimeError):
+            ot.TiltedSurface(r=3)
+        d = t._desc()
+        assert d.kind == _capi.SURF_TILTED and abs(d.normal[1] + 0.45) < 1e-15
+
+        with pytest.raises(ValueError):
+            ot.DataSurface1D(r=2, data=np.zeros(20))  # too few values
+        with pytest.raises(ValueError):
+            ot.DataSurface2D(r=2, data=np.zeros((60, 70)))  # not square
+        r = np.linspace(0, 3, 200)
+        d1 = ot.DataSurface1D(r=3, data=10 - np.sqrt(100 - r ** 2), parax_roc=10.)
+        assert abs(d1.z_min) < 1e-12 and abs(d1.z_max - (10 - np.sqrt(91))) < 1e-9 and d1.rotational_symmetry
+        dd = d1._desc()
+        n = dd.nknots
+        assert dd.kind == _capi.SURF_DATA1D and dd.tab_len == 3 * n and n == 2 * 200 - 1 + _capi.SPL_K + 1
+        zmin, zmax = d1.z_min, d1.z_max
+        d1.flip()
+        assert d1._sign == -1 and d1.parax_roc == -10. and abs(d1.z_max + zmin) < 1e-15 and abs(d1.z_min + zmax) < 1e-15
+
+        xy = np.linspace(-2, 2, 80)
+        X, Y = np.meshgrid(xy, xy)
+        d2 = ot.DataSurface2D(r=2, data=X ** 2 / 20 + Y ** 2 / 30)
+        d2.rotate(30)
+        dd = d2._desc()
+        nc = dd.nknots - _capi.SPL_K - 1
+        assert dd.kind == _capi.SURF_DATA2D and dd.tab_len == dd.nknots + nc * nc + 2 * (nc - 1) * nc
+        assert abs(dd.angle - np.deg2rad(30)) < 1e-15 and not d2.rotational_symmetry
+
+        with pytest.raises(TypeError):
+            ot.FunctionSurface2D(r=2, func=3)
+        with pytest.raises(RuntimeError):
+            ot.FunctionSurface2D(r=2, func=lambda x, y: 1.0)  # must return an array
+        with pytest.raises(NotImplementedError):
+            ot.FunctionSurface2D(r=2, func=lambda x, y: x * 0.1, mask_func=lambda x, y: x > 0)
+        with pytest.raises(ValueError):
+            ot.FunctionSurface1D(r=2, func=lambda r: r ** 2 / 10, z_min=0.)  # z_min and z_max only together
+        f1 = ot.FunctionSurface1D(r=2, func=lambda r: 0.5 + r ** 2 / 10, z_min=0.5, z_max=0.9)
+        assert abs(f1.z_min) < 1e-12 and abs(f1.z_max - 0.4) < 1e-12 and f1._tab_residual < 1e-12
+        f2 = ot.FunctionSurface2D(r=2, func=lambda x, y: x ** 2 / 10 + y ** 2 / 25)
+        assert f2._nknots == 401 + _capi.SPL_K + 1 and f2._tab_residual < 1e-12 and f2._grad_residual < 1e-9
+        f2.rotate(45)
+        f2.flip()
+        assert f2._sign == -1 and abs(f2._angle - np.pi / 4) < 1e-15 and f2._desc().flags == 0
+        f3 = ot.FunctionSurface2D(r=2, func=lambda x, y: x ** 2 / 10, deriv_func=lambda x, y: (x / 5, 0 * y))
+        assert f3._desc().flags == _capi.SURF_FLAG_DERIV_UNROTATED
