@@ -75,7 +75,16 @@ def cpu_baseline(RT, scene, seconds: float) -> dict:
     n2 = int(min(n_avail, max(n, n * seconds / max(t, 1e-6))))
     if n2 > n:
         t, n = run(n2), n2
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": n * M / t, "unit": "ray-surface-intersections/s", "cores": 1, "kind": "port",
+            "cpu_model": model, "host_cores_available": os.cpu_count(),
             "sample": f"{n} rays x {M} surfaces of the same scene (device-generated rays), {t:.1f} s on 1 core"}
 
 
