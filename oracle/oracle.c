@@ -953,6 +953,26 @@ int orc_trace(const ot_scene_desc* sc, const ot_rays* R, const double* hurb_norm
     return status;
 }
 
+/* The same loop over rays split across host threads (rays are independent; the reference's own thread split is
+ * ray_storage.py:147-171): used by bench.py's cpu_baseline leg only.  Counters are kept per thread and summed. */
+int orc_trace_mt(const ot_scene_desc* sc, const ot_rays* R, const double* hurb_normals, int64_t* msgs, int n_threads) {
+    int status = 0;
+    const int n_msg = OT_N_INFOS * R->nt;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1) reduction(| : status)
+    {
+        int64_t* local = (int64_t*)calloc((size_t)n_msg, sizeof(int64_t));
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < R->N; r++) {
+            rayctx cx = {sc, R, r, local, 0.f};
+            if (trace_ray(&cx, hurb_normals)) status |= 1;
+        }
+#pragma omp critical
+        for (int k = 0; k < n_msg; k++) msgs[k] += local[k];
+        free(local);
+    }
+    return status ? -1 : 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * array front ends of the leaf functions (for the known-answer tests)
  * ---------------------------------------------------------------------------------------------- */

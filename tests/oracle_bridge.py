@@ -112,13 +112,14 @@ class HostRays:
         return self.s.reshape(3, self.N).T
 
 
-def trace(desc: _capi.SceneDesc, rays: HostRays, hurb_normals=None) -> tuple[np.ndarray, int]:
+def trace(desc: _capi.SceneDesc, rays: HostRays, hurb_normals=None, threads: int = 1) -> tuple[np.ndarray, int]:
+    """orc_trace on one thread, or orc_trace_mt on `threads` host threads (same result: rays are independent)."""
     msgs = np.zeros(5 * rays.nt, dtype=np.int64)
     hn = None
     if hurb_normals is not None:
         hn = np.ascontiguousarray(hurb_normals, dtype=np.float64).reshape(-1)
-    st = lib().orc_trace(C.byref(desc), C.byref(rays.struct), _d(hn) if hn is not None else None,
-                         msgs.ctypes.data_as(C.POINTER(C.c_int64)))
+    args = (C.byref(desc), C.byref(rays.struct), _d(hn) if hn is not None else None, msgs.ctypes.data_as(C.POINTER(C.c_int64)))
+    st = lib().orc_trace(*args) if threads <= 1 else lib().orc_trace_mt(*args, C.c_int(int(threads)))
     return msgs.reshape(5, rays.nt), st
 
 
