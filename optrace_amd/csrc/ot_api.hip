@@ -1031,7 +1031,7 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     if (!sc || !msgs) return fail(OT_ERR_INVALID, "ot_trace: null argument");
     bool pol = !sc->h.no_pol;
     if (int rc = check_rays(rays, pol)) return rc;
-    if (rays->N >= (1ll << 29)) return fail(OT_ERR_UNSUPPORTED, "at most 2^29 - 1 rays per launch (32-bit lane offsets); split the bundle");
+    if (rays->N >= (1ll << 32)) return fail(OT_ERR_UNSUPPORTED, "at most 2^32 - 1 rays per launch (32-bit ray index); split the bundle");
     if (rays->nt != sc->h.nt) return fail(OT_ERR_INVALID, "ray storage has " + std::to_string(rays->nt) +
                                                              " sections, the scene needs " + std::to_string(sc->h.nt));
     if (rays->N == 0) return OT_OK;

@@ -245,7 +245,7 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
 
 // One section of one ray.  The plane base addresses (array + N * plane) are wave-uniform and stay in SGPRs;
 // the lane contributes a 32-bit element index, so every store is `global_store ... v_offset, s[base]` with no
-// per-lane 64-bit address arithmetic (35 -> 8 VALU-free instructions per section).  Requires N < 2^29
+// per-lane 64-bit address arithmetic (35 -> 8 instructions per section).  The ray index is 32 bits wide: N < 2^32
 // (checked by the host entry points).
 template <bool POL>
 OT_DEV void store_section(const ot_rays& R, uint32_t ray, int sec, const V3& p, float w, double n, float px, float py,
