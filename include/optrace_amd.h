@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 2
+#define OT_ABI_VERSION 3
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -205,6 +205,7 @@ typedef struct ot_scene ot_scene; /* opaque: device copy of the tables */
 
 #define OT_OR_CONSTANT 0   /* ray_source.py:266 */
 #define OT_OR_CONVERGING 1 /* ray_source.py:269 */
+#define OT_OR_ARRAY 2      /* "Function" ray_source.py:272-274: base orientations evaluated by the caller  */
 
 #define OT_POL_CONSTANT 0 /* also "x" (0) and "y" (pi/2), ray_source.py:366-376 */
 #define OT_POL_UNIFORM 1  /* :378 */
@@ -248,6 +249,12 @@ typedef struct ot_source {
     const double* div_tab;  int64_t n_div;
     const double* img_pdf;
     const double* img_rgb;
+    /* OR_ARRAY: DEVICE pointer (caller-owned, NOT copied; must stay valid while the table is used) to the base
+     * orientation of each ray of this source, x[n_or] | y[n_or] | z[n_or]; every range of this source must
+     * hold exactly n_or rays, ray j of the range reads element j.  With a NULL pointer the source emits along
+     * `s`: start positions do not depend on the orientation, so the caller runs ot_rays_generate once with NULL,
+     * evaluates its orientation function at the positions, and generates again with the result.             */
+    const double* s_or; int64_t n_or;
 } ot_source;
 
 /* A contiguous block of rays generated from one source: rays [first, first+count) of the launch. */

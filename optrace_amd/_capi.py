@@ -27,7 +27,7 @@ T_CONSTANT, T_DATA, T_RECTANGLE, T_GAUSSIAN, T_LINES = range(5)
 EL_LENS, EL_IDEAL_LENS, EL_FILTER, EL_APERTURE = range(4)
 SRC_POINT, SRC_LINE, SRC_CIRCLE, SRC_RING, SRC_RECT, SRC_IMAGE_RGB, SRC_IMAGE_GRAY = range(7)
 DIV_NONE, DIV_LAMBERTIAN, DIV_ISOTROPIC, DIV_TABLE = range(4)
-OR_CONSTANT, OR_CONVERGING = range(2)
+OR_CONSTANT, OR_CONVERGING, OR_ARRAY = range(3)
 POL_CONSTANT, POL_UNIFORM, POL_LIST, POL_TABLE = range(4)
 SPEC_MONO, SPEC_UNIFORM, SPEC_LINES, SPEC_GAUSSIAN, SPEC_TABLE = range(5)
 PROJ_NONE, PROJ_EQUIDISTANT, PROJ_ORTHOGRAPHIC, PROJ_EQUAL_AREA, PROJ_STEREOGRAPHIC = range(5)
@@ -88,7 +88,8 @@ class Source(C.Structure):
                 ("spec_tab", C.POINTER(C.c_double)), ("n_spec", C.c_int64),
                 ("pol_tab", C.POINTER(C.c_double)), ("n_pol", C.c_int64),
                 ("div_tab", C.POINTER(C.c_double)), ("n_div", C.c_int64),
-                ("img_pdf", C.POINTER(C.c_double)), ("img_rgb", C.POINTER(C.c_double))]
+                ("img_pdf", C.POINTER(C.c_double)), ("img_rgb", C.POINTER(C.c_double)),
+                ("s_or", C.c_void_p), ("n_or", C.c_int64)]
 
 
 class SourceRange(C.Structure):
@@ -138,7 +139,7 @@ SIGNATURES = {
 }
 
 FOCUS_WS = 16  # OT_FOCUS_WS
-ABI_VERSION = 2  # OT_ABI_VERSION
+ABI_VERSION = 3  # OT_ABI_VERSION
 
 _lib = None
 

@@ -532,6 +532,12 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             d.gauss_xr = (1 + std::erf((s.wl1 - s.mu) / (std::sqrt(2.0) * s.sig))) / 2;
         }
         if (s.shape < OT_SRC_POINT || s.shape > OT_SRC_IMAGE_GRAY) return fail(OT_ERR_INVALID, "source: unknown shape");
+        if (s.orientation < OT_OR_CONSTANT || s.orientation > OT_OR_ARRAY) return fail(OT_ERR_INVALID, "source: unknown orientation");
+        if (s.orientation == OT_OR_ARRAY && s.s_or) {
+            if (s.n_or < 1) return fail(OT_ERR_INVALID, "source: orientation array without a length");
+            d.s_or = s.s_or;
+            d.n_or = s.n_or;
+        }
         bool needs_spec = s.shape != OT_SRC_IMAGE_RGB && (s.spectrum == OT_SPEC_LINES || s.spectrum == OT_SPEC_TABLE);
         if (needs_spec) {
             if (!s.spec_tab || s.n_spec < 1) return fail(OT_ERR_INVALID, "source: spectrum table missing");
@@ -643,6 +649,8 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
     so->d = (SourceDev*)blob;
     so->n = n_sources;
     so->blob = blob;
+    so->n_or = new int64_t[n_sources];
+    for (int i = 0; i < n_sources; i++) so->n_or[i] = devs[i].s_or ? devs[i].n_or : -1;
     (void)hipGetDevice(&so->device);
     *out = so;
     return OT_OK;
@@ -651,6 +659,7 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
 extern "C" void ot_sources_destroy(ot_sources* s) {
     if (!s) return;
     (void)hipFree(s->blob);
+    delete[] s->n_or;
     delete s;
 }
 
@@ -960,6 +969,8 @@ static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot
         if (ranges[k].first < 0 || ranges[k].count < 0 || ranges[k].first + ranges[k].count > N)
             return fail(OT_ERR_INVALID, "range outside the ray storage");
         if (ranges[k].count > 0xffffffffll) return fail(OT_ERR_UNSUPPORTED, "more than 2^32 rays in one source range");
+        if (src->n_or[ranges[k].source] >= 0 && src->n_or[ranges[k].source] != ranges[k].count)
+            return fail(OT_ERR_INVALID, "range: ray count differs from the length of the source's orientation array");
         const uint64_t cnt = (uint64_t)ranges[k].count;
         uint32_t n2 = (uint32_t)std::sqrt((double)cnt);
         while ((uint64_t)n2 * n2 > cnt) n2--;

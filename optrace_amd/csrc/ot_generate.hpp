@@ -331,6 +331,10 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         s_or.x = d.x * il;
         s_or.y = d.y * il;
         s_or.z = d.z * il;
+    } else if (src.orientation == OT_OR_ARRAY && src.s_or) {  // or_func(x, y) evaluated by the caller (:272-274)
+        s_or.x = src.s_or[g.j];
+        s_or.y = src.s_or[g.j + src.n_or];
+        s_or.z = src.s_or[g.j + 2 * src.n_or];
     } else {
         s_or.x = src.s[0];
         s_or.y = src.s[1];

@@ -131,6 +131,7 @@ struct SourceDev {
     // the continuous inverse-CDF tables once more as (F_j, x_j) pairs: the two nodes an interpolation needs sit in
     // one 32-byte load, which also decides whether the search has to step (see inv_cdf_linear)
     const double *spec_pairs, *pol_pairs, *div_pairs, *prim_pairs;
+    const double* s_or; int64_t n_or;  // OR_ARRAY: caller-owned base orientations x[n_or] | y[n_or] | z[n_or]
 };
 
 struct ot_sources {
@@ -138,6 +139,7 @@ struct ot_sources {
     int32_t n;
     void* blob;
     int device;
+    int64_t* n_or;  // host, per source: rays a range of this source must hold (OR_ARRAY with an array), else -1
 };
 
 #define OT_PRIM_N 5000

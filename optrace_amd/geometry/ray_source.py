@@ -134,8 +134,12 @@ class RaySource(Element):
             f["orientation"] = _capi.OR_CONVERGING
             f["conv_pos"] = [float(v) for v in self.conv_pos]
         else:
-            raise _capi.BackendError("orientation='Function' calls back into Python per ray and cannot run "
-                                     "inside the device generation kernel.")
+            # or_func is a Python callable of the start positions: RayStorage evaluates it between a position
+            # pre-pass and the generation proper and hands the result to the kernel as an array
+            if not callable(self.or_func):
+                raise TypeError("RaySource.or_func needs to be callable")
+            f["orientation"] = _capi.OR_ARRAY
+            f["s"] = [float(v) for v in self.s]
 
         # divergence
         f["div_2d"] = int(self.div_2d)

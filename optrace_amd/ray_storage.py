@@ -24,10 +24,12 @@ class SourceTable:
 
     _ptr_fields = ("spec_tab", "pol_tab", "div_tab", "img_pdf", "img_rgb")
 
-    def __init__(self, sources: list, powers: list) -> None:
+    def __init__(self, sources: list, powers: list, s_or: dict = None) -> None:
+        """`s_or`: source index -> flat device tensor x[n] | y[n] | z[n] of base orientations (orientation
+        "Function"); sources of that kind without an entry emit along their constant `s` (position pre-pass)."""
         lib = _capi.load_library()
         require_device()
-        self._keep = []
+        self._keep = [s_or]
         arr = (_capi.Source * len(sources))()
         for j, (rs, power) in enumerate(zip(sources, powers)):
             f = rs._source_fields()
@@ -42,6 +44,8 @@ class SourceTable:
                 else:
                     setattr(s, key, val)
             s.power = float(power)
+            if s_or and j in s_or:
+                s.s_or, s.n_or = s_or[j].data_ptr(), s_or[j].shape[0] // 3
         self.handle = C.c_void_p()
         _capi.check(lib.ot_sources_create(arr, len(sources), C.byref(self.handle)))
         self._lib = lib
@@ -146,14 +150,50 @@ class RayStorage(BaseClass):
             rng[i].count = int(self.N_list[i])
         return rng
 
-    def _source_table(self) -> SourceTable:
-        return SourceTable(self.ray_source_list, self._powers)
+    @property
+    def _has_function_orientation(self) -> bool:
+        return any(rs.orientation == "Function" for rs in self.ray_source_list)
+
+    def _function_orientations(self, seed: int) -> dict:
+        """orientation="Function" (ray_source.py:272-274): `or_func` is a Python callable of the start positions.
+        The start position of a ray depends on (seed, ray index, source shape) only, not on its direction, so a
+        pre-pass generates the rays once with a constant orientation, the callable is evaluated on the host at
+        the positions of its source's rays, and the result goes to the device as an array the generation proper
+        reads its base orientations from.  -> {source index: device tensor x[n] | y[n] | z[n]}"""
+        idx = [i for i, rs in enumerate(self.ray_source_list) if rs.orientation == "Function" and self.N_list[i] > 0]
+        if not idx:
+            return {}
+        lib, dev, N = _capi.load_library(), require_device(), self._N
+        pre = _capi.Rays()
+        buf = {k: torch.empty(n * N, dtype=dt, device=dev) for k, n, dt in
+               (("p", 3, torch.float64), ("s", 3, torch.float64), ("w", 1, torch.float32), ("n", 1, torch.float64),
+                ("wl", 1, torch.float32))}
+        pre.N, pre.nt = N, 1
+        pre.p, pre.s, pre.w, pre.n, pre.wl = (buf[k].data_ptr() for k in ("p", "s", "w", "n", "wl"))
+        pre.pol = None
+        tab = SourceTable(self.ray_source_list, self._powers)
+        rng = self._source_ranges()
+        _capi.check(lib.ot_rays_generate(tab.handle, rng, len(rng), int(seed), 1, C.byref(pre), stream_ptr()))
+        out = {}
+        for i in idx:
+            rs, Ns, Ne = self.ray_source_list[i], int(self.B_list[i]), int(self.B_list[i + 1])
+            x, y = buf["p"][Ns:Ne].cpu().numpy(), buf["p"][N + Ns:N + Ne].cpu().numpy()
+            s_or = rs.or_func(x, y, **rs.or_args)
+            if not isinstance(s_or, np.ndarray) or s_or.shape != (Ne - Ns, 3):
+                raise RuntimeError("or_func must return a np.ndarray of shape (N, 3).")
+            out[i] = torch.from_numpy(np.ascontiguousarray(s_or.T, dtype=np.float64).reshape(-1)).to(dev)
+        return out
+
+    def _source_table(self, seed: int = None) -> SourceTable:
+        """`seed`: the seed of the generation this table is for (needed by orientation="Function" sources)."""
+        s_or = self._function_orientations(seed) if self._has_function_orientation else None
+        return SourceTable(self.ray_source_list, self._powers, s_or)
 
     def generate(self, seed: int | None) -> None:
         """Fill section 0 from the sources (RaySource.create_rays on the device)."""
         lib = _capi.load_library()
         seed = int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
-        tab = self._source_table()
+        tab = self._source_table(seed)
         rng = self._source_ranges()
         rays = self._rays_struct()
         _capi.check(lib.ot_rays_generate(tab.handle, rng, len(rng), seed, int(self.no_pol), C.byref(rays),

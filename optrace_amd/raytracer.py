@@ -342,10 +342,13 @@ class Raytracer(Group):
         seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed) + 1000003 * int(_chunk)
 
         if _initial_rays is None:
-            skey = repr(snap["RaySources"]) + repr(self.rays._powers)
-            if self._source_cache is None or self._source_cache[0] != skey:
-                self._source_cache = (skey, self.rays._source_table())
-            tab = self._source_cache[1]
+            if self.rays._has_function_orientation:  # per-trace orientation arrays: nothing to reuse
+                tab = self.rays._source_table(seed)
+            else:
+                skey = repr(snap["RaySources"]) + repr(self.rays._powers)
+                if self._source_cache is None or self._source_cache[0] != skey:
+                    self._source_cache = (skey, self.rays._source_table())
+                tab = self._source_cache[1]
             rng = self.rays._source_ranges()
             _capi.check(lib.ot_generate_and_trace(self._scene_handle, tab.handle, rng, len(rng), seed,
                                                   C.byref(rays), ptr(msgs), stream_ptr()))

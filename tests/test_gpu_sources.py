@@ -175,3 +175,60 @@ def test_grayscale_image_source(fp):
     assert np.all(counts[expect == 0] == 0)
     assert np.max(np.abs(counts - expect)) < 4
     assert np.all(wl == 600.) and np.all(s[:, 2] == 1.0)
+
+
+def _or_func(x, y, f=5.):
+    s = np.column_stack((-x, -y, np.full_like(x, f)))
+    return s / np.linalg.norm(s, axis=1)[:, None]
+
+
+def test_function_orientation_create_rays():
+    """orientation="Function" (ray_source.py:272-274, tests/test_geometry.py:477-484): without divergence every
+    direction IS or_func at the ray's own start position; with divergence the cone opens around it."""
+    N = 50_000
+    mono = ot.LightSpectrum("Monochromatic", wl=550.)
+    rs = ot.RaySource(ot.RectangularSurface(dim=[2, 3]), spectrum=mono, divergence="None", orientation="Function",
+                      or_func=_or_func, or_args=dict(f=7.), pos=[0.5, -2, 3])
+    p, s, pol, w, wl = rs.create_rays(N)
+    np.testing.assert_array_equal(s, _or_func(p[:, 0], p[:, 1], f=7.))
+    assert np.max(np.abs((pol * s).sum(axis=1))) < 1e-6
+    # positions keep the distribution of the plain source
+    np.testing.assert_allclose(p.mean(axis=0), [0.5, -2, 3], atol=0.01)
+    np.testing.assert_allclose(p.std(axis=0)[:2], np.array([2, 3]) / np.sqrt(12), rtol=0.01)
+
+    rs = ot.RaySource(ot.CircularSurface(r=2), spectrum=mono, divergence="Isotropic", div_angle=3., orientation="Function",
+                      or_func=_or_func, pos=[0, 0, 0])
+    p, s, pol, w, wl = rs.create_rays(N)
+    c = (s * _or_func(p[:, 0], p[:, 1])).sum(axis=1)
+    # theta = arccos(1 - r^2) with r <= sin(div_angle) (ray_source.py:314-318): cos(theta) uniform in [1 - sin^2, 1]
+    sin2 = np.sin(np.radians(3.)) ** 2
+    assert c.min() >= 1 - sin2 - 1e-12 and c.max() <= 1 + 1e-12
+    np.testing.assert_allclose(c.mean(), 1 - sin2 / 2, rtol=1e-5)
+
+    with pytest.raises(RuntimeError):  # wrong shape
+        ot.RaySource(ot.Point(), spectrum=mono, orientation="Function", or_func=lambda x, y: np.ones(3)).create_rays(100)
+    with pytest.raises(RuntimeError):  # s_z <= 0 (ray_source.py:353)
+        ot.RaySource(ot.Point(), spectrum=mono, divergence="None", orientation="Function",
+                     or_func=lambda x, y: np.tile([0., 1., 0.], (x.shape[0], 1))).create_rays(100)
+
+
+def test_function_orientation_in_trace():
+    """Generation inside the tracing kernel: mixed sources, the function source focuses onto its own focal point."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-5, 5, -5, 5, -1, 12], seed=5)
+        RT.add(ot.RaySource(ot.CircularSurface(r=1.5), divergence="None", orientation="Function", or_func=_or_func,
+                            or_args=dict(f=12.), pos=[0, 0, 0], power=2.))
+        RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=2., pos=[1, 1, 0], power=1.))
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[6, 6]), pos=[0, 0, 10]))
+        RT.trace(30_001)
+        n0 = int(RT.rays.N_list[0])
+        assert n0 in (20_000, 20_001)
+        p, s = RT.rays.p_list, RT.rays.s0_list
+        np.testing.assert_array_equal(s[:n0], _or_func(p[:n0, 0, 0], p[:n0, 0, 1], f=12.))
+        # all rays of the function source meet at (0, 0, 12) on the outline's end plane; the point source does not
+        assert np.max(np.abs(p[:n0, 1, :2])) < 1e-12 and np.all(p[:, 1, 2] == 12)
+        assert np.max(np.abs(p[n0:, 1, :2] - 1)) > 0.1
+        # seeded: the same trace again gives the same rays
+        p_first = p.copy()
+        RT.trace(30_001)
+        np.testing.assert_array_equal(RT.rays.p_list, p_first)
