@@ -113,7 +113,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # launched by torch.distributed.run (also with one rank: the same RCCL path as the N > 1 runs)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         ndev = torch.cuda.device_count()
@@ -124,7 +126,7 @@ def main():
         local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    on_host = world > 1 and args.backend != "nccl"  # gloo rehearsal: collectives on host copies
+    on_host = use_dist and args.backend != "nccl"  # gloo rehearsal: collectives on host copies
 
     import optrace_amd as ot
     from optrace_amd import _capi
@@ -154,7 +156,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +175,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
     t = torch.tensor([t_local], dtype=torch.float64, device="cpu" if on_host else dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_max = float(t.item())
 
@@ -191,7 +193,7 @@ def main():
     t_det = time.perf_counter() - td0
     hist = img._dev
     t_red = 0.0
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
         if on_host:
@@ -239,7 +241,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(RT, scene, args.cpu_seconds)
             out["cpu_baseline"]["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["value_one_core"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

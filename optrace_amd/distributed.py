@@ -62,8 +62,8 @@ def shard_source_powers(N: int, powers: list[float], rank: int, world_size: int,
 
 
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
-    """In-place sum over all ranks (no-op for a single process)."""
-    if world()[1] > 1:
+    """In-place sum over all ranks (no-op without a process group)."""
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
