@@ -257,12 +257,17 @@ typedef struct ot_source {
     const double* s_or; int64_t n_or;
 } ot_source;
 
-/* A contiguous block of rays generated from one source: rays [first, first+count) of the launch. */
+/* A contiguous block of rays generated from one source: rays [first, first+count) of the launch.  A block
+ * is one stratification domain, as one thread's share is in the reference (ray_storage.py:147-166); a source
+ * may be cut into several.  Blocks whose count is a power of two are the cheapest to generate (their stratum
+ * permutation needs no rejection step). */
 typedef struct ot_source_range {
     int32_t source;  /* index into the source table                                                 */
     int32_t _pad;
     int64_t first;   /* first ray index inside this launch                                          */
     int64_t count;   /* number of rays (stratification domain, ray_storage.py:160-163)              */
+    double ray_power; /* power of each ray of the block (`power/N` ray_source.py:220, stored f32);
+                       * <= 0: the source's `power` / count                                         */
 } ot_source_range;
 
 typedef struct ot_sources ot_sources; /* opaque: device copy of sources + tables */

@@ -93,7 +93,8 @@ class Source(C.Structure):
 
 
 class SourceRange(C.Structure):
-    _fields_ = [("source", C.c_int32), ("_pad", C.c_int32), ("first", C.c_int64), ("count", C.c_int64)]
+    _fields_ = [("source", C.c_int32), ("_pad", C.c_int32), ("first", C.c_int64), ("count", C.c_int64),
+                ("ray_power", C.c_double)]
 
 
 class Rays(C.Structure):

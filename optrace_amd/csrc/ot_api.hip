@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "ot_detector.hpp"
@@ -650,7 +651,11 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
     so->n = n_sources;
     so->blob = blob;
     so->n_or = new int64_t[n_sources];
-    for (int i = 0; i < n_sources; i++) so->n_or[i] = devs[i].s_or ? devs[i].n_or : -1;
+    so->power = new double[n_sources];
+    for (int i = 0; i < n_sources; i++) {
+        so->n_or[i] = devs[i].s_or ? devs[i].n_or : -1;
+        so->power[i] = devs[i].power;
+    }
     (void)hipGetDevice(&so->device);
     *out = so;
     return OT_OK;
@@ -660,6 +665,7 @@ extern "C" void ot_sources_destroy(ot_sources* s) {
     if (!s) return;
     (void)hipFree(s->blob);
     delete[] s->n_or;
+    delete[] s->power;
     delete s;
 }
 
@@ -676,6 +682,7 @@ struct RangeRec {  // one source range in device memory (scenes with more than O
     int32_t source;
     uint32_t n2;
     double inv_n, inv_n2;
+    float w;
 };
 
 struct RangeArgs {
@@ -688,6 +695,7 @@ struct RangeArgs {
     uint32_t n2[OT_MAX_RANGES];
     double inv_n[OT_MAX_RANGES];
     double inv_n2[OT_MAX_RANGES];
+    float w[OT_MAX_RANGES];  // power of each ray of the range
     const RangeRec* ext;  // n > OT_MAX_RANGES: n records sorted by `first`, contiguous; the arrays above are unused
 };
 
@@ -708,6 +716,7 @@ OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& k, in
         g.n2 = rr.n2;
         g.inv_n = rr.inv_n;
         g.inv_n2 = rr.inv_n2;
+        g.w = rr.w;
         k = lo;
         src = rr.source;
         return true;
@@ -719,6 +728,7 @@ OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& k, in
             g.n2 = rg.n2[q];
             g.inv_n = rg.inv_n[q];
             g.inv_n2 = rg.inv_n2[q];
+            g.w = rg.w[q];
             k = q;
             src = rg.source[q];
             return true;
@@ -738,22 +748,42 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
     GenCtx g;
     g.seed = seed;
     g.gidx = (uint64_t)ray;
+    // the range of the wave's first ray, found on the scalar unit: the records are sorted and contiguous
+    // (make_ranges), so it is the last one that starts at or before that ray
+    const uint64_t ray0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)ray >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ray);
+    int lo = 0, hi = rg.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int64_t f = rg.ext ? as_const(rg.ext)[mid].first : rg.first[mid];
+        if ((uint64_t)f <= ray0)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    int64_t first0, count0;
+    int src0;
+    if (rg.ext) {
+        const auto& rr = as_const(rg.ext)[lo];
+        first0 = rr.first; count0 = rr.count; src0 = rr.source;
+        g.n2 = rr.n2; g.inv_n = rr.inv_n; g.inv_n2 = rr.inv_n2; g.w = rr.w;
+    } else {
+        first0 = rg.first[lo]; count0 = rg.count[lo]; src0 = rg.source[lo];
+        g.n2 = rg.n2[lo]; g.inv_n = rg.inv_n[lo]; g.inv_n2 = rg.inv_n2[lo]; g.w = rg.w[lo];
+    }
+    const bool inside = ray >= first0 && ray < first0 + count0;
+    if (__ballot(inside) == __ballot(true)) {  // one range in this wave
+        g.j = (uint32_t)(ray - first0);
+        g.n = (uint32_t)count0;
+        g.range = (uint32_t)lo;
+        const auto& S = as_const(sources)[src0];
+        fill_dither_for(g, S);
+        nr = generate_ray(S, g, no_pol);
+        return true;
+    }
     int k = -1, src = 0;
     const bool have = locate_range(rg, ray, g, k, src);
-    const unsigned long long todo = __ballot(have);
-    if (!todo) return false;
-    const int lead = __builtin_ctzll(todo);
-    const int ku = __builtin_amdgcn_readlane(k, lead);
-    if (__ballot(have && k == ku) == todo) {  // one range in this wave
-        if (have) {
-            g.n = (uint32_t)__builtin_amdgcn_readlane((int)g.n, lead);
-            g.n2 = (uint32_t)__builtin_amdgcn_readlane((int)g.n2, lead);
-            g.range = (uint32_t)ku;
-            const auto& S = as_const(sources)[__builtin_amdgcn_readlane(src, lead)];
-            fill_dither_for(g, S);
-            nr = generate_ray(S, g, no_pol);
-        }
-    } else if (have) {
+    if (have) {
         g.range = (uint32_t)k;
         fill_dither_for(g, sources[src]);
         nr = generate_ray(sources[src], g, no_pol);
@@ -963,30 +993,40 @@ static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot
     rg.n = n_ranges;
     const bool big = n_ranges > OT_MAX_RANGES;
     std::vector<RangeRec> recs(big ? n_ranges : 0);
+    // the kernel finds a wave's range by bisection: records sorted by their first ray, gap-free (empty ranges first
+    // among equal starts)
+    std::vector<int> order(n_ranges);
+    for (int k = 0; k < n_ranges; k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return ranges[a].first != ranges[b].first ? ranges[a].first < ranges[b].first : ranges[a].count < ranges[b].count;
+    });
     int64_t covered = 0;
-    for (int k = 0; k < n_ranges; k++) {
+    for (int q = 0; q < n_ranges; q++) {
+        const int k = order[q];
         if (ranges[k].source < 0 || ranges[k].source >= src->n) return fail(OT_ERR_INVALID, "range: source out of range");
         if (ranges[k].first < 0 || ranges[k].count < 0 || ranges[k].first + ranges[k].count > N)
             return fail(OT_ERR_INVALID, "range outside the ray storage");
         if (ranges[k].count > 0xffffffffll) return fail(OT_ERR_UNSUPPORTED, "more than 2^32 rays in one source range");
         if (src->n_or[ranges[k].source] >= 0 && src->n_or[ranges[k].source] != ranges[k].count)
             return fail(OT_ERR_INVALID, "range: ray count differs from the length of the source's orientation array");
+        if (ranges[k].first != covered) return fail(OT_ERR_INVALID, "source ranges must cover all N rays exactly once");
         const uint64_t cnt = (uint64_t)ranges[k].count;
         uint32_t n2 = (uint32_t)std::sqrt((double)cnt);
         while ((uint64_t)n2 * n2 > cnt) n2--;
         while ((uint64_t)(n2 + 1) * (n2 + 1) <= cnt) n2++;
         const double inv_n = cnt ? 1.0 / (double)cnt : 0.0, inv_n2 = n2 ? 1.0 / (double)n2 : 0.0;
+        const float w = (float)(ranges[k].ray_power > 0 ? ranges[k].ray_power
+                                                        : (cnt ? src->power[ranges[k].source] / (double)cnt : 0.0));
         if (big) {
-            if (ranges[k].first != covered)
-                return fail(OT_ERR_INVALID, "more than 64 source ranges must be sorted and contiguous");
-            recs[k] = {ranges[k].first, ranges[k].count, ranges[k].source, n2, inv_n, inv_n2};
+            recs[q] = {ranges[k].first, ranges[k].count, ranges[k].source, n2, inv_n, inv_n2, w};
         } else {
-            rg.source[k] = ranges[k].source;
-            rg.first[k] = ranges[k].first;
-            rg.count[k] = ranges[k].count;
-            rg.n2[k] = n2;
-            rg.inv_n[k] = inv_n;
-            rg.inv_n2[k] = inv_n2;
+            rg.w[q] = w;
+            rg.source[q] = ranges[k].source;
+            rg.first[q] = ranges[k].first;
+            rg.count[q] = ranges[k].count;
+            rg.n2[q] = n2;
+            rg.inv_n[q] = inv_n;
+            rg.inv_n2[q] = inv_n2;
         }
         covered += ranges[k].count;
     }

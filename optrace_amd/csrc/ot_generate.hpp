@@ -19,33 +19,44 @@ enum : uint32_t {
 
 // Keyed bijection of [0, l): hash rounds on the enclosing power of two with cycle walking
 // (construction of A. Kensler, "Correlated Multi-Jittered Sampling", Pixar TM 13-01, 2013).
+OT_DEV uint32_t permute_hash(uint32_t i, uint32_t w, uint32_t key) {  // bijection of [0, w], w = 2^k - 1
+    i ^= key;
+    i *= 0xe170893du;
+    i ^= key >> 16;
+    i ^= (i & w) >> 4;
+    i ^= key >> 8;
+    i *= 0x0929eb3fu;
+    i ^= key >> 23;
+    i ^= (i & w) >> 1;
+    i *= 1u | key >> 27;
+    i *= 0x6935fa69u;
+    i ^= (i & w) >> 11;
+    i *= 0x74dcb303u;
+    i ^= (i & w) >> 2;
+    i *= 0x9e501cc3u;
+    i ^= (i & w) >> 2;
+    i *= 0xc860a3dfu;
+    i &= w;
+    i ^= i >> 5;
+    return i;
+}
+
 OT_DEV uint32_t permute_index(uint32_t i, uint32_t l, uint32_t key) {
     if (l <= 1) return 0;
     uint32_t w = l - 1;
+    if ((l & w) == 0) {  // power of two (what the host cuts long ranges into): no cycle walking, no divergence
+        i = permute_hash(i, w, key);
+        return (i + (key & w)) & w;
+    }
     w |= w >> 1;
     w |= w >> 2;
     w |= w >> 4;
     w |= w >> 8;
     w |= w >> 16;
+    // cycle walking: a wave iterates until its slowest lane is back inside [0, l) -- with l just above half the
+    // power of two that is 4-6 rounds for 64 lanes, although a single lane needs 1.3 on average
     do {
-        i ^= key;
-        i *= 0xe170893du;
-        i ^= key >> 16;
-        i ^= (i & w) >> 4;
-        i ^= key >> 8;
-        i *= 0x0929eb3fu;
-        i ^= key >> 23;
-        i ^= (i & w) >> 1;
-        i *= 1u | key >> 27;
-        i *= 0x6935fa69u;
-        i ^= (i & w) >> 11;
-        i *= 0x74dcb303u;
-        i ^= (i & w) >> 2;
-        i *= 0x9e501cc3u;
-        i ^= (i & w) >> 2;
-        i *= 0xc860a3dfu;
-        i &= w;
-        i ^= i >> 5;
+        i = permute_hash(i, w, key);
     } while (i >= l);
     // rotate by a key-dependent offset in [0, l): w < 2 l, so one conditional subtraction each replaces `% l`
     uint32_t rot = key & w;
@@ -74,6 +85,7 @@ struct GenCtx {
     uint32_t range;  // range id (permutation keys differ per range)
     uint32_t n2;     // floor(sqrt(n)): side of the jittered grid of the 2-D samplers
     double inv_n, inv_n2;  // 1 / n, 1 / n2 (host)
+    float w;         // power of each ray of the range (host)
     double u[12];    // dither values in [0,1), 32 random bits each: one to three Philox-4x32-10 blocks per ray
 };
 
@@ -244,7 +256,7 @@ struct NewRay {
 template <class SRC>
 OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
     NewRay o;
-    o.w = (float)(src.power / (double)g.n);  // ray_source.py:220
+    o.w = g.w;  // power / N, ray_source.py:220
 
     // ---- wavelength (light_spectrum.py:81-138) ----
     double wl = 0.0;

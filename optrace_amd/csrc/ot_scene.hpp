@@ -140,6 +140,7 @@ struct ot_sources {
     void* blob;
     int device;
     int64_t* n_or;  // host, per source: rays a range of this source must hold (OR_ARRAY with an array), else -1
+    double* power;  // host, per source
 };
 
 #define OT_PRIM_N 5000

@@ -140,14 +140,29 @@ class RayStorage(BaseClass):
         r.pol = d["pol"].data_ptr() if d["pol"] is not None else None
         return r
 
+    # blocks below this size are not cut further (their share of the rays, and of the time, is negligible)
+    _MIN_BLOCK = 1 << 16
+
     def _source_ranges(self):
-        """One stratification range per source (what RayStorage.thread_rays does for one thread,
-        ray_storage.py:147-166)."""
-        rng = (_capi.SourceRange * len(self.N_list))()
-        for i in range(len(self.N_list)):
-            rng[i].source = i
-            rng[i].first = int(self.B_list[i])
-            rng[i].count = int(self.N_list[i])
+        """Stratification ranges of the launch.  The reference cuts every source's rays among its threads and each
+        thread stratifies its own share (ray_storage.py:147-166); here a source's rays are cut into power-of-two
+        blocks, largest first, plus one ragged rest: a power-of-two block's stratum permutation needs no rejection
+        step (ot_generate.hpp::permute_index), and a wave runs as long as its slowest lane.  Every ray of a source
+        carries power / N_source, whatever its block."""
+        per_source = max(1, 64 // max(len(self.N_list), 1))  # at most 64 ranges travel as kernel arguments
+        recs = []
+        for i, n in enumerate(int(v) for v in self.N_list):
+            first, rest = int(self.B_list[i]), n
+            ray_power = self._powers[i] / n if n else 0.
+            if self.ray_source_list[i].orientation != "Function":  # those read one orientation array per range
+                while rest >= self._MIN_BLOCK and rest & (rest - 1) and sum(r[0] == i for r in recs) < per_source - 1:
+                    blk = 1 << (rest.bit_length() - 1)
+                    recs.append((i, first, blk, ray_power))
+                    first, rest = first + blk, rest - blk
+            recs.append((i, first, rest, ray_power))
+        rng = (_capi.SourceRange * len(recs))()
+        for r, (i, first, count, ray_power) in zip(rng, recs):
+            r.source, r.first, r.count, r.ray_power = i, first, count, ray_power
         return rng
 
     @property

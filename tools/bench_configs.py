@@ -47,13 +47,18 @@ CONFIGS = {
     "freeform (spline surfaces)": (lambda o: scenes.freeform_scene(o, seed=5), 10_000_000),
 }
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # optional name prefixes, e.g. `bench_configs.py C4`
+REPS = 2 if "--short" in sys.argv else 5
+
 for name, (build, N) in CONFIGS.items():
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        continue
     with ot.global_options.no_warnings():
         RT = build(ot)
         RT.trace(N)  # warm-up: scene compile, geometry checks, allocation
         torch.cuda.synchronize()
         ts = []
-        for _ in range(5):
+        for _ in range(REPS):
             t0 = time.perf_counter()
             RT.trace(N)
             torch.cuda.synchronize()
