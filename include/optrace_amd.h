@@ -364,10 +364,12 @@ int ot_refraction_index(const ot_medium* medium, const double* table_pool, int64
  * Outputs are dense per-ray arrays (count entries): ph (count,3) F-order projected hit, hw f32 weight
  * (0 = no valid hit; the reference drops those rows, raytracer.py:1023), and ill_count (device
  * int64[2], ADDED to: [0] ill-conditioned rays, [1] rays whose numeric hit search timed out).  extent4 (device f64[4], may be NULL): running xmin,xmax,ymin,ymax of valid hits
- * (raytracer.py:1044-1046), must be initialised by the caller to +inf,-inf,+inf,-inf. */
+ * (raytracer.py:1044-1046), must be initialised by the caller to +inf,-inf,+inf,-inf.
+ * crop4 (HOST f64[4] xmin,xmax,ymin,ymax, may be NULL): a user extent; hits outside it are dropped like hits
+ * without weight (raytracer.py:1036-1040). */
 int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
-                     int32_t projection, double* ph, float* hw, double* extent4, int64_t* ill_count,
-                     void* stream);
+                     int32_t projection, const double* crop4, double* ph, float* hw, double* extent4,
+                     int64_t* ill_count, void* stream);
 
 /* SphericalSurface.sphere_projection (spherical_surface.py:36-97): p (n,3) F-order -> out (n,3) F-order */
 int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, const double* p, double* out,

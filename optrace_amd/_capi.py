@@ -127,7 +127,7 @@ SIGNATURES = {
     "ot_surface_values": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp]),
     "ot_surface_hurb_props": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp, vp, vp, vp]),
     "ot_refraction_index": (C.c_int, [C.POINTER(Medium), vp, i64, i64, vp, vp, vp]),
-    "ot_detector_hits": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(Surface), i32, vp, vp, vp, vp, vp]),
+    "ot_detector_hits": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(Surface), i32, C.POINTER(C.c_double), vp, vp, vp, vp, vp]),
     "ot_sphere_projection": (C.c_int, [C.POINTER(Surface), i32, i64, vp, vp, vp]),
     "ot_image_convert": (C.c_int, [vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]),
     "ot_image_convolve": (C.c_int, [vp, i32, i32, vp, i32, vp, vp]),

@@ -15,6 +15,7 @@
 #include "ot_focus.hpp"
 #include "ot_generate.hpp"
 #include "ot_image.hpp"
+#include "ot_render_tiles.hpp"
 #include "ot_scene.hpp"
 #include "ot_spectrum.hpp"
 #include "ot_trace.hpp"
@@ -1221,8 +1222,8 @@ extern "C" int ot_refraction_index(const ot_medium* medium, const double* table_
 
 // ---- detector + render -------------------------------------------------------------------------------------
 extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
-                                int32_t projection, double* ph, float* hw, double* extent4, int64_t* ill_count,
-                                void* stream) {
+                                int32_t projection, const double* crop4, double* ph, float* hw, double* extent4,
+                                int64_t* ill_count, void* stream) {
     if (!rays || !detector || !ph || !hw || !ill_count) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
     if (!rays->p || !rays->w) return fail(OT_ERR_INVALID, "ot_detector_hits: ray storage has null buffers");
     if (first < 0 || count < 0 || first + count > rays->N) return fail(OT_ERR_INVALID, "ot_detector_hits: range outside the storage");
@@ -1239,8 +1240,10 @@ extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t coun
         HIP_TRY(hipMallocAsync((void**)&slots, sizeof(unsigned long long) * 4 * OT_EXT_SLOTS, st));
         hipLaunchKernelGGL(extent_init_kernel, dim3(1), dim3(4 * OT_EXT_SLOTS), 0, st, slots);
     }
+    Crop crop = {0.0, 0.0, 0.0, 0.0, 0};
+    if (crop4) crop = {crop4[0], crop4[1], crop4[2], crop4[3], 1};
     hipLaunchKernelGGL(detector_kernel, grid_for(count), dim3(256), 0, st, *rays, first, count, d, R, projection, ph, hw,
-                       slots, (unsigned long long*)ill_count);
+                       slots, (unsigned long long*)ill_count, crop);
     if (extent4) {
         hipLaunchKernelGGL(extent_final_kernel, dim3(1), dim3(64), 0, st, slots, extent4);
         HIP_TRY(hipFreeAsync(slots, st));
@@ -1261,6 +1264,22 @@ extern "C" int ot_sphere_projection(const ot_surface* surf, int32_t projection, 
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }
+
+// Stream-ordered scratch (hipMallocAsync) goes back to the driver at every synchronisation unless the pool is told to
+// keep it; the tile path asks for gigabytes per image, so the pool keeps what it has (once per device).
+static hipError_t keep_async_pool(int dev) {
+    static thread_local bool done[64] = {false};
+    if (dev < 0 || dev >= 64 || done[dev]) return hipSuccess;
+    hipMemPool_t pool;
+    hipError_t e = hipDeviceGetDefaultMemPool(&pool, dev);
+    if (e != hipSuccess) return e;
+    unsigned long long keep = ~0ull;
+    e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    done[dev] = (e == hipSuccess);
+    return e;
+}
+
+#define OT_TILE_MIN_HITS (1ll << 21)  // shorter lists: the direct kernel alone
 
 extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* py, const float* w, const float* wl,
                                     const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream) {
@@ -1286,8 +1305,82 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
         cus = prop.multiProcessorCount;
     int64_t blocks = (n + 1023) / 1024;
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, n, px, py, w, wl, a, table, hist);
-    HIP_TRY(hipGetLastError());
+    hipStream_t st = (hipStream_t)stream;
+    // OT_RENDER_PATH = direct | tiles pins the path (tests, profiling); default: by list length and probe
+    const char* pin = std::getenv("OT_RENDER_PATH");
+    const bool pin_direct = pin && !std::strcmp(pin, "direct"), pin_tiles = pin && !std::strcmp(pin, "tiles");
+    if (pin_direct || (n < OT_TILE_MIN_HITS && !pin_tiles)) {
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return OT_OK;
+    }
+    // long lists: a probe decides on the device whether the direct kernel or the tile path bins them
+    // (ot_render_tiles.hpp); both are enqueued, the one that is not needed returns at once
+    TileArgs t;
+    t.a = a;
+    t.tx = (Nx + OT_TILE_W - 1) / OT_TILE_W;
+    t.ty = (Ny + OT_TILE_W - 1) / OT_TILE_W;
+    t.K = t.tx * t.ty;
+    if (t.K > OT_TILE_MAX) {  // no image of RenderImage is this large; stay on the direct path
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return OT_OK;
+    }
+    t.n = n;
+    t.piece = ((n + OT_TILE_PIECES - 1) / OT_TILE_PIECES + 1023) / 1024 * 1024;
+    t.chunk = ((n + 1023) / 1024 + 1023) / 1024 * 1024;
+    if (t.chunk < 16384) t.chunk = 16384;
+    t.max_chunks = (int32_t)(n / t.chunk + t.K + 1);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_spread = carve(sizeof(int));
+    const size_t o_counts = carve(sizeof(unsigned int) * OT_TILE_PIECES * (size_t)t.K);
+    const size_t o_tot = carve(sizeof(unsigned long long) * t.K);
+    const size_t o_starts = carve(sizeof(unsigned long long) * (t.K + 1));
+    const size_t o_cstart = carve(sizeof(int) * (t.K + 1));
+    const size_t o_w = carve(sizeof(float) * (size_t)n);
+    const size_t o_wl = carve(sizeof(float) * (size_t)n);
+    const size_t o_px = carve(sizeof(unsigned short) * (size_t)n);
+    const size_t o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)t.max_chunks);
+    char* ws = nullptr;
+    HIP_TRY(keep_async_pool(dev));
+    HIP_TRY(hipMallocAsync((void**)&ws, off, st));
+    TileWork wk;
+    wk.spread = (int*)(ws + o_spread);
+    wk.counts = (unsigned int*)(ws + o_counts);
+    wk.tot = (unsigned long long*)(ws + o_tot);
+    wk.starts = (unsigned long long*)(ws + o_starts);
+    wk.chunk_start = (int*)(ws + o_cstart);
+    wk.rec_w = (float*)(ws + o_w);
+    wk.rec_wl = (float*)(ws + o_wl);
+    wk.rec_px = (unsigned short*)(ws + o_px);
+    wk.slabs = (double*)(ws + o_slabs);
+    const int lds_probe = OT_TILE_PROBE_SET * (int)sizeof(int);
+    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
+    static thread_local bool lds_set[64] = {false};
+    if (dev >= 0 && dev < 64 && !lds_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)tile_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_probe));
+        HIP_TRY(hipFuncSetAttribute((const void*)tile_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
+        lds_set[dev] = true;
+    }
+    if (pin_tiles)
+        HIP_TRY(hipMemsetAsync(wk.spread, 1, sizeof(int), st));
+    else
+        hipLaunchKernelGGL(tile_probe_kernel, dim3(1), dim3(1024), lds_probe, st, t, px, py, w, wk.spread);
+    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)wk.spread);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(OT_TILE_PIECES), dim3(1024), 0, st, t, px, py, w, wk);
+    hipLaunchKernelGGL(tile_cursor_kernel, dim3((unsigned)((t.K + 3) / 4)), dim3(256), 0, st, t, wk, wk.tot);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, t, wk, (const unsigned long long*)wk.tot);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(OT_TILE_PIECES), dim3(1024), 0, st, t, px, py, w, wl, wk);
+    hipLaunchKernelGGL(tile_accum_kernel, dim3((unsigned)t.max_chunks), dim3(1024), lds_accum, st, t, table, wk);
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3(OT_TILE_PX / 256, (unsigned)t.K), dim3(256), 0, st, t, wk, hist);
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, st);
+    HIP_TRY(e);
     return OT_OK;
 }
 

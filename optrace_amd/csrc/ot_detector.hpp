@@ -123,12 +123,17 @@ OT_DEV V3 section_dir(const ot_rays& R, int64_t r, int k) {
     return normalize3(d);
 }
 
+struct Crop {
+    double x0, x1, y0, y1;
+    int on;
+};
+
 // Raytracer._hit_detector raytracer.py:922-1051, one lane per ray of [first, first+count).
 // ill_count[0] += ill-conditioned rays, ill_count[1] += rays whose numeric hit search timed out.
 __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first, int64_t count, SurfDev det, double Rcurv,
                                                        int projection, double* __restrict__ ph_out, float* __restrict__ hw_out,
                                                        unsigned long long* __restrict__ ext_slots,
-                                                       unsigned long long* __restrict__ ill_count) {
+                                                       unsigned long long* __restrict__ ill_count, Crop crop) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = q < count;
     const int64_t r = first + (active ? q : 0);
@@ -191,6 +196,8 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
     }
     bool valid = active && ish && (w > 0);
     if (valid) sphere_project(det.px, det.py, det.pz, Rcurv, projection, ph);
+    // user extent: hits outside are dropped (raytracer.py:1036-1040)
+    if (crop.on) valid = valid && crop.x0 <= ph.x && ph.x <= crop.x1 && crop.y0 <= ph.y && ph.y <= crop.y1;
     if (active) {
         ph_out[q] = valid ? ph.x : 0.0;
         ph_out[q + count] = valid ? ph.y : 0.0;
@@ -261,9 +268,42 @@ static const double* observer_table_device() {
 #define OT_HASH_PROBES 4    // linear probes before falling back to a global atomic
 #define OT_HASH_EMPTY (-1)
 
+// misc.binning_indices_2d misc.py:75-89: pixel index iy * Nx + ix of a hit, -1 outside (weight 0 in the reference)
+OT_DEV int hit_pixel(const RenderArgs& a, double x, double y, int32_t& ix, int32_t& iy) {
+    ix = (int32_t)floor(a.fx * (x - a.x0));
+    iy = (int32_t)floor(a.fy * (y - a.y0));
+    if (y == a.y1) iy = a.Ny - 1;
+    if (x == a.x1) ix = a.Nx - 1;
+    if (ix < 0 || iy < 0 || iy >= a.Ny || ix >= a.Nx) return -1;
+    return iy * a.Nx + ix;
+}
+
+// color.x/y/z_observer observers.py:14-41 = np.interp on the 1 nm CIE grid: the interval index is floor(wl - 360);
+// obs: the 471 x 3 table (LDS copy)
+OT_DEV void observer_xyz_at(const double* obs, double l, double& xo, double& yo, double& zo) {
+    xo = yo = zo = 0.0;
+    double u = l - OT_OBS_WL0;
+    if (u >= 0.0 && u <= (double)(OT_OBS_N - 1)) {
+        int j = (int)floor(u);
+        if (j >= OT_OBS_N - 1) {
+            xo = obs[3 * (OT_OBS_N - 1)];
+            yo = obs[3 * (OT_OBS_N - 1) + 1];
+            zo = obs[3 * (OT_OBS_N - 1) + 2];
+        } else {
+            double t = l - (OT_OBS_WL0 + (double)j);
+            const double* f0 = &obs[3 * j];
+            xo = (f0[3] - f0[0]) / 1.0 * t + f0[0];
+            yo = (f0[4] - f0[1]) / 1.0 * t + f0[1];
+            zo = (f0[5] - f0[2]) / 1.0 * t + f0[2];
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* __restrict__ px, const double* __restrict__ py,
                                                       const float* __restrict__ w, const float* __restrict__ wl, RenderArgs a,
-                                                      const double* __restrict__ table, double* __restrict__ hist) {
+                                                      const double* __restrict__ table, double* __restrict__ hist,
+                                                      const int* __restrict__ spread) {
+    if (spread && spread[0]) return;  // the hits cover many pixels: the tile path bins them (ot_render_tiles.hpp)
     __shared__ double obs[OT_OBS_N * 3];
     __shared__ double hval[OT_HASH_N * 4];
     __shared__ int hkey[OT_HASH_N];
@@ -279,33 +319,12 @@ __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* _
     for (int64_t i = (int64_t)blockIdx.x * chunk + threadIdx.x; i < i_end; i += blockDim.x) {
         float wi = w[i];
         if (!(wi > 0.f || wi < 0.f)) continue;  // w == 0: adds nothing (and NaN weights are dropped)
-        double x = px[i], y = py[i];
-        // misc.binning_indices_2d misc.py:75-89
-        int32_t ix = (int32_t)floor(a.fx * (x - a.x0));
-        int32_t iy = (int32_t)floor(a.fy * (y - a.y0));
-        if (y == a.y1) iy = a.Ny - 1;
-        if (x == a.x1) ix = a.Nx - 1;
-        if (ix < 0 || iy < 0 || iy >= a.Ny || ix >= a.Nx) continue;  // outside: weight 0 in the reference
-        // np.interp on the 1 nm grid: interval index is floor(wl - 360)
-        double l = (double)wl[i];
-        double xo = 0.0, yo = 0.0, zo = 0.0;
-        double u = l - OT_OBS_WL0;
-        if (u >= 0.0 && u <= (double)(OT_OBS_N - 1)) {
-            int j = (int)floor(u);
-            if (j >= OT_OBS_N - 1) {
-                xo = obs[3 * (OT_OBS_N - 1)];
-                yo = obs[3 * (OT_OBS_N - 1) + 1];
-                zo = obs[3 * (OT_OBS_N - 1) + 2];
-            } else {
-                double t = l - (OT_OBS_WL0 + (double)j);
-                const double* f0 = &obs[3 * j];
-                xo = (f0[3] - f0[0]) / 1.0 * t + f0[0];
-                yo = (f0[4] - f0[1]) / 1.0 * t + f0[1];
-                zo = (f0[5] - f0[2]) / 1.0 * t + f0[2];
-            }
-        }
+        int32_t ix, iy;
+        const int pix = hit_pixel(a, px[i], py[i], ix, iy);
+        if (pix < 0) continue;
+        double xo, yo, zo;
+        observer_xyz_at(obs, (double)wl[i], xo, yo, zo);
         double wm = (double)wi;
-        const int pix = iy * a.Nx + ix;
         // LDS hash insert: claim or match one of OT_HASH_PROBES consecutive entries
         unsigned int h = ((unsigned int)pix * 2654435761u) >> (32 - 11);  // OT_HASH_N = 2^11
         int slot = -1;

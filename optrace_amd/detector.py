@@ -13,8 +13,10 @@ from . import _capi
 from ._device import require_device, stream_ptr, ptr, to_dev, f_order_flat, from_f_order
 
 
-def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projection: int, want_extent: bool):
-    """-> (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count)."""
+def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projection: int, want_extent: bool,
+                  crop=None):
+    """-> (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count).
+    `crop` = user extent [x0, x1, y0, y1]: hits outside it come back with weight 0 (raytracer.py:1036-1040)."""
     lib = _capi.load_library()
     dev = require_device()
     ph = torch.empty(3 * count, dtype=torch.float64, device=dev)
@@ -24,7 +26,8 @@ def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projec
     if want_extent:
         ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float64, device=dev)
     rs = rays._rays_struct()
-    _capi.check(lib.ot_detector_hits(C.byref(rs), int(first), int(count), C.byref(surf_desc), int(projection),
+    crop4 = None if crop is None else (C.c_double * 4)(*(float(v) for v in crop))
+    _capi.check(lib.ot_detector_hits(C.byref(rs), int(first), int(count), C.byref(surf_desc), int(projection), crop4,
                                      ptr(ph), ptr(hw), ptr(ext), ptr(ill), stream_ptr()))
     # closed-form hits (flat / conic detectors) can neither be ill-conditioned nor time out: no read-back, no sync
     numeric = surf_desc.kind >= _capi.SURF_ASPHERE and surf_desc.z_min != surf_desc.z_max

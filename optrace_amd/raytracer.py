@@ -403,18 +403,16 @@ class Raytracer(Group):
         if not (extent is None or isinstance(extent, (list, np.ndarray))):
             raise ValueError(f"Invalid extent '{extent}'.")
 
-        ph, hw, ext4, ill_count = _detector.detector_hits(self.rays, Ns, Ne - Ns, dsurf._desc(),
-                                                          _capi.PROJECTIONS[projection], extent is None)
-        wl = self.rays._dev["wl"][Ns:Ne]
-
+        extent_out = None
         if extent is not None:
             extent_out = np.asarray_chkfinite(np.array(extent, dtype=np.float64).copy(), dtype=np.float64)
-            # rays outside a user extent are dropped (raytracer.py:1036-1040); binning gives them weight 0
-            n = Ne - Ns
-            x, y = ph[:n], ph[n:2 * n]
-            inside = (extent_out[0] <= x) & (x <= extent_out[1]) & (extent_out[2] <= y) & (y <= extent_out[3])
-            hw = torch.where(inside, hw, torch.zeros_like(hw))
-        else:
+        # rays outside a user extent are dropped (raytracer.py:1036-1040): the hit kernel gives them weight 0
+        ph, hw, ext4, ill_count = _detector.detector_hits(self.rays, Ns, Ne - Ns, dsurf._desc(),
+                                                          _capi.PROJECTIONS[projection], extent is None,
+                                                          crop=extent_out)
+        wl = self.rays._dev["wl"][Ns:Ne]
+
+        if extent is None:
             extent_out = self.detectors[detector_index].pos[:2].repeat(2)
             if np.all(np.isfinite(ext4)):
                 extent_out = ext4.copy()
