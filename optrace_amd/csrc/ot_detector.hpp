@@ -149,25 +149,37 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
         // Along a traced ray z never decreases (s_z > 0 on every living section, dead rays keep their position),
         // so the reference's whole-row tests reduce to the two end sections and argmax(z >= z_min) to a binary
         // search: 2 + log2(nt) plane reads per ray instead of nt.
+        // The planes are read from the far end: a detector behind the last surface (the usual place) is settled by
+        // the last two, z[nt-2] < z_min <= z[nt-1].
         const double* __restrict__ zp = R.p + r + N * (2 * (int64_t)nt);
-        const double z0 = zp[0], zl = zp[N * (int64_t)(nt - 1)];
-        const bool all_b = z0 >= det.z_max && z0 >= det.z_min;   // np.all(bh_zmin & bh_zmax): starts behind it
+        const double zl = zp[N * (int64_t)(nt - 1)];
+        bool all_b = false;                                            // np.all(bh_zmin & bh_zmax): starts behind it
         const bool all_nb = !(zl >= det.z_min) && !(zl >= det.z_max);  // np.all(~bh_zmin & ~bh_zmax): ends before
         int first_ge = -1;
-        if (!(all_b || all_nb)) {
-            if (z0 >= det.z_min) {
-                first_ge = 0;
-            } else if (zl >= det.z_min) {
-                int lo = 0, hi = nt - 1;  // z[lo] < z_min <= z[hi]
-                while (hi - lo > 1) {
-                    int mid = (lo + hi) >> 1;
-                    if (zp[N * (int64_t)mid] >= det.z_min)
-                        hi = mid;
-                    else
-                        lo = mid;
+        if (!all_nb && zl >= det.z_min) {
+            const double zq = zp[N * (int64_t)(nt >= 2 ? nt - 2 : 0)];
+            if (nt >= 2 && !(zq >= det.z_min)) {
+                first_ge = nt - 1;  // z0 <= z[nt-2] < z_min: not all_b either
+            } else {
+                const double z0 = zp[0];
+                all_b = z0 >= det.z_max && z0 >= det.z_min;
+                if (z0 >= det.z_min) {
+                    first_ge = 0;
+                } else {
+                    int lo = 0, hi = nt >= 2 ? nt - 2 : 0;  // z[lo] < z_min <= z[hi]
+                    while (hi - lo > 1) {
+                        int mid = (lo + hi) >> 1;
+                        if (zp[N * (int64_t)mid] >= det.z_min)
+                            hi = mid;
+                        else
+                            lo = mid;
+                    }
+                    first_ge = hi;
                 }
-                first_ge = hi;
             }
+        } else if (!all_nb) {  // z_min > zl >= z_max cannot happen for a surface (z_max >= z_min); kept for exactness
+            const double z0 = zp[0];
+            all_b = z0 >= det.z_max && z0 >= det.z_min;
         }
         if (!(all_b || all_nb)) {
             int k = (first_ge < 0 ? 0 : first_ge) - 1;
