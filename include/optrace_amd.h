@@ -378,7 +378,10 @@ int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, 
 /* RenderImage.render inner part (render_image.py:396-418 + misc.binning_indices_2d misc.py:59-91 +
  * color.x/y/z_observer observers.py:14-41): bins n hits into hist (Ny, Nx, 4) f64 device array,
  * ADDING w*[xbar(wl), ybar(wl), zbar(wl), 1].  extent = [x0,x1,y0,y1] after RenderImage.__fix_extent.
- * Rays with w == 0 are skipped (they add nothing in the reference either). */
+ * Rays with w == 0 are skipped (they add nothing in the reference either).  Lists of 2^21 hits or more that
+ * spread over many pixels are binned tile by tile in LDS (stream-ordered scratch of ~11 B per hit from the
+ * device's default memory pool, which is set to keep its memory); the environment variable OT_RENDER_PATH =
+ * direct | tiles pins the path. */
 int ot_render_accumulate(int64_t n, const double* px, const double* py, const float* w,
                          const float* wl, const double extent[4], int32_t Nx, int32_t Ny,
                          double* hist, void* stream);
