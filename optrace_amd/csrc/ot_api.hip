@@ -1242,8 +1242,12 @@ extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t coun
     }
     Crop crop = {0.0, 0.0, 0.0, 0.0, 0};
     if (crop4) crop = {crop4[0], crop4[1], crop4[2], crop4[3], 1};
-    hipLaunchKernelGGL(detector_kernel, grid_for(count), dim3(256), 0, st, *rays, first, count, d, R, projection, ph, hw,
-                       slots, (unsigned long long*)ill_count, crop);
+    if (d.kind == OT_SURF_CONIC || d.flat)
+        hipLaunchKernelGGL(detector_kernel<false>, grid_for(count), dim3(256), 0, st, *rays, first, count, d, R, projection, ph,
+                           hw, slots, (unsigned long long*)ill_count, crop);
+    else
+        hipLaunchKernelGGL(detector_kernel<true>, grid_for(count), dim3(256), 0, st, *rays, first, count, d, R, projection, ph,
+                           hw, slots, (unsigned long long*)ill_count, crop);
     if (extent4) {
         hipLaunchKernelGGL(extent_final_kernel, dim3(1), dim3(64), 0, st, slots, extent4);
         HIP_TRY(hipFreeAsync(slots, st));

@@ -130,6 +130,9 @@ struct Crop {
 
 // Raytracer._hit_detector raytracer.py:922-1051, one lane per ray of [first, first+count).
 // ill_count[0] += ill-conditioned rays, ill_count[1] += rays whose numeric hit search timed out.
+// NUMERIC = false: detectors with a closed-form hit (flat, conic) -- without the Illinois loop and the spline code the
+// kernel needs a third of the registers, and this kernel lives on loads in flight.
+template <bool NUMERIC>
 __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first, int64_t count, SurfDev det, double Rcurv,
                                                        int projection, double* __restrict__ ph_out, float* __restrict__ hw_out,
                                                        unsigned long long* __restrict__ ext_slots,
@@ -152,12 +155,18 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
         // The planes are read from the far end: a detector behind the last surface (the usual place) is settled by
         // the last two, z[nt-2] < z_min <= z[nt-1].
         const double* __restrict__ zp = R.p + r + N * (2 * (int64_t)nt);
-        const double zl = zp[N * (int64_t)(nt - 1)];
+        const double* __restrict__ xp = R.p + r;
+        const double* __restrict__ yp = R.p + r + N * (int64_t)nt;
+        const int kq = nt >= 2 ? nt - 2 : 0;
+        // everything the usual case needs is requested at once (one memory round trip instead of three)
+        const double zl = zp[N * (int64_t)(nt - 1)], zq = zp[N * (int64_t)kq];
+        const double xl = xp[N * (int64_t)(nt - 1)], xq = xp[N * (int64_t)kq];
+        const double yl = yp[N * (int64_t)(nt - 1)], yq = yp[N * (int64_t)kq];
+        const float wq = R.w[r + N * (int64_t)kq];
         bool all_b = false;                                            // np.all(bh_zmin & bh_zmax): starts behind it
         const bool all_nb = !(zl >= det.z_min) && !(zl >= det.z_max);  // np.all(~bh_zmin & ~bh_zmax): ends before
         int first_ge = -1;
         if (!all_nb && zl >= det.z_min) {
-            const double zq = zp[N * (int64_t)(nt >= 2 ? nt - 2 : 0)];
             if (nt >= 2 && !(zq >= det.z_min)) {
                 first_ge = nt - 1;  // z0 <= z[nt-2] < z_min: not all_b either
             } else {
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
                 if (z0 >= det.z_min) {
                     first_ge = 0;
                 } else {
-                    int lo = 0, hi = nt >= 2 ? nt - 2 : 0;  // z[lo] < z_min <= z[hi]
+                    int lo = 0, hi = kq;  // z[lo] < z_min <= z[hi]
                     while (hi - lo > 1) {
                         int mid = (lo + hi) >> 1;
                         if (zp[N * (int64_t)mid] >= det.z_min)
@@ -184,9 +193,17 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
         if (!(all_b || all_nb)) {
             int k = (first_ge < 0 ? 0 : first_ge) - 1;
             if (k < 0) k = 0;
-            V3 p = {R.p[r + N * k], R.p[r + N * (k + (int64_t)nt)], R.p[r + N * (k + 2 * (int64_t)nt)]};
-            V3 s = section_dir(R, r, k);
-            w = R.w[r + N * k];
+            V3 p, s;
+            if (k == kq && nt >= 2) {  // the prefetched pair of sections
+                p = {xq, yq, zq};
+                V3 d = {xl - xq, yl - yq, zl - zq};
+                s = normalize3(d);
+                w = wq;
+            } else {
+                p = {xp[N * (int64_t)k], yp[N * (int64_t)k], zp[N * (int64_t)k]};
+                s = section_dir(R, r, k);
+                w = R.w[r + N * k];
+            }
             for (;;) {
                 k += 1;
                 if (k >= nt) {
@@ -194,12 +211,12 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
                     break;
                 }
                 bool ill;
-                if (!find_hit(det, p, s, ph, ish, ill)) timeout = true;
+                if (!find_hit<NUMERIC>(det, p, s, ph, ish, ill)) timeout = true;
                 any_ill = any_ill || ill;
-                double p2z = R.p[r + N * (k + 2 * (int64_t)nt)];
+                double p2z = (k == nt - 1) ? zl : zp[N * (int64_t)k];
                 if (!(ph.z > p2z + OT_C_EPS)) break;  // hit lies inside this section (raytracer.py:985)
-                p.x = R.p[r + N * k];
-                p.y = R.p[r + N * (k + (int64_t)nt)];
+                p.x = xp[N * (int64_t)k];
+                p.y = yp[N * (int64_t)k];
                 p.z = p2z;
                 s = section_dir(R, r, k);
                 w = R.w[r + N * k];
