@@ -1346,9 +1346,7 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     const size_t o_tot = carve(sizeof(unsigned long long) * t.K);
     const size_t o_starts = carve(sizeof(unsigned long long) * (t.K + 1));
     const size_t o_cstart = carve(sizeof(int) * (t.K + 1));
-    const size_t o_w = carve(sizeof(float) * (size_t)n);
-    const size_t o_wl = carve(sizeof(float) * (size_t)n);
-    const size_t o_px = carve(sizeof(unsigned short) * (size_t)n);
+    const size_t o_rec = carve(sizeof(TileRec) * (size_t)n);
     const size_t o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)t.max_chunks);
     char* ws = nullptr;
     HIP_TRY(keep_async_pool(dev));
@@ -1359,9 +1357,7 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     wk.tot = (unsigned long long*)(ws + o_tot);
     wk.starts = (unsigned long long*)(ws + o_starts);
     wk.chunk_start = (int*)(ws + o_cstart);
-    wk.rec_w = (float*)(ws + o_w);
-    wk.rec_wl = (float*)(ws + o_wl);
-    wk.rec_px = (unsigned short*)(ws + o_px);
+    wk.rec = (TileRec*)(ws + o_rec);
     wk.slabs = (double*)(ws + o_slabs);
     const int lds_probe = OT_TILE_PROBE_SET * (int)sizeof(int);
     const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);

@@ -12,11 +12,11 @@
 //   count    hits per tile of every workgroup's contiguous piece of the list            reads x, y, w      20 B/hit
 //   cursor   every piece's write cursor inside each tile's part of the list (one wave per tile)
 //   scan     tile starts, work list of (tile, chunk of hits)
-//   scatter  (w, wl, pixel inside the tile) of every hit to its tile's part of the list reads 24, writes 10 B/hit
+//   scatter  (w, wl, pixel inside the tile) of every hit to its tile's part of the list reads 24, writes 12 B/hit
 //   accum    one workgroup per chunk: ds_add_f64 into the LDS tile, tile written to its own slab, no atomics
 //   reduce   slabs of a tile summed into the image, every pixel owned by one thread
 //
-// 64 B of traffic per hit instead of 4 contended atomics.  Sums are the same values added in another order.
+// 68 B of traffic per hit instead of 4 contended atomics.  Sums are the same values added in another order.
 #pragma once
 #include "ot_detector.hpp"
 
@@ -37,6 +37,13 @@ struct TileArgs {
     int32_t max_chunks;  // grid of accum, slabs allocated
 };
 
+// one hit in its tile's part of the list: a single 12-byte store per hit (three separate arrays cost three partial
+// cache-line writes per hit, and the scatter is bound by exactly those)
+struct TileRec {
+    float w, wl;
+    uint32_t px;  // pixel inside the tile
+};
+
 // everything the kernels exchange, carved out of one allocation
 struct TileWork {
     int* spread;                 // [1] probe verdict
@@ -44,9 +51,7 @@ struct TileWork {
     unsigned long long* tot;     // [K] hits of each tile
     unsigned long long* starts;  // [K + 1] first record of each tile
     int* chunk_start;            // [K + 1] first chunk of each tile
-    float* rec_w;                // [n]
-    float* rec_wl;               // [n]
-    unsigned short* rec_px;      // [n] pixel inside the tile
+    TileRec* rec;                // [n] hits sorted by tile
     double* slabs;               // [max_chunks][TILE_PX * 4]
 };
 
@@ -180,9 +185,8 @@ __global__ __launch_bounds__(1024) void tile_scatter_kernel(TileArgs t, const do
         int local;
         const int tl = tile_of(t, ix, iy, local);
         const unsigned long long pos = wk.starts[tl] + atomicAdd(&cur[tl], 1u);
-        wk.rec_w[pos] = wi;
-        wk.rec_wl[pos] = wl[i];
-        wk.rec_px[pos] = (unsigned short)local;
+        TileRec rec = {wi, wl[i], (uint32_t)local};
+        wk.rec[pos] = rec;
     }
 }
 
@@ -209,10 +213,11 @@ __global__ __launch_bounds__(1024) void tile_accum_kernel(TileArgs t, const doub
     if (r1 > wk.starts[lo + 1]) r1 = wk.starts[lo + 1];
     __syncthreads();
     for (unsigned long long r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const double wm = (double)wk.rec_w[r];
+        const TileRec rec = wk.rec[r];
+        const double wm = (double)rec.w;
         double xo, yo, zo;
-        observer_xyz_at(obs, (double)wk.rec_wl[r], xo, yo, zo);
-        double* hv = tile + 4 * (int)wk.rec_px[r];
+        observer_xyz_at(obs, (double)rec.wl, xo, yo, zo);
+        double* hv = tile + 4 * (int)rec.px;
         unsafeAtomicAdd(hv + 0, xo * wm);
         unsafeAtomicAdd(hv + 1, yo * wm);
         unsafeAtomicAdd(hv + 2, zo * wm);
