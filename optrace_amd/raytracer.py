@@ -42,9 +42,12 @@ class Raytracer(Group):
     MAX_RAY_STORAGE_RAM: int = 200_000_000_000
     """Upper bound for the ray storage of one trace.  The reference guards host RAM with 6 GB
     (raytracer.py:37); here the storage lives in the 288 GB of HBM3E of one MI355X."""
-    ITER_RAYS_STEP: int = 10_000_000
-    """Rays per chunk of `iterative_render`.  The reference uses 1 M to bound host RAM (raytracer.py:40); a chunk of
-    10 M rays keeps the storage of a 15-surface scene at 8.4 GB of HBM and needs ten times fewer launches."""
+    ITER_RAYS_STEP: int = None
+    """Rays per chunk of `iterative_render` (the reference: 1 M, to bound host RAM, raytracer.py:40).  None: as many
+    as ITER_STORAGE_BYTES of ray storage hold, in equal chunks."""
+    ITER_STORAGE_BYTES: int = 16_000_000_000
+    """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are
+    19 M rays of a 15-surface scene with polarisation or 93 M rays of a two-surface scene without."""
 
     class INFOS(IntEnum):
         ABSORB_MISSING = 0
@@ -663,14 +666,22 @@ class Raytracer(Group):
             raise ValueError("extent list needs to have the same length as pos list")
         extentc = extent.copy()
 
+        nt = len(self.tracing_surfaces) + 2
         rays_step = self.ITER_RAYS_STEP
-        iterations = max(1, int(N / rays_step))
+        if rays_step is None:
+            # chunk = what ITER_STORAGE_BYTES of ray storage hold (the reference's 1 M rays are sized for a few GB of
+            # host RAM, raytracer.py:40); chunks of equal size, at least 1 M rays
+            step_max = max(1_000_000, self.rays.max_rays_for_size(self.ITER_STORAGE_BYTES, nt, self.no_pol))
+            iterations = -(-N // step_max)
+            rays_step = -(-N // iterations)
+        else:
+            iterations = max(1, int(N / rays_step))
+        step0 = rays_step
         images: list = []
 
         if self._pretrace_check(rays_step):
             raise RuntimeError("Geometry checks failed. Tracing aborted. Check the warnings.")
 
-        nt = len(self.tracing_surfaces) + 2
         msgs_cum = np.zeros((len(self.INFOS), nt), dtype=int)
         scale0, scaled = 1.0, False
 
@@ -687,7 +698,7 @@ class Raytracer(Group):
                     # chunks of equal size are binned straight into the image of the first chunk (their common
                     # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
                     # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
-                    direct = 0 < i and rays_step == self.ITER_RAYS_STEP
+                    direct = 0 < i and rays_step == step0
                     img = self.detector_image(detector_index=detector_index[j], extent=extentc[j], limit=limit[j],
                                               _dont_filter=True, _keep_on_device=True,
                                               _into=images[j]._dev if direct else None,

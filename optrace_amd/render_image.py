@@ -32,15 +32,23 @@ class RenderImage(BaseClass):
         self._new_lock = False
         self.extent = extent
         self._extent0 = self.extent.copy()
-        self._data = None
+        self._host = None  # host copy of the image, made when `_data` is first read
         self._dev = None
         self._limit = None
         self.projection = projection
         super().__init__(**kwargs)
         self._new_lock = True
 
+    @property
+    def _data(self):
+        """(Ny, Nx, 4) float64 XYZW image as the reference exposes it (render_image.py:80); the histogram lives in
+        HBM (`_dev`) and is copied to the host when this attribute is first read."""
+        if self._host is None and self._dev is not None:
+            self._host = self._dev.cpu().numpy()
+        return self._host
+
     def has_image(self) -> bool:
-        return self._data is not None
+        return self._host is not None or self._dev is not None
 
     def _check_for_image(self) -> None:
         if not self.has_image():
@@ -53,7 +61,7 @@ class RenderImage(BaseClass):
     @property
     def shape(self) -> tuple:
         self._check_for_image()
-        return self._data.shape
+        return tuple(self._dev.shape) if self._host is None else self._host.shape
 
     @property
     def data(self) -> np.ndarray:
@@ -67,10 +75,14 @@ class RenderImage(BaseClass):
 
     def power(self) -> float:
         self._check_for_image()
+        if self._host is None:  # no host copy yet: reduce on the device instead of moving 28-143 MB
+            return float(self._dev[:, :, 3].sum())
         return float(np.sum(self._data[:, :, 3]))
 
     def luminous_power(self) -> float:
         self._check_for_image()
+        if self._host is None:
+            return float(self.K * self._dev[:, :, 1].sum())
         return float(self.K * np.sum(self._data[:, :, 1]))
 
     @property
@@ -109,6 +121,8 @@ class RenderImage(BaseClass):
 
         p (n, 3) positions, w (n,) powers, wl (n,) wavelengths: NumPy arrays, or device tensors in the
         layout `ot_detector_hits` produces (p flat component-major).  Hits with w == 0 add nothing.
+        The image stays in HBM; `_data` copies it to the host when it is first read (`_keep_on_device` is accepted
+        for older callers and has no effect).
         """
         self._limit = limit
         self._fix_extent()
@@ -137,8 +151,7 @@ class RenderImage(BaseClass):
             _capi.check(lib.ot_render_accumulate(n, ptr(px), ptr(py), ptr(dw), ptr(dwl), ext, Nx, Ny,
                                                  ptr(hist), stream_ptr()))
         self._dev = hist.view(Ny, Nx, 4)
-        if not _keep_on_device:
-            self._data = self._dev.cpu().numpy()
+        self._host = None
         if not _dont_filter and self._limit is not None:
             self._apply_rayleigh_filter()
 
@@ -160,7 +173,7 @@ class RenderImage(BaseClass):
             raise ValueError(f"Invalid display_mode {mode}, should be one of {self.image_modes}.")
         lib = _capi.load_library()
         dev = require_device()
-        Ny, Nx, _ = self._data.shape
+        Ny, Nx, _ = self.shape
         Na = self.SIZES[int(np.argmin(np.abs(N - np.array(self.SIZES))))]
         fact = int(self.MAX_IMAGE_SIDE / Na)
         nx, ny = Nx // fact, Ny // fact
@@ -180,7 +193,8 @@ class RenderImage(BaseClass):
         return ScalarImage(data.reshape(ny, nx), **iargs)
 
     def _sync_host(self) -> None:
-        self._data = self._dev.cpu().numpy()
+        """The device histogram changed: the host copy is made again when `_data` is next read."""
+        self._host = None
 
     # ---- on-disk format (render_image.py:298-328): same keys, files are interchangeable with the reference ----
     def save(self, path: str) -> None:
@@ -200,8 +214,7 @@ class RenderImage(BaseClass):
                          projection=str(io["proj"][()]))
         im._limit = io["limit"][()] if not np.isnan(io["limit"]) else None
         im.projection = None if im.projection == "None" else im.projection  # None is stored as a string
-        im._data = np.ascontiguousarray(io["_data"], dtype=np.float64)
-        im._dev = None  # uploaded on first use (get / filter)
+        im._data = np.ascontiguousarray(io["_data"], dtype=np.float64)  # uploaded on first use (get / filter)
         return im
 
     def _apply_rayleigh_filter(self) -> None:
@@ -210,8 +223,8 @@ class RenderImage(BaseClass):
         import scipy.special
         if self._limit is not None and self.projection is not None:
             raise RuntimeError("Resolution limit filter is not applicable for a projected image.")
-        px = self._limit / 1000.0 / (self.s[0] / self._data.shape[1])
-        py = self._limit / 1000.0 / (self.s[1] / self._data.shape[0])
+        px = self._limit / 1000.0 / (self.s[0] / self.shape[1])
+        py = self._limit / 1000.0 / (self.s[1] / self.shape[0])
         ps = int(np.ceil(2.7 * max(px, py)))
         ps = ps + 1 if ps % 2 else ps
         Y, X = np.mgrid[-ps:ps:(2 * ps + 1) * 1j, -ps:ps:(2 * ps + 1) * 1j]
@@ -223,13 +236,13 @@ class RenderImage(BaseClass):
         psf *= 1 / psf.sum()
         lib = _capi.load_library()
         dev = require_device()
-        Ny, Nx, _ = self._data.shape
+        Ny, Nx, _ = self.shape
         src = (self._dev if self._dev is not None else to_dev(self._data, np.float64)).reshape(-1)
         out = torch.empty_like(src)
         dpsf = to_dev(psf, np.float64)
         _capi.check(lib.ot_image_convolve(ptr(src), Nx, Ny, ptr(dpsf), ps, ptr(out), stream_ptr()))
         self._dev = out.view(Ny, Nx, 4)
-        self._data = self._dev.cpu().numpy()
+        self._host = None
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key == "extent" and val is not None:
@@ -243,4 +256,7 @@ class RenderImage(BaseClass):
             val = float(val)
         elif key == "projection":
             check_type(key, val, (str, type(None)))
+        elif key == "_data":  # an image assigned from outside replaces the histogram; it is uploaded when next needed
+            super().__setattr__("_dev", None)
+            key = "_host"
         super().__setattr__(key, val)
