@@ -7,7 +7,7 @@
 // trace that produced them.  Here the image is cut into 64 x 64 pixel tiles; one tile's four planes are 128 KB and
 // fit the 160 KB of LDS of a CU:
 //
-//   probe    one workgroup looks at 16 k hits spread over the list; few distinct pixels -> the direct path runs
+//   probe    one workgroup looks at 4096 hits spread over the list; few distinct pixels -> the direct path runs
 //            and the kernels below return at once (no host round trip)
 //   count    hits per tile of every workgroup's contiguous piece of the list            reads x, y, w      20 B/hit
 //   cursor   every piece's write cursor inside each tile's part of the list (one wave per tile)
@@ -24,8 +24,8 @@
 #define OT_TILE_PX (OT_TILE_W * OT_TILE_W)
 #define OT_TILE_MAX 2048           // tiles of the largest image (945 x 4725 -> 15 x 74)
 #define OT_TILE_PIECES 1024        // workgroups of count / scatter: contiguous pieces of the hit list
-#define OT_TILE_PROBE 16384        // hits the probe looks at
-#define OT_TILE_PROBE_SET 32768    // hash set of the probe (ints, 128 KB)
+#define OT_TILE_PROBE 4096         // hits the probe looks at
+#define OT_TILE_PROBE_SET 8192     // hash set of the probe (ints, 32 KB)
 #define OT_TILE_DISTINCT 1024      // more distinct pixels than this among the probed hits: tile path
 
 struct TileArgs {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(1024) void tile_probe_kernel(TileArgs t, const doub
         int32_t ix, iy;
         const int pix = hit_pixel(t.a, px[i], py[i], ix, iy);
         if (pix < 0) continue;
-        unsigned int h = ((unsigned int)pix * 2654435761u) >> (32 - 15);
+        unsigned int h = ((unsigned int)pix * 2654435761u) >> (32 - 13);  // OT_TILE_PROBE_SET = 2^13
         for (int pr = 0; pr < OT_TILE_PROBE_SET; pr++) {  // the set is twice as large as the sample: always ends
             const int sidx = (int)((h + pr) & (OT_TILE_PROBE_SET - 1));
             int k0 = pset[sidx];

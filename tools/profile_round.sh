@@ -1,0 +1,42 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence behind bench.py's numbers on the GPU box and writes the summaries to
+# gpurun_out/profile/ (copy what should be judged into profiles/<round>/).  Three runs, as the profiling rules ask:
+# kernel trace + stats, then one --pmc pass per HBM counter.  Usage: bash tools/profile_round.sh
+set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/profile
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --skip-cpu > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu > "$OUT/bench_write.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/sq" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu > "$OUT/bench_sq.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/detector" -- python3 "$R/tools/bench_detector.py" > "$OUT/detector.log" 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, json, os, sys
+out = sys.argv[1]
+newest = lambda pat: max(glob.glob(os.path.join(out, pat)), key=os.path.getmtime)
+# kernel stats of the bench run
+os.replace(newest("stats/*/*_kernel_stats.csv"), os.path.join(out, "bench_kernel_stats.csv"))
+rows = [r for r in csv.DictReader(open(newest("stats/*/*_kernel_trace.csv"))) if "trace_kernel" in r["Kernel_Name"]]
+ms = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 4) for r in rows]
+line = [l for l in open(os.path.join(out, "bench_stats.log")) if l.startswith("{")]
+json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu   (30 warm-up + 50 timed launches)",
+           "kernel": rows[0]["Kernel_Name"][:40], "launch_ms": ms, "timed_mean_ms": sum(ms[-50:]) / 50,
+           "bench_line": json.loads(line[-1]) if line else None}, open(os.path.join(out, "trace_kernel_launches.json"), "w"), indent=1)
+pmc = {"rays": 10000000, "pol": True, "unit": "KB per launch",
+       "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --skip-cpu"}
+for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    rows = [r for r in csv.DictReader(open(newest(d + "/*/*_counter_collection.csv"))) if "trace_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    pmc[name] = [float(r["Counter_Value"]) for r in rows]
+json.dump(pmc, open(os.path.join(out, "trace_kernel_pmc.json"), "w"), indent=1)
+sq = {}
+for r in csv.DictReader(open(newest("sq/*/*_counter_collection.csv"))):
+    if "trace_kernel" in r["Kernel_Name"]:
+        sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+json.dump({k: sum(v) / len(v) for k, v in sq.items()}, open(os.path.join(out, "trace_kernel_sq.json"), "w"), indent=1)
+os.replace(newest("detector/*/*_kernel_stats.csv"), os.path.join(out, "detector_kernel_stats.csv"))
+print(open(os.path.join(out, "trace_kernel_sq.json")).read())
+print("timed mean ms", sum(ms[-50:]) / 50)
+PY
+grep -v amdgpu.ids "$OUT/detector.log" | grep "rays/s" > "$OUT/detector_full_size_profiled.txt" || true
