@@ -371,6 +371,22 @@ int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot
                      int32_t projection, const double* crop4, double* ph, float* hw, double* extent4,
                      int64_t* ill_count, void* stream);
 
+/* The same for up to 8 detectors (or positions of one detector) in one pass over the ray sections: the sections are
+ * read once, every request gets its own outputs.  Serves Raytracer.iterative_render with a list of detector positions
+ * (raytracer.py:1235-1267). */
+typedef struct ot_detector_req {
+    const ot_surface* detector;
+    int32_t projection;   /* OT_PROJ_*                                              */
+    int32_t _pad;
+    const double* crop4;  /* HOST f64[4] user extent or NULL                        */
+    double* ph;           /* device (count,3) F-order                               */
+    float* hw;            /* device (count)                                         */
+    double* extent4;      /* device f64[4] or NULL, initialised by the caller       */
+    int64_t* ill_count;   /* device int64[2], added to                              */
+} ot_detector_req;
+int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_req* reqs,
+                           int32_t n_reqs, void* stream);
+
 /* SphericalSurface.sphere_projection (spherical_surface.py:36-97): p (n,3) F-order -> out (n,3) F-order */
 int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, const double* p, double* out,
                          void* stream);

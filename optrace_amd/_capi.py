@@ -92,6 +92,12 @@ class Source(C.Structure):
                 ("s_or", C.c_void_p), ("n_or", C.c_int64)]
 
 
+class DetectorReq(C.Structure):
+    _fields_ = [("detector", C.c_void_p), ("projection", C.c_int32), ("_pad", C.c_int32),
+                ("crop4", C.c_void_p), ("ph", C.c_void_p), ("hw", C.c_void_p), ("extent4", C.c_void_p),
+                ("ill_count", C.c_void_p)]
+
+
 class SourceRange(C.Structure):
     _fields_ = [("source", C.c_int32), ("_pad", C.c_int32), ("first", C.c_int64), ("count", C.c_int64),
                 ("ray_power", C.c_double)]
@@ -128,6 +134,7 @@ SIGNATURES = {
     "ot_surface_hurb_props": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp, vp, vp, vp]),
     "ot_refraction_index": (C.c_int, [C.POINTER(Medium), vp, i64, i64, vp, vp, vp]),
     "ot_detector_hits": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(Surface), i32, C.POINTER(C.c_double), vp, vp, vp, vp, vp]),
+    "ot_detector_hits_multi": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(DetectorReq), i32, vp]),
     "ot_sphere_projection": (C.c_int, [C.POINTER(Surface), i32, i64, vp, vp, vp]),
     "ot_image_convert": (C.c_int, [vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]),
     "ot_image_convolve": (C.c_int, [vp, i32, i32, vp, i32, vp, vp]),

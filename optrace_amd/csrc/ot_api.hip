@@ -1221,39 +1221,94 @@ extern "C" int ot_refraction_index(const ot_medium* medium, const double* table_
 }
 
 // ---- detector + render -------------------------------------------------------------------------------------
+extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_req* reqs,
+                                      int32_t n_reqs, void* stream) {
+    if (!rays || !reqs || n_reqs < 1) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
+    if (n_reqs > OT_DET_MAX) return fail(OT_ERR_INVALID, "ot_detector_hits_multi: at most 8 detectors per call");
+    if (!rays->p || !rays->w) return fail(OT_ERR_INVALID, "ot_detector_hits: ray storage has null buffers");
+    if (first < 0 || count < 0 || first + count > rays->N) return fail(OT_ERR_INVALID, "ot_detector_hits: range outside the storage");
+    for (int k = 0; k < n_reqs; k++) {
+        const ot_detector_req& q = reqs[k];
+        if (!q.detector || !q.ph || !q.hw || !q.ill_count) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
+        if (q.projection < OT_PROJ_NONE || q.projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
+    }
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<LeafSurface> ls(n_reqs);
+    std::vector<DetOne> host(n_reqs);
+    bool numeric = false;
+    int n_ext = 0;
+    for (int k = 0; k < n_reqs; k++) {
+        if (int rc = ls[k].init(reqs[k].detector, st)) return rc;
+        n_ext += reqs[k].extent4 != nullptr;
+    }
+    if (count == 0) return OT_OK;
+    // one stream-ordered scratch block: the detector records, then the extent slot tables
+    const size_t o_slots = align_up(sizeof(DetOne) * n_reqs);
+    const size_t total = o_slots + sizeof(unsigned long long) * 4 * OT_EXT_SLOTS * (size_t)n_ext;
+    char* scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&scratch, total, st));
+    unsigned long long* slots = (unsigned long long*)(scratch + o_slots);
+    int e = 0;
+    for (int k = 0; k < n_reqs; k++) {
+        DetOne& d = host[k];
+        std::memset(&d, 0, sizeof(d));
+        d.det = ls[k].d;
+        d.Rcurv = reqs[k].detector->R;
+        if (reqs[k].crop4) d.crop = {reqs[k].crop4[0], reqs[k].crop4[1], reqs[k].crop4[2], reqs[k].crop4[3], 1};
+        d.ph = reqs[k].ph;
+        d.hw = reqs[k].hw;
+        d.ill = (unsigned long long*)reqs[k].ill_count;
+        d.projection = reqs[k].projection;
+        if (reqs[k].extent4) d.ext_slots = slots + (size_t)4 * OT_EXT_SLOTS * e++;
+        numeric = numeric || !(d.det.kind == OT_SURF_CONIC || d.det.flat);
+    }
+    hipError_t err = hipSuccess;
+    if (n_reqs > 1) err = hipMemcpyAsync(scratch, host.data(), sizeof(DetOne) * n_reqs, hipMemcpyHostToDevice, st);
+    if (err == hipSuccess) {
+        if (n_ext) hipLaunchKernelGGL(extent_init_kernel, dim3(n_ext), dim3(4 * OT_EXT_SLOTS), 0, st, slots);
+        if (n_reqs == 1) {  // the record travels in the kernel arguments (scalar registers)
+            if (numeric)
+                hipLaunchKernelGGL(detector_kernel<true>, grid_for(count), dim3(256), 0, st, *rays, first, count, host[0]);
+            else
+                hipLaunchKernelGGL(detector_kernel<false>, grid_for(count), dim3(256), 0, st, *rays, first, count, host[0]);
+        } else {
+            const dim3 g = grid_for(count), b(256);
+            const DetOne* dd = (const DetOne*)scratch;
+#define OT_LAUNCH_DET(NUM, ND) hipLaunchKernelGGL((detector_multi_kernel<NUM, ND>), g, b, 0, st, *rays, first, count, dd, n_reqs)
+            if (numeric) {
+                OT_LAUNCH_DET(true, 8);
+            } else {
+                if (n_reqs <= 2) OT_LAUNCH_DET(false, 2);
+                else if (n_reqs <= 4) OT_LAUNCH_DET(false, 4);
+                else OT_LAUNCH_DET(false, 8);
+            }
+#undef OT_LAUNCH_DET
+        }
+        e = 0;
+        for (int k = 0; k < n_reqs; k++)
+            if (reqs[k].extent4)
+                hipLaunchKernelGGL(extent_final_kernel, dim3(1), dim3(64), 0, st, slots + (size_t)4 * OT_EXT_SLOTS * e++, reqs[k].extent4);
+        err = hipGetLastError();
+    }
+    (void)hipFreeAsync(scratch, st);
+    HIP_TRY(err);
+    return OT_OK;
+}
+
 extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
                                 int32_t projection, const double* crop4, double* ph, float* hw, double* extent4,
                                 int64_t* ill_count, void* stream) {
-    if (!rays || !detector || !ph || !hw || !ill_count) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
-    if (!rays->p || !rays->w) return fail(OT_ERR_INVALID, "ot_detector_hits: ray storage has null buffers");
-    if (first < 0 || count < 0 || first + count > rays->N) return fail(OT_ERR_INVALID, "ot_detector_hits: range outside the storage");
-    if (projection < OT_PROJ_NONE || projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
-    if (int rc = require_device()) return rc;
-    LeafSurface ls;
-    if (int rc = ls.init(detector, (hipStream_t)stream)) return rc;
-    const SurfDev& d = ls.d;
-    if (count == 0) return OT_OK;
-    double R = detector->R;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned long long* slots = nullptr;
-    if (extent4) {  // stream-ordered scratch for the extent slot tables
-        HIP_TRY(hipMallocAsync((void**)&slots, sizeof(unsigned long long) * 4 * OT_EXT_SLOTS, st));
-        hipLaunchKernelGGL(extent_init_kernel, dim3(1), dim3(4 * OT_EXT_SLOTS), 0, st, slots);
-    }
-    Crop crop = {0.0, 0.0, 0.0, 0.0, 0};
-    if (crop4) crop = {crop4[0], crop4[1], crop4[2], crop4[3], 1};
-    if (d.kind == OT_SURF_CONIC || d.flat)
-        hipLaunchKernelGGL(detector_kernel<false>, grid_for(count), dim3(256), 0, st, *rays, first, count, d, R, projection, ph,
-                           hw, slots, (unsigned long long*)ill_count, crop);
-    else
-        hipLaunchKernelGGL(detector_kernel<true>, grid_for(count), dim3(256), 0, st, *rays, first, count, d, R, projection, ph,
-                           hw, slots, (unsigned long long*)ill_count, crop);
-    if (extent4) {
-        hipLaunchKernelGGL(extent_final_kernel, dim3(1), dim3(64), 0, st, slots, extent4);
-        HIP_TRY(hipFreeAsync(slots, st));
-    }
-    HIP_TRY(hipGetLastError());
-    return OT_OK;
+    ot_detector_req q;
+    q.detector = detector;
+    q.projection = projection;
+    q._pad = 0;
+    q.crop4 = crop4;
+    q.ph = ph;
+    q.hw = hw;
+    q.extent4 = extent4;
+    q.ill_count = ill_count;
+    return ot_detector_hits_multi(rays, first, count, &q, 1, stream);
 }
 
 extern "C" int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, const double* p, double* out,

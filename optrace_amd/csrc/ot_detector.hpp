@@ -45,7 +45,7 @@ OT_HD double ordered_to_f64(unsigned long long u) {
 #define OT_EXT_SLOTS 64  // extent slot tables: workgroup b updates table b % 64 (four ordered values each)
 
 __global__ void extent_init_kernel(unsigned long long* __restrict__ slots) {
-    const int i = threadIdx.x;  // 4 * OT_EXT_SLOTS threads
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 4 * OT_EXT_SLOTS threads per slot table set
     slots[i] = (i & 1) ? 0ull : ~0ull;  // max entries start at the smallest, min entries at the largest code
 }
 
@@ -128,21 +128,45 @@ struct Crop {
     int on;
 };
 
-// Raytracer._hit_detector raytracer.py:922-1051, one lane per ray of [first, first+count).
-// ill_count[0] += ill-conditioned rays, ill_count[1] += rays whose numeric hit search timed out.
+// One detector of a launch.  Several positions of `iterative_render` (raytracer.py:1235-1267) are intersected in one
+// pass over the ray sections: the sections are read once, every detector writes its own hits.
+#define OT_DET_MAX 8
+struct DetOne {
+    SurfDev det;
+    double Rcurv;
+    Crop crop;
+    double* ph;                     // (count, 3) F-order projected hits
+    float* hw;                      // (count) weights, 0 = no valid hit
+    unsigned long long* ext_slots;  // extent slot tables or null
+    unsigned long long* ill;        // [2] ill-conditioned, timed out
+    int projection;
+    int _pad;
+};
+
+// Raytracer._hit_detector raytracer.py:922-1051, one lane per ray of [first, first+count), n_det detectors.
+// ill[0] += ill-conditioned rays, ill[1] += rays whose numeric hit search timed out.
 // NUMERIC = false: detectors with a closed-form hit (flat, conic) -- without the Illinois loop and the spline code the
 // kernel needs a third of the registers, and this kernel lives on loads in flight.
-template <bool NUMERIC>
-__global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first, int64_t count, SurfDev det, double Rcurv,
-                                                       int projection, double* __restrict__ ph_out, float* __restrict__ hw_out,
-                                                       unsigned long long* __restrict__ ext_slots,
-                                                       unsigned long long* __restrict__ ill_count, Crop crop) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = q < count;
-    const int64_t r = first + (active ? q : 0);
+struct SectionPair {  // the last two sections of a ray and the weight of the last but one
+    double zl, zq, xl, xq, yl, yq;
+    float wq;
+};
+
+template <bool NUMERIC, class DET>
+OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, int64_t count, DET& D, const SectionPair& sp,
+                         double (*sext)[4]) {
     const int64_t N = R.N;
     const int nt = R.nt;
+    const int lane = __lane_id();
+    const double* __restrict__ zp = R.p + r + N * (2 * (int64_t)nt);
+    const double* __restrict__ xp = R.p + r;
+    const double* __restrict__ yp = R.p + r + N * (int64_t)nt;
+    const int kq = nt >= 2 ? nt - 2 : 0;
+    const double zl = sp.zl, zq = sp.zq, xl = sp.xl, xq = sp.xq, yl = sp.yl, yq = sp.yq;
+    const float wq = sp.wq;
+    {
 
+    const auto& det = D.det;
     V3 ph = {0.0, 0.0, 0.0};
     float w = 0.f;
     bool ish = false, any_ill = false, timeout = false;
@@ -154,15 +178,6 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
         // search: 2 + log2(nt) plane reads per ray instead of nt.
         // The planes are read from the far end: a detector behind the last surface (the usual place) is settled by
         // the last two, z[nt-2] < z_min <= z[nt-1].
-        const double* __restrict__ zp = R.p + r + N * (2 * (int64_t)nt);
-        const double* __restrict__ xp = R.p + r;
-        const double* __restrict__ yp = R.p + r + N * (int64_t)nt;
-        const int kq = nt >= 2 ? nt - 2 : 0;
-        // everything the usual case needs is requested at once (one memory round trip instead of three)
-        const double zl = zp[N * (int64_t)(nt - 1)], zq = zp[N * (int64_t)kq];
-        const double xl = xp[N * (int64_t)(nt - 1)], xq = xp[N * (int64_t)kq];
-        const double yl = yp[N * (int64_t)(nt - 1)], yq = yp[N * (int64_t)kq];
-        const float wq = R.w[r + N * (int64_t)kq];
         bool all_b = false;                                            // np.all(bh_zmin & bh_zmax): starts behind it
         const bool all_nb = !(zl >= det.z_min) && !(zl >= det.z_max);  // np.all(~bh_zmin & ~bh_zmax): ends before
         int first_ge = -1;
@@ -224,25 +239,23 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
         }
     }
     bool valid = active && ish && (w > 0);
-    if (valid) sphere_project(det.px, det.py, det.pz, Rcurv, projection, ph);
+    if (valid) sphere_project(det.px, det.py, det.pz, D.Rcurv, D.projection, ph);
     // user extent: hits outside are dropped (raytracer.py:1036-1040)
-    if (crop.on) valid = valid && crop.x0 <= ph.x && ph.x <= crop.x1 && crop.y0 <= ph.y && ph.y <= crop.y1;
+    if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
     if (active) {
-        ph_out[q] = valid ? ph.x : 0.0;
-        ph_out[q + count] = valid ? ph.y : 0.0;
-        ph_out[q + 2 * count] = valid ? ph.z : 0.0;
-        hw_out[q] = valid ? w : 0.f;
+        D.ph[q] = valid ? ph.x : 0.0;
+        D.ph[q + count] = valid ? ph.y : 0.0;
+        D.ph[q + 2 * count] = valid ? ph.z : 0.0;
+        D.hw[q] = valid ? w : 0.f;
     }
     // counters and extent: wave-level reduction, one atomic per wave
     unsigned long long m_ill = __ballot(any_ill), m_to = __ballot(timeout);
-    const int lane = __lane_id();
     if (lane == 0) {
-        if (m_ill) atomicAdd(&ill_count[0], (unsigned long long)__popcll(m_ill));
-        if (m_to) atomicAdd(&ill_count[1], (unsigned long long)__popcll(m_to));
+        if (m_ill) atomicAdd(&D.ill[0], (unsigned long long)__popcll(m_ill));
+        if (m_to) atomicAdd(&D.ill[1], (unsigned long long)__popcll(m_to));
     }
-    if (ext_slots) {  // extent of the valid hits: wave shuffle -> LDS across the four waves -> one slot table
+    if (D.ext_slots) {  // extent of the valid hits: wave shuffle -> LDS across the four waves -> one slot table
         const double inf = __builtin_inf();
-        __shared__ double sext[4][4];
         double e[4] = {wave_min(valid ? ph.x : inf), wave_max(valid ? ph.x : -inf), wave_min(valid ? ph.y : inf),
                        wave_max(valid ? ph.y : -inf)};
         const int wave = threadIdx.x >> 6;
@@ -254,13 +267,64 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
             double v = sext[0][c];
             for (int k = 1; k < 4; k++) v = (c & 1) ? fmax(v, sext[k][c]) : fmin(v, sext[k][c]);
             if (v == v && v != ((c & 1) ? -inf : inf)) {
-                unsigned long long* dst = ext_slots + 4 * (blockIdx.x % OT_EXT_SLOTS) + c;
+                unsigned long long* dst = D.ext_slots + 4 * (blockIdx.x % OT_EXT_SLOTS) + c;
                 if (c & 1)
                     atomicMax(dst, f64_to_ordered(v));
                 else
                     atomicMin(dst, f64_to_ordered(v));
             }
         }
+        __syncthreads();  // sext is used again by the next detector
+    }
+    }
+}
+
+OT_DEV SectionPair load_section_pair(const ot_rays& R, int64_t r, bool active) {
+    // everything the usual case needs is requested at once (one memory round trip instead of three)
+    SectionPair sp = {0, 0, 0, 0, 0, 0, 0.f};
+    if (active) {
+        const int64_t N = R.N;
+        const int nt = R.nt;
+        const double* __restrict__ zp = R.p + r + N * (2 * (int64_t)nt);
+        const double* __restrict__ xp = R.p + r;
+        const double* __restrict__ yp = R.p + r + N * (int64_t)nt;
+        const int kq = nt >= 2 ? nt - 2 : 0;
+        sp.zl = zp[N * (int64_t)(nt - 1)], sp.zq = zp[N * (int64_t)kq];
+        sp.xl = xp[N * (int64_t)(nt - 1)], sp.xq = xp[N * (int64_t)kq];
+        sp.yl = yp[N * (int64_t)(nt - 1)], sp.yq = yp[N * (int64_t)kq];
+        sp.wq = R.w[r + N * (int64_t)kq];
+    }
+    return sp;
+}
+
+// one detector, its record in the kernel arguments (scalar registers)
+template <bool NUMERIC>
+__global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first, int64_t count, DetOne D) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < count;
+    const int64_t r = first + (active ? q : 0);
+    __shared__ double sext[4][4];
+    const SectionPair sp = load_section_pair(R, r, active);
+    detector_one<NUMERIC>(R, q, r, active, count, D, sp, sext);
+}
+
+// several detectors, records in device memory.  The detector loop is unrolled at compile time (NDET = 2, 4, 8; unused
+// entries repeat the last record's outputs with a null hit list): as a run-time loop every lane constant of the body is
+// hoisted and kept in registers, 157 instead of 77 VGPRs and half the waves in flight.
+template <bool NUMERIC, int NDET>
+__global__ __launch_bounds__(256) void detector_multi_kernel(ot_rays R, int64_t first, int64_t count,
+                                                             const DetOne* __restrict__ dets, int n_det) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < count;
+    const int64_t r = first + (active ? q : 0);
+    __shared__ double sext[4][4];
+    const SectionPair sp = load_section_pair(R, r, active);
+    if constexpr (NUMERIC) {  // the Illinois loop and the spline code do not unroll; rare as detectors (run-time loop)
+        for (int di = 0; di < n_det; di++) detector_one<NUMERIC>(R, q, r, active, count, as_const(dets)[di], sp, sext);
+    } else {
+#pragma unroll
+        for (int di = 0; di < NDET; di++)
+            if (di < n_det) detector_one<NUMERIC>(R, q, r, active, count, as_const(dets)[di], sp, sext);
     }
 }
 

@@ -13,28 +13,55 @@ from . import _capi
 from ._device import require_device, stream_ptr, ptr, to_dev, f_order_flat, from_f_order
 
 
+def detector_hits_multi(rays, first: int, count: int, requests: list):
+    """Hit search for several detectors in one pass over the ray sections (`ot_detector_hits_multi`).
+
+    requests: dicts with surf_desc (_capi.Surface), projection (int), want_extent (bool), crop ([x0, x1, y0, y1] or
+    None: hits outside come back with weight 0, raytracer.py:1036-1040).
+    -> list of (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count)."""
+    lib = _capi.load_library()
+    dev = require_device()
+    n = len(requests)
+    reqs = (_capi.DetectorReq * n)()
+    keep, outs = [], []
+    ill = torch.zeros(2 * n, dtype=torch.int64, device=dev)
+    any_numeric = False
+    for k, rq in enumerate(requests):
+        sd = rq["surf_desc"]
+        ph = torch.empty(3 * count, dtype=torch.float64, device=dev)
+        hw = torch.empty(count, dtype=torch.float32, device=dev)
+        ext = None
+        if rq["want_extent"]:
+            ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float64, device=dev)
+        crop4 = None if rq.get("crop") is None else (C.c_double * 4)(*(float(v) for v in rq["crop"]))
+        keep.append((sd, crop4))
+        r = reqs[k]
+        r.detector = C.addressof(sd)
+        r.projection = int(rq["projection"])
+        r.crop4 = None if crop4 is None else C.addressof(crop4)
+        r.ph, r.hw, r.extent4 = ph.data_ptr(), hw.data_ptr(), (ext.data_ptr() if ext is not None else None)
+        r.ill_count = ill.data_ptr() + 16 * k
+        # closed-form hits (flat / conic detectors) can neither be ill-conditioned nor time out
+        numeric = sd.kind >= _capi.SURF_ASPHERE and sd.z_min != sd.z_max
+        any_numeric = any_numeric or numeric
+        outs.append([ph, hw, ext, numeric])
+    rs = rays._rays_struct()
+    _capi.check(lib.ot_detector_hits_multi(C.byref(rs), int(first), int(count), reqs, n, stream_ptr()))
+    ill_h = ill.cpu().numpy() if any_numeric else np.zeros(2 * n, dtype=np.int64)  # no read-back, no sync otherwise
+    res = []
+    for k, (ph, hw, ext, numeric) in enumerate(outs):
+        if ill_h[2 * k + 1]:
+            raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
+        res.append((ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill_h[2 * k])))
+    return res
+
+
 def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projection: int, want_extent: bool,
                   crop=None):
     """-> (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count).
     `crop` = user extent [x0, x1, y0, y1]: hits outside it come back with weight 0 (raytracer.py:1036-1040)."""
-    lib = _capi.load_library()
-    dev = require_device()
-    ph = torch.empty(3 * count, dtype=torch.float64, device=dev)
-    hw = torch.empty(count, dtype=torch.float32, device=dev)
-    ill = torch.zeros(2, dtype=torch.int64, device=dev)
-    ext = None
-    if want_extent:
-        ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float64, device=dev)
-    rs = rays._rays_struct()
-    crop4 = None if crop is None else (C.c_double * 4)(*(float(v) for v in crop))
-    _capi.check(lib.ot_detector_hits(C.byref(rs), int(first), int(count), C.byref(surf_desc), int(projection), crop4,
-                                     ptr(ph), ptr(hw), ptr(ext), ptr(ill), stream_ptr()))
-    # closed-form hits (flat / conic detectors) can neither be ill-conditioned nor time out: no read-back, no sync
-    numeric = surf_desc.kind >= _capi.SURF_ASPHERE and surf_desc.z_min != surf_desc.z_max
-    ill_h = ill.cpu().numpy() if numeric else (0, 0)
-    if ill_h[1]:
-        raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
-    return ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill_h[0])
+    return detector_hits_multi(rays, first, count, [dict(surf_desc=surf_desc, projection=projection,
+                                                         want_extent=want_extent, crop=crop)])[0]
 
 
 def project_points(surf_desc: _capi.Surface, p: np.ndarray, projection: int) -> np.ndarray:

@@ -376,50 +376,89 @@ class Raytracer(Group):
         self._last_trace_snapshot = snap
 
     # ---- detector (raytracer.py:881-1098) ----------------------------------------------------------------
-    def _hit_detector(self, info: str, detector_index: int = 0, source_index: int = None, extent=None,
-                      projection_method: str = "Equidistant"):
-        """Device hit search -> (ph, hw, wl) device tensors of the selected ray range (dense: rays without a
-        valid hit carry weight 0), the extent actually used, the projection name and the ill-conditioned count."""
+    def _hit_detectors(self, info: str, specs: list) -> list:
+        """Device hit search for several (detector, position) pairs in one pass over the ray sections.
+
+        specs: dicts with detector_index, source_index, extent, projection_method and optionally pos (the detector is
+        moved there first, as `iterative_render` does position by position, raytracer.py:1244).
+        -> per spec (ph, hw, wl, extent_out, projection, ill_count, desc): device tensors of the selected ray range
+        (dense: rays without a valid hit carry weight 0), the extent actually used, the projection name, the
+        ill-conditioned count and the image description at that position."""
         if not self.detectors:
             raise RuntimeError("Detector Missing")
         if not self.rays.N:
             raise RuntimeError("No rays traced.")
-        if source_index is not None and (source_index > len(self.ray_sources) - 1 or source_index < 0):
-            raise IndexError("Invalid source_index.")
-        if detector_index > len(self.detectors) - 1 or detector_index < 0:
-            raise IndexError("Invalid detector_index.")
+        for sp in specs:
+            source_index, detector_index = sp.get("source_index"), sp.get("detector_index", 0)
+            if source_index is not None and (source_index > len(self.ray_sources) - 1 or source_index < 0):
+                raise IndexError("Invalid source_index.")
+            if detector_index > len(self.detectors) - 1 or detector_index < 0:
+                raise IndexError("Invalid detector_index.")
         if not self._rays_known_current and not self.check_if_rays_are_current():
             raise RuntimeError("Tracing geometry/properties changed. Please retrace first.")
 
-        Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
-        Ns, Ne = int(Ns), int(Ne)
-        dsurf = self.detectors[detector_index].surface
+        groups: dict = {}  # ray range -> requests (one launch per range and at most 8 detectors)
+        meta = []
+        for n, sp in enumerate(specs):
+            source_index, detector_index = sp.get("source_index"), sp.get("detector_index", 0)
+            extent, projection_method = sp.get("extent"), sp.get("projection_method", "Equidistant")
+            Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
+            Ns, Ne = int(Ns), int(Ne)
+            det = self.detectors[detector_index]
+            if sp.get("pos") is not None:
+                det.move_to(sp["pos"])
+            dsurf = det.surface
 
-        if isinstance(dsurf, SphericalSurface) and projection_method is not None:
-            if projection_method not in SphericalSurface.sphere_projection_methods:
-                raise ValueError(f"Invalid projection_method {projection_method}, "
-                                 f"must be one of {SphericalSurface.sphere_projection_methods}.")
-            projection = projection_method
-        else:
-            projection = None
+            if isinstance(dsurf, SphericalSurface) and projection_method is not None:
+                if projection_method not in SphericalSurface.sphere_projection_methods:
+                    raise ValueError(f"Invalid projection_method {projection_method}, "
+                                     f"must be one of {SphericalSurface.sphere_projection_methods}.")
+                projection = projection_method
+            else:
+                projection = None
 
-        if not (extent is None or isinstance(extent, (list, np.ndarray))):
-            raise ValueError(f"Invalid extent '{extent}'.")
+            if not (extent is None or isinstance(extent, (list, np.ndarray))):
+                raise ValueError(f"Invalid extent '{extent}'.")
+            extent_out = None
+            if extent is not None:
+                extent_out = np.asarray_chkfinite(np.array(extent, dtype=np.float64).copy(), dtype=np.float64)
 
-        extent_out = None
-        if extent is not None:
-            extent_out = np.asarray_chkfinite(np.array(extent, dtype=np.float64).copy(), dtype=np.float64)
-        # rays outside a user extent are dropped (raytracer.py:1036-1040): the hit kernel gives them weight 0
-        ph, hw, ext4, ill_count = _detector.detector_hits(self.rays, Ns, Ne - Ns, dsurf._desc(),
-                                                          _capi.PROJECTIONS[projection], extent is None,
-                                                          crop=extent_out)
-        wl = self.rays._dev["wl"][Ns:Ne]
+            pname = f": {det.desc}" if det.desc != "" else ""
+            desc = f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm"
+            # rays outside a user extent are dropped (raytracer.py:1036-1040): the hit kernel gives them weight 0
+            groups.setdefault((Ns, Ne), []).append((n, dict(surf_desc=dsurf._desc(), want_extent=extent is None,
+                                                            projection=_capi.PROJECTIONS[projection], crop=extent_out)))
+            meta.append((Ns, Ne, extent_out, projection, desc, det.pos[:2].repeat(2)))
 
-        if extent is None:
-            extent_out = self.detectors[detector_index].pos[:2].repeat(2)
-            if np.all(np.isfinite(ext4)):
-                extent_out = ext4.copy()
-        return ph, hw, wl, extent_out, projection, ill_count
+        out = [None] * len(specs)
+        for (Ns, Ne), reqs in groups.items():
+            for b in range(0, len(reqs), 8):
+                part = reqs[b:b + 8]
+                res = _detector.detector_hits_multi(self.rays, Ns, Ne - Ns, [r for _, r in part])
+                for (n, _), (ph, hw, ext4, ill_count) in zip(part, res):
+                    _, _, extent_out, projection, desc, centre = meta[n]
+                    if extent_out is None:
+                        extent_out = ext4.copy() if np.all(np.isfinite(ext4)) else centre
+                    out[n] = (ph, hw, self.rays._dev["wl"][Ns:Ne], extent_out, projection, ill_count, desc)
+        return out
+
+    def _hit_detector(self, info: str, detector_index: int = 0, source_index: int = None, extent=None,
+                      projection_method: str = "Equidistant"):
+        """One detector: (ph, hw, wl, extent_out, projection, ill_count), see `_hit_detectors`."""
+        return self._hit_detectors(info, [dict(detector_index=detector_index, source_index=source_index, extent=extent,
+                                               projection_method=projection_method)])[0][:6]
+
+    def _image_from_hits(self, hits: tuple, detector_index: int, source_index, limit, **kwargs) -> RenderImage:
+        p, w, wl, extent_out, projection, ill_count, desc = hits
+        if source_index is not None:
+            desc = f"Rays from RS{source_index} at " + desc
+        img = RenderImage(long_desc=desc, extent=extent_out, projection=projection)
+        img.render(p, w, wl, limit=limit, **kwargs)
+        if ill_count:
+            warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
+                    f"numerical hit finding at detector {detector_index}. "
+                    "Where and whether they intersect might be wrong.")
+        return img
 
     def detector_image(self, detector_index: int = 0, source_index: int = None, extent=None,
                        limit: float = None, projection_method: str = "Equidistant", **kwargs) -> RenderImage:
@@ -428,22 +467,9 @@ class Raytracer(Group):
             warning("Using the limit parameter in combination with a user defined extent"
                     " will produce an incorrect detector image, as the rays outside the extent"
                     " are not included in the convolution calculation.")
-        p, w, wl, extent_out, projection, ill_count = self._hit_detector(
-            "Detector Image", detector_index, source_index, extent, projection_method)
-
-        det = self.detectors[detector_index]
-        pname = f": {det.desc}" if det.desc != "" else ""
-        desc = f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm"
-        if source_index is not None:
-            desc = f"Rays from RS{source_index} at " + desc
-
-        img = RenderImage(long_desc=desc, extent=extent_out, projection=projection)
-        img.render(p, w, wl, limit=limit, **kwargs)
-        if ill_count:
-            warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
-                    f"numerical hit finding at detector {detector_index}. "
-                    "Where and whether they intersect might be wrong.")
-        return img
+        hits = self._hit_detectors("Detector Image", [dict(detector_index=detector_index, source_index=source_index,
+                                                           extent=extent, projection_method=projection_method)])[0]
+        return self._image_from_hits(hits, detector_index, source_index, limit, **kwargs)
 
     def detector_spectrum(self, detector_index: int = 0, source_index: int = None, extent=None,
                           **kwargs) -> LightSpectrum:
@@ -693,16 +719,18 @@ class Raytracer(Group):
                 msgs_cum += self._msgs
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
+                # all positions are intersected in one pass over the sections (`ot_detector_hits_multi`)
+                hits = self._hit_detectors("Detector Image", [
+                    dict(detector_index=detector_index[j], extent=extentc[j], projection_method=projection_method[j],
+                         pos=pos[j]) for j in range(len(pos))])
                 for j in range(len(pos)):
-                    self.detectors[detector_index[j]].move_to(pos[j])
                     # chunks of equal size are binned straight into the image of the first chunk (their common
                     # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
                     # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
                     direct = 0 < i and rays_step == step0
-                    img = self.detector_image(detector_index=detector_index[j], extent=extentc[j], limit=limit[j],
-                                              _dont_filter=True, _keep_on_device=True,
-                                              _into=images[j]._dev if direct else None,
-                                              projection_method=projection_method[j])
+                    img = self._image_from_hits(hits[j], detector_index[j], None, limit[j], _dont_filter=True,
+                                                _into=images[j]._dev if direct else None)
+                    hits[j] = None  # hit lists of a chunk are gigabytes: release each as soon as it is binned
                     if i == 0:
                         images.append(img)
                         extentc[j] = img._extent0
