@@ -171,3 +171,36 @@ def test_backward_directions_raise_like_create_rays():
         rs.div_angle = 20  # inside the forward half space again
         RT.trace(20000)
         assert RT._msgs[RT.INFOS.HURB_NEG_DIR, 0] == 0
+
+
+def test_batched_detector_hits_equal_single_calls():
+    """`ot_detector_hits_multi` (iterative_render's positions in one pass over the sections) gives, detector by
+    detector, exactly what single calls give: positions inside the lens stack, behind it, before the source, a
+    spherical detector with projection, a user extent and automatic extents."""
+    import torch
+    with ot.global_options.no_warnings():
+        RT = scenes.asphere_scene(ot, seed=3)
+        RT.trace(60_000)
+        zs = [-5., 2., 11., 20., 30., 34., 39.]
+        specs = [dict(detector_index=1, pos=[0.1 * k, -0.05 * k, z], extent=None if k % 2 else [-3, 3, -2.5, 2.5])
+                 for k, z in enumerate(zs)]
+        specs += [dict(detector_index=0, pos=[0, 0, 36.], projection_method=pm, extent=None)
+                  for pm in ("Equidistant", "Orthographic")]
+        single = [RT._hit_detectors("t", [sp])[0] for sp in specs]
+        batch = RT._hit_detectors("t", specs)
+        assert len(batch) == len(specs)
+        hits = 0
+        for a, b in zip(single, batch):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])   # positions, weights
+            np.testing.assert_array_equal(a[3], b[3])                     # extent
+            assert a[4] == b[4] and a[5] == b[5] and a[6] == b[6]         # projection, ill count, description
+            hits += int((a[1] > 0).sum())
+        assert hits > 0
+        # iterative_render through the batch equals detector images position by position (same seed, one chunk)
+        RT2 = scenes.asphere_scene(ot, seed=3)
+        pos = [[0, 0, z] for z in (20., 30., 34.)]
+        imgs = RT2.iterative_render(60_000, detector_index=1, pos=pos, extent=[[-4, 4, -4, 4]] * 3)
+        for p_, im in zip(pos, imgs):
+            RT2.detectors[1].move_to(p_)
+            ref = RT2.detector_image(detector_index=1, extent=[-4, 4, -4, 4])
+            np.testing.assert_allclose(im._data, ref._data, rtol=1e-12, atol=1e-300)
