@@ -520,6 +520,19 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
         d.div_axis = s.div_axis_angle * (M_PI / 180.0);
         std::memcpy(d.s, s.s, sizeof(d.s));
         std::memcpy(d.conv_pos, s.conv_pos, sizeof(d.conv_pos));
+        if (s.orientation == OT_OR_CONSTANT || (s.orientation == OT_OR_CONVERGING && s.shape == OT_SRC_POINT)) {
+            if (s.orientation == OT_OR_CONVERGING) {  // misc.normalize(conv_pos - p) with p = pos (ray_source.py:269)
+                const double dx = s.conv_pos[0] - s.pos[0], dy = s.conv_pos[1] - s.pos[1], dz = s.conv_pos[2] - s.pos[2];
+                const double l = std::sqrt(dx * dx + dy * dy + dz * dz);
+                d.s[0] = dx / l; d.s[1] = dy / l; d.s[2] = dz / l;
+            }
+            const double fa = 1.0 / std::sqrt(1 - d.s[0] * d.s[0]);  // ray_source.py:339-341
+            d.fy[0] = 0.0; d.fy[1] = -d.s[2] * fa; d.fy[2] = d.s[1] * fa;
+            d.fx[0] = d.s[1] * d.fy[2] - d.s[2] * d.fy[1];
+            d.fx[1] = d.s[2] * d.fy[0] - d.s[0] * d.fy[2];
+            d.fx[2] = d.s[0] * d.fy[1] - d.s[1] * d.fy[0];
+            d.frame_uniform = 1;
+        }
         d.pol_angle = s.pol_angle;
         d.pol_cos = std::cos(s.pol_angle);
         d.pol_sin = std::sin(s.pol_angle);

@@ -337,7 +337,11 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
 
     // ---- orientation (ray_source.py:264-277) ----
     V3 s_or;
-    if (src.orientation == OT_OR_CONVERGING) {
+    if (src.frame_uniform) {  // one base orientation for the whole source (host): constant, or a point source converging
+        s_or.x = src.s[0];
+        s_or.y = src.s[1];
+        s_or.z = src.s[2];
+    } else if (src.orientation == OT_OR_CONVERGING) {
         V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
         const double il = ot_rcp3(ot_sqrt(d.x * d.x + d.y * d.y + d.z * d.z));
         s_or.x = d.x * il;
@@ -403,9 +407,15 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 }
             }
         }
-        double fa = ot_rcp3(ot_sqrt(1 - s_or.x * s_or.x));
-        V3 sy = {0.0, -s_or.z * fa, s_or.y * fa};
-        V3 sx = cross3(s_or, sy);
+        V3 sx, sy;  // the frame around s_or (ray_source.py:339-341): sy = [1, 0, 0] x s_or, sx = s_or x sy
+        if (src.frame_uniform) {
+            sx = {src.fx[0], src.fx[1], src.fx[2]};
+            sy = {src.fy[0], src.fy[1], src.fy[2]};
+        } else {
+            double fa = ot_rcp3(ot_sqrt(1 - s_or.x * s_or.x));
+            sy = {0.0, -s_or.z * fa, s_or.y * fa};
+            sx = cross3(s_or, sy);
+        }
         s.x = ct * s_or.x + st * (ca * sx.x + sa * sy.x);
         s.y = ct * s_or.y + st * (ca * sx.y + sa * sy.y);
         s.z = ct * s_or.z + st * (ca * sx.z + sa * sy.z);

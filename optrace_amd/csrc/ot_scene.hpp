@@ -132,6 +132,10 @@ struct SourceDev {
     // one 32-byte load, which also decides whether the search has to step (see inv_cdf_linear)
     const double *spec_pairs, *pol_pairs, *div_pairs, *prim_pairs;
     const double* s_or; int64_t n_or;  // OR_ARRAY: caller-owned base orientations x[n_or] | y[n_or] | z[n_or]
+    // the same base orientation for every ray (constant orientation; point source converging onto conv_pos): it is in
+    // `s` and its divergence frame in fx, fy, all evaluated once on the host instead of once per ray
+    int32_t frame_uniform, _pad2;
+    double fx[3], fy[3];
 };
 
 struct ot_sources {
