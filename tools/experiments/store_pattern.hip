@@ -18,6 +18,26 @@ __global__ __launch_bounds__(256) void planar(double* p, double* n, float* w, fl
     }
 }
 
+// planar with non-temporal (streaming) stores: written once, never read by this kernel
+template <int WORK>
+__global__ __launch_bounds__(256) void planar_nt(double* p, double* n, float* w, float* pol, long N, int nt) {
+    long ray = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= N) return;
+    double a = (double)ray * 1e-9, b = 1.0 + a, c = 2.0 - a;
+    for (int sec = 0; sec < nt; sec++) {
+#pragma unroll 1
+        for (int k = 0; k < WORK; k++) { a = a * 1.0000001 + b; b = b * 0.9999999 + c; c = c * 1.0000002 - a; }
+        __builtin_nontemporal_store(a, &p[ray + N * sec]);
+        __builtin_nontemporal_store(b, &p[ray + N * (sec + nt)]);
+        __builtin_nontemporal_store(c, &p[ray + N * (sec + 2L * nt)]);
+        __builtin_nontemporal_store(a + b, &n[ray + N * sec]);
+        __builtin_nontemporal_store((float)c, &w[ray + N * sec]);
+        __builtin_nontemporal_store((float)a, &pol[ray + N * sec]);
+        __builtin_nontemporal_store((float)b, &pol[ray + N * (sec + nt)]);
+        __builtin_nontemporal_store((float)c, &pol[ray + N * (sec + 2L * nt)]);
+    }
+}
+
 // tile = 64 rays x nt sections x (4 f64 + 4 f32) = 64*nt*48 bytes, contiguous per wave
 template <int WORK>
 __global__ __launch_bounds__(256) void tiled(char* buf, long N, int nt) {
@@ -70,6 +90,9 @@ int main() {
         printf("%-28s %.3f ms  %.0f GB/s\n", name, ms, N * nt * 48.0 / ms / 1e6);
     };
     run("planar work=0", [&] { hipLaunchKernelGGL(planar<0>, g, b, 0, 0, p, n, w, pol, N, nt); });
+    run("planar non-temporal work=0", [&] { hipLaunchKernelGGL(planar_nt<0>, g, b, 0, 0, p, n, w, pol, N, nt); });
+    run("planar non-temporal work=60", [&] { hipLaunchKernelGGL(planar_nt<60>, g, b, 0, 0, p, n, w, pol, N, nt); });
+    run("planar non-temporal work=150", [&] { hipLaunchKernelGGL(planar_nt<150>, g, b, 0, 0, p, n, w, pol, N, nt); });
     run("tiled  work=0", [&] { hipLaunchKernelGGL(tiled<0>, g, b, 0, 0, buf, N, nt); });
     run("semi   work=0", [&] { hipLaunchKernelGGL(semi<0>, g, b, 0, 0, p, n, w, pol, N, nt); });
     run("semi   work=60", [&] { hipLaunchKernelGGL(semi<60>, g, b, 0, 0, p, n, w, pol, N, nt); });
