@@ -322,3 +322,32 @@ def test_tilted_data_function_surfaces_host_logic():
         assert f2._sign == -1 and abs(f2._angle - np.pi / 4) < 1e-15 and f2._desc().flags == 0
         f3 = ot.FunctionSurface2D(r=2, func=lambda x, y: x ** 2 / 10, deriv_func=lambda x, y: (x / 5, 0 * y))
         assert f3._desc().flags == _capi.SURF_FLAG_DERIV_UNROTATED
+
+
+@pytest.mark.parametrize("N_list", [[200_001], [1 << 20], [5, 0, 70_000, 1_000_003], [10_000_000 // 5] * 5, [3] * 70,
+                                    [2_000_000_000]])
+def test_source_ranges_are_power_of_two_blocks(N_list):
+    """Stratification blocks of a launch (RayStorage._source_ranges): they tile [0, N) source by source, all but the
+    last block of a source are powers of two in descending order, at most 64 blocks travel as kernel arguments
+    unless there are more sources than that, and every block of a source carries the same ray power."""
+    from optrace_amd.ray_storage import RayStorage
+    st = RayStorage()
+    st.N_list = np.array(N_list)
+    st.B_list = np.concatenate(([0], np.cumsum(N_list)))
+    st.ray_source_list = [ot.RaySource(ot.Point(), spectrum=ot.LightSpectrum("Monochromatic", wl=550.)) for _ in N_list]
+    st._powers = [1.5 + k for k in range(len(N_list))]
+    rng = st._source_ranges()
+    assert len(rng) <= max(64, len(N_list))
+    pos = 0
+    for i, n in enumerate(N_list):
+        blocks = [r for r in rng if r.source == i]
+        assert sum(b.count for b in blocks) == n
+        for b in blocks:
+            assert b.first == pos
+            pos += b.count
+            assert b.ray_power == (st._powers[i] / n if n else 0.)
+        sizes = [b.count for b in blocks[:-1]]
+        assert all(s & (s - 1) == 0 and s >= (1 << 16) for s in sizes) and sizes == sorted(sizes, reverse=True)
+        if len(blocks) > 1:  # the ragged rest is smaller than every power-of-two block before it or the cap was hit
+            assert blocks[-1].count < sizes[-1] or len(blocks) == max(1, 64 // len(N_list))
+    assert pos == sum(N_list)
