@@ -377,9 +377,9 @@ int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot
 typedef struct ot_detector_req {
     const ot_surface* detector;
     int32_t projection;   /* OT_PROJ_*                                              */
-    int32_t _pad;
+    int32_t xy_only;      /* 1: ph is (count,2), the z plane is not written         */
     const double* crop4;  /* HOST f64[4] user extent or NULL                        */
-    double* ph;           /* device (count,3) F-order                               */
+    double* ph;           /* device (count,3) F-order, (count,2) with xy_only       */
     float* hw;            /* device (count)                                         */
     double* extent4;      /* device f64[4] or NULL, initialised by the caller       */
     int64_t* ill_count;   /* device int64[2], added to                              */

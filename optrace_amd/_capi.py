@@ -93,7 +93,7 @@ class Source(C.Structure):
 
 
 class DetectorReq(C.Structure):
-    _fields_ = [("detector", C.c_void_p), ("projection", C.c_int32), ("_pad", C.c_int32),
+    _fields_ = [("detector", C.c_void_p), ("projection", C.c_int32), ("xy_only", C.c_int32),
                 ("crop4", C.c_void_p), ("ph", C.c_void_p), ("hw", C.c_void_p), ("extent4", C.c_void_p),
                 ("ill_count", C.c_void_p)]
 

@@ -1273,6 +1273,7 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
         d.hw = reqs[k].hw;
         d.ill = (unsigned long long*)reqs[k].ill_count;
         d.projection = reqs[k].projection;
+        d.xy_only = reqs[k].xy_only != 0;
         if (reqs[k].extent4) d.ext_slots = slots + (size_t)4 * OT_EXT_SLOTS * e++;
         numeric = numeric || !(d.det.kind == OT_SURF_CONIC || d.det.flat);
     }
@@ -1315,7 +1316,7 @@ extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t coun
     ot_detector_req q;
     q.detector = detector;
     q.projection = projection;
-    q._pad = 0;
+    q.xy_only = 0;
     q.crop4 = crop4;
     q.ph = ph;
     q.hw = hw;

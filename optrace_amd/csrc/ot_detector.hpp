@@ -140,7 +140,7 @@ struct DetOne {
     unsigned long long* ext_slots;  // extent slot tables or null
     unsigned long long* ill;        // [2] ill-conditioned, timed out
     int projection;
-    int _pad;
+    int xy_only;  // the z plane of ph is not wanted (binning and spectra use x, y only)
 };
 
 // Raytracer._hit_detector raytracer.py:922-1051, one lane per ray of [first, first+count), n_det detectors.
@@ -245,7 +245,7 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
     if (active) {
         D.ph[q] = valid ? ph.x : 0.0;
         D.ph[q + count] = valid ? ph.y : 0.0;
-        D.ph[q + 2 * count] = valid ? ph.z : 0.0;
+        if (!D.xy_only) D.ph[q + 2 * count] = valid ? ph.z : 0.0;
         D.hw[q] = valid ? w : 0.f;
     }
     // counters and extent: wave-level reduction, one atomic per wave

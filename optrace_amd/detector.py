@@ -18,7 +18,8 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
 
     requests: dicts with surf_desc (_capi.Surface), projection (int), want_extent (bool), crop ([x0, x1, y0, y1] or
     None: hits outside come back with weight 0, raytracer.py:1036-1040).
-    -> list of (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count)."""
+    -> list of (ph flat f64 device tensor: x plane, y plane and, with want_z, z plane of count entries each, hw (count)
+    f32 device tensor, extent4 or None, ill_count).  Binning and spectra use x and y only."""
     lib = _capi.load_library()
     dev = require_device()
     n = len(requests)
@@ -28,7 +29,8 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
     any_numeric = False
     for k, rq in enumerate(requests):
         sd = rq["surf_desc"]
-        ph = torch.empty(3 * count, dtype=torch.float64, device=dev)
+        want_z = bool(rq.get("want_z", False))
+        ph = torch.empty((3 if want_z else 2) * count, dtype=torch.float64, device=dev)
         hw = torch.empty(count, dtype=torch.float32, device=dev)
         ext = None
         if rq["want_extent"]:
@@ -38,6 +40,7 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         r = reqs[k]
         r.detector = C.addressof(sd)
         r.projection = int(rq["projection"])
+        r.xy_only = 0 if want_z else 1
         r.crop4 = None if crop4 is None else C.addressof(crop4)
         r.ph, r.hw, r.extent4 = ph.data_ptr(), hw.data_ptr(), (ext.data_ptr() if ext is not None else None)
         r.ill_count = ill.data_ptr() + 16 * k
@@ -60,7 +63,7 @@ def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projec
                   crop=None):
     """-> (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count).
     `crop` = user extent [x0, x1, y0, y1]: hits outside it come back with weight 0 (raytracer.py:1036-1040)."""
-    return detector_hits_multi(rays, first, count, [dict(surf_desc=surf_desc, projection=projection,
+    return detector_hits_multi(rays, first, count, [dict(surf_desc=surf_desc, projection=projection, want_z=True,
                                                          want_extent=want_extent, crop=crop)])[0]
 
 

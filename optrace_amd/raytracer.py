@@ -381,7 +381,8 @@ class Raytracer(Group):
 
         specs: dicts with detector_index, source_index, extent, projection_method and optionally pos (the detector is
         moved there first, as `iterative_render` does position by position, raytracer.py:1244).
-        -> per spec (ph, hw, wl, extent_out, projection, ill_count, desc): device tensors of the selected ray range
+        -> per spec (ph, hw, wl, extent_out, projection, ill_count, desc): device tensors of the selected ray range; ph
+        holds the x and y planes, the z plane as well with want_z
         (dense: rays without a valid hit carry weight 0), the extent actually used, the projection name, the
         ill-conditioned count and the image description at that position."""
         if not self.detectors:
@@ -427,7 +428,8 @@ class Raytracer(Group):
             desc = f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm"
             # rays outside a user extent are dropped (raytracer.py:1036-1040): the hit kernel gives them weight 0
             groups.setdefault((Ns, Ne), []).append((n, dict(surf_desc=dsurf._desc(), want_extent=extent is None,
-                                                            projection=_capi.PROJECTIONS[projection], crop=extent_out)))
+                                                            projection=_capi.PROJECTIONS[projection], crop=extent_out,
+                                                            want_z=bool(sp.get("want_z", False)))))
             meta.append((Ns, Ne, extent_out, projection, desc, det.pos[:2].repeat(2)))
 
         out = [None] * len(specs)
@@ -446,7 +448,7 @@ class Raytracer(Group):
                       projection_method: str = "Equidistant"):
         """One detector: (ph, hw, wl, extent_out, projection, ill_count), see `_hit_detectors`."""
         return self._hit_detectors(info, [dict(detector_index=detector_index, source_index=source_index, extent=extent,
-                                               projection_method=projection_method)])[0][:6]
+                                               projection_method=projection_method, want_z=True)])[0][:6]
 
     def _image_from_hits(self, hits: tuple, detector_index: int, source_index, limit, **kwargs) -> RenderImage:
         p, w, wl, extent_out, projection, ill_count, desc = hits
