@@ -1419,7 +1419,13 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     const size_t o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)t.max_chunks);
     char* ws = nullptr;
     HIP_TRY(keep_async_pool(dev));
-    HIP_TRY(hipMallocAsync((void**)&ws, off, st));
+    if (hipMallocAsync((void**)&ws, off, st) != hipSuccess || !ws) {
+        // no room for the hit records (12 B per hit): the direct kernel needs no scratch
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return OT_OK;
+    }
     TileWork wk;
     wk.spread = (int*)(ws + o_spread);
     wk.counts = (unsigned int*)(ws + o_counts);
