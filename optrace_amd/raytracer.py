@@ -721,26 +721,29 @@ class Raytracer(Group):
                 msgs_cum += self._msgs
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
-                # all positions are intersected in one pass over the sections (`ot_detector_hits_multi`)
-                hits = self._hit_detectors("Detector Image", [
-                    dict(detector_index=detector_index[j], extent=extentc[j], projection_method=projection_method[j],
-                         pos=pos[j]) for j in range(len(pos))])
-                for j in range(len(pos)):
-                    # chunks of equal size are binned straight into the image of the first chunk (their common
-                    # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
-                    # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
-                    direct = 0 < i and rays_step == step0
-                    img = self._image_from_hits(hits[j], detector_index[j], None, limit[j], _dont_filter=True,
-                                                _into=images[j]._dev if direct else None)
-                    hits[j] = None  # hit lists of a chunk are gigabytes: release each as soon as it is binned
-                    if i == 0:
-                        images.append(img)
-                        extentc[j] = img._extent0
-                        scale0 = rays_step / N
-                    elif not direct:
-                        images[j]._dev *= scale0
-                        images[j]._dev += img._dev * (rays_step / N)
-                        scaled = True
+                # up to 8 positions are intersected in one pass over the sections (`ot_detector_hits_multi`); their
+                # hit lists (20 B per ray and position) are binned and released before the next group is searched
+                for j0 in range(0, len(pos), 8):
+                    group = range(j0, min(j0 + 8, len(pos)))
+                    hits = self._hit_detectors("Detector Image", [
+                        dict(detector_index=detector_index[j], extent=extentc[j], projection_method=projection_method[j],
+                             pos=pos[j]) for j in group])
+                    for g, j in enumerate(group):
+                        # chunks of equal size are binned straight into the image of the first chunk (their common
+                        # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
+                        # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
+                        direct = 0 < i and rays_step == step0
+                        img = self._image_from_hits(hits[g], detector_index[j], None, limit[j], _dont_filter=True,
+                                                    _into=images[j]._dev if direct else None)
+                        hits[g] = None
+                        if i == 0:
+                            images.append(img)
+                            extentc[j] = img._extent0
+                            scale0 = rays_step / N
+                        elif not direct:
+                            images[j]._dev *= scale0
+                            images[j]._dev += img._dev * (rays_step / N)
+                            scaled = True
             finally:
                 self._rays_known_current = False
         if not scaled:

@@ -198,8 +198,8 @@ def test_batched_detector_hits_equal_single_calls():
         assert hits > 0
         # iterative_render through the batch equals detector images position by position (same seed, one chunk)
         RT2 = scenes.asphere_scene(ot, seed=3)
-        pos = [[0, 0, z] for z in (20., 30., 34.)]
-        imgs = RT2.iterative_render(60_000, detector_index=1, pos=pos, extent=[[-4, 4, -4, 4]] * 3)
+        pos = [[0, 0, z] for z in (20., 22., 24., 26., 28., 30., 31., 32., 33., 34.)]  # more than one group of 8
+        imgs = RT2.iterative_render(60_000, detector_index=1, pos=pos, extent=[[-4, 4, -4, 4]] * len(pos))
         for p_, im in zip(pos, imgs):
             RT2.detectors[1].move_to(p_)
             ref = RT2.detector_image(detector_index=1, extent=[-4, 4, -4, 4])
