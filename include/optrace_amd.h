@@ -236,7 +236,8 @@ typedef struct ot_source {
     double conv_pos[3];  /* CONVERGING                                                              */
     double pol_angle;    /* [rad] for POL_CONSTANT                                                  */
     double wl, wl0, wl1, mu, sig;
-    double power;        /* power carried by THIS bundle of n rays (ray_storage.py:160)             */
+    double power;        /* power of the source; a range without ray_power gives each of its rays
+                          * power / count (ray_storage.py:160, ray_source.py:220)                   */
     /* tables (device copies made by ot_sources_create); layouts:
      *   spec_tab : LINES: n_spec lines (as the reference's float32 values upcast) then n_spec weights;
      *              TABLE: n_spec wavelengths then n_spec pdf values
