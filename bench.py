@@ -98,6 +98,31 @@ def cpu_baseline(RT, scene, seconds: float) -> dict:
                       f"threads; {n1} rays on 1 thread in {t1:.2f} s"}
 
 
+def secondary_no_pol(ot, scenes, lib, N, dev, steps):
+    """The bench scene with no_pol=True: {value, ms_per_step, roofline_frac} from `steps` launches after 10 warm-up ones."""
+    from optrace_amd import _capi
+    from optrace_amd._device import ptr, stream_ptr
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, no_pol=True, seed=77)
+        RT._geometry_checks()
+        scene = RT._compile()
+        nt = scene.nt
+        RT.rays.init(RT.ray_sources, N, nt, True)
+    rays, tab, rng = RT.rays._rays_struct(), RT.rays._source_table(), RT.rays._source_ranges()
+    msgs = torch.zeros(5 * nt + 1, dtype=torch.int64, device=dev)
+    for i in range(10 + steps):
+        if i == 10:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        _capi.check(lib.ot_generate_and_trace(RT._scene_handle, tab.handle, rng, len(rng), 500 + i, C.byref(rays),
+                                              ptr(msgs), stream_ptr()))
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    b = N * (nt * 36 + 28)
+    return {"value": N * (nt - 2) / t, "ms_per_step": 1e3 * t, "roofline_frac": b / t / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": b}
+
+
 def measured_traffic(pol: bool, N: int):
     """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (separate --pmc
     FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/<round>/trace_kernel_pmc.json; FETCH_SIZE
@@ -213,6 +238,10 @@ def main():
         assert cnt.sum() >= RT._msgs.sum()
     total_power = float(hist[..., 3].sum().item())
 
+    other = None
+    if world == 1 and not args.no_pol:  # same scene without polarisation tracking, outside the timed region
+        other = secondary_no_pol(ot, scenes, lib, N, dev, args.steps)
+
     if rank == 0:
         pol = not args.no_pol
         bytes_per_ray = nt * (48 if pol else 36) + 28  # compulsory RayStorage traffic of trace()
@@ -242,6 +271,8 @@ def main():
             "detector": {"rays_per_s": N / t_det, "ms": 1e3 * t_det, "allreduce_ms": 1e3 * t_red,
                          "image_power_all_ranks": total_power},
         }
+        if world == 1 and not args.no_pol:
+            out["no_pol"] = other  # BASELINE config C2 is quoted with polarisation on and off: the other setting
         if not args.skip_cpu and world == 1:  # CPU leg on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(RT, scene, args.cpu_seconds)
             out["cpu_baseline"]["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["value_one_core"]
