@@ -280,18 +280,41 @@ class RayStorage(BaseClass):
     def direction_vectors(self, normalize: bool = True) -> np.ndarray:
         return self.rays_by_mask(ret=[0, 1, 0, 0, 0, 0, 0], normalize=normalize)[1]
 
+    def _select(self, name: str, ind: np.ndarray, ch2) -> np.ndarray:
+        """Rows `ind` (ray indices) of the list `name`, all sections (ch2 = slice) or one section per ray (ch2 = index
+        array): what `list[ch, ch2]` gives on the host copy, gathered on the device unless the host copy exists already
+        (a selection of a few thousand rays must not pull gigabytes over PCIe)."""
+        N, nt = self._N, self._nt
+        t = self._dev.get(name)
+        if name in self._host or t is None:
+            a = self._view(name)
+            return a[ind] if name == "wl" else a[ind, ch2]
+        idx = torch.from_numpy(np.ascontiguousarray(ind, dtype=np.int64)).to(t.device)
+        if name == "wl":
+            return t[idx].cpu().numpy()
+        vec = name in ("p", "pol")
+        v = t.view(3, nt, N) if vec else t.view(nt, N)  # element (ray, section, component) at ray + N*(section + nt*comp)
+        if isinstance(ch2, slice):
+            g = v[..., idx][..., ch2, :]                                  # ([3,] sections, n)
+            out = g.permute(2, 1, 0) if vec else g.permute(1, 0)            # (n, sections[, 3])
+        else:
+            sec = torch.from_numpy(np.ascontiguousarray(ch2, dtype=np.int64)).to(t.device)
+            g = v[..., sec, idx]                                          # ([3,] n)
+            out = g.permute(1, 0) if vec else g
+        return np.asfortranarray(out.cpu().numpy()) if vec and isinstance(ch2, slice) else out.cpu().numpy()
+
     def rays_by_mask(self, ch=None, ch2=None, ret=None, normalize: bool = True):
         """Properties of selected rays / sections (ray_storage.py:235-293): (p, s, pol, w, wl, snum, n).
-        Post-processing helper on the host copies; the tracing and detector kernels never call it."""
+        Post-processing helper; the selection is gathered on the device, only the selected rows reach the host."""
         assert self.N, "ray_source_list has no rays stored."
         ret = [1, 1, 1, 1, 1, 1, 1] if ret is None else ret
         ch = np.ones(self.N, dtype=bool) if ch is None else ch
         ch2 = slice(None) if ch2 is None else ch2
         assert ch.shape[0] == self.N
+        ind = np.nonzero(ch)[0]
 
         snums = s = None
         if ret[5]:
-            ind = np.nonzero(ch)[0]
             snums = np.zeros_like(ind, dtype=int)
             for i, _ in enumerate(self.N_list):
                 Ns, Ne = self.B_list[i:i + 2]
@@ -299,14 +322,21 @@ class RayStorage(BaseClass):
         if ret[1]:
             if not isinstance(ch2, slice):
                 ch21 = np.where(ch2 < self.Nt - 1, ch2 + 1, ch2)
-                s = self.p_list[ch, ch21] - self.p_list[ch, ch2]
+                s = self._select("p", ind, ch21) - self._select("p", ind, ch2)
                 if normalize:
                     s = misc.normalize(s)
             else:
-                s = self.p_list[ch, 1:] - self.p_list[ch, :-1]
+                pa = self._select("p", ind, slice(None))
+                s = pa[:, 1:] - pa[:, :-1]
                 s = np.hstack((s, np.zeros((s.shape[0], 1, 3), order='F', dtype=np.float64)))
                 if normalize:
                     s = misc.normalize(s.reshape((s.shape[0] * s.shape[1], 3))).reshape(s.shape)
-        return (self.p_list[ch, ch2] if ret[0] else None, s if ret[1] else None,
-                self.pol_list[ch, ch2] if ret[2] else None, self.w_list[ch, ch2] if ret[3] else None,
-                self.wl_list[ch] if ret[4] else None, snums, self.n_list[ch, ch2] if ret[6] else None)
+        pol = None
+        if ret[2]:
+            if self._dev.get("pol") is None:
+                pol = self.pol_list[ind, ch2]
+            else:
+                pol = self._select("pol", ind, ch2)
+        return (self._select("p", ind, ch2) if ret[0] else None, s if ret[1] else None, pol,
+                self._select("w", ind, ch2) if ret[3] else None, self._select("wl", ind, None) if ret[4] else None,
+                snums, self._select("n", ind, ch2) if ret[6] else None)

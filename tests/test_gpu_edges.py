@@ -204,3 +204,33 @@ def test_batched_detector_hits_equal_single_calls():
             RT2.detectors[1].move_to(p_)
             ref = RT2.detector_image(detector_index=1, extent=[-4, 4, -4, 4])
             np.testing.assert_allclose(im._data, ref._data, rtol=1e-12, atol=1e-300)
+
+
+def test_rays_by_mask_gathers_on_the_device():
+    """RayStorage.rays_by_mask (ray_storage.py:235-293): the device gather returns exactly what indexing the host
+    copies returns, for row masks, all sections or one section per ray, with and without polarisation."""
+    for no_pol in (False, True):
+        with ot.global_options.no_warnings():
+            RT = scenes.double_gauss(ot, seed=9, no_pol=no_pol)
+            RT.trace(20_000)
+        r = RT.rays
+        rng = np.random.default_rng(4)
+        ch = rng.random(r.N) < 0.1
+        ch2 = rng.integers(0, r.Nt, int(ch.sum()))
+        assert not r._host  # nothing copied yet: the first calls take the device path
+        dev_all = r.rays_by_mask(ch)
+        dev_sec = r.rays_by_mask(ch, ch2, normalize=False)
+        dev_len, dev_opt, dev_src = r.ray_lengths(ch, ch2), r.optical_lengths(ch), r.source_numbers()
+        assert set(r._host) <= {"pol"}  # still no host copy of the big lists (pol is a broadcast NaN with no_pol)
+        for name in ("p", "s", "w", "n", "wl", "pol"):
+            r._view(name)             # now the host copies exist and are used
+        host_all = r.rays_by_mask(ch)
+        host_sec = r.rays_by_mask(ch, ch2, normalize=False)
+        for a, b in zip(dev_all + dev_sec, host_all + host_sec):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert a.shape == b.shape and a.dtype == b.dtype
+                np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(dev_len, r.ray_lengths(ch, ch2))
+        np.testing.assert_array_equal(dev_opt, r.optical_lengths(ch))
+        np.testing.assert_array_equal(dev_src, r.source_numbers())
