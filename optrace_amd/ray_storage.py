@@ -260,11 +260,20 @@ class RayStorage(BaseClass):
         self._new_lock = True
 
     def source_sections(self, index: int = None):
+        """(p, s, pol, w, wl) of the first section of one source's rays, or of all (ray_storage.py:212-233); only these
+        rows are copied from the device."""
         assert self.N, "ray_source_list has no rays stored."
         assert index is None or 0 <= index < len(self.N_list)
         Ns, Ne = self.B_list[index:index + 2] if index is not None else (0, self.N)
-        return (self.p_list[Ns:Ne, 0], self.s0_list[Ns:Ne], self.pol_list[Ns:Ne, 0],
-                self.w_list[Ns:Ne, 0], self.wl_list[Ns:Ne])
+        ind = np.arange(int(Ns), int(Ne))
+        first = np.zeros(ind.shape[0], dtype=np.int64)
+        pol = self.pol_list[ind, 0] if self._dev.get("pol") is None else self._select("pol", ind, first)
+        if "s" in self._host:
+            s0 = self.s0_list[ind]
+        else:
+            idx = torch.from_numpy(ind).to(self._dev["s"].device)
+            s0 = self._dev["s"].view(3, self._N)[:, idx].t().cpu().numpy()
+        return (self._select("p", ind, first), s0, pol, self._select("w", ind, first), self._select("wl", ind, None))
 
     def ray_lengths(self, ch=None, ch2=None) -> np.ndarray:
         _, s, _, _, _, _, _ = self.rays_by_mask(ch, ch2, ret=[0, 1, 0, 0, 0, 0, 0], normalize=False)

@@ -221,6 +221,7 @@ def test_rays_by_mask_gathers_on_the_device():
         dev_all = r.rays_by_mask(ch)
         dev_sec = r.rays_by_mask(ch, ch2, normalize=False)
         dev_len, dev_opt, dev_src = r.ray_lengths(ch, ch2), r.optical_lengths(ch), r.source_numbers()
+        dev_ss = r.source_sections(1) + r.source_sections()
         assert set(r._host) <= {"pol"}  # still no host copy of the big lists (pol is a broadcast NaN with no_pol)
         for name in ("p", "s", "w", "n", "wl", "pol"):
             r._view(name)             # now the host copies exist and are used
@@ -234,3 +235,6 @@ def test_rays_by_mask_gathers_on_the_device():
         np.testing.assert_array_equal(dev_len, r.ray_lengths(ch, ch2))
         np.testing.assert_array_equal(dev_opt, r.optical_lengths(ch))
         np.testing.assert_array_equal(dev_src, r.source_numbers())
+        for a, b in zip(dev_ss, r.source_sections(1) + r.source_sections()):
+            assert a.shape == b.shape and a.dtype == b.dtype
+            np.testing.assert_array_equal(a, b)
