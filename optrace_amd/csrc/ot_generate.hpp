@@ -41,10 +41,32 @@ OT_DEV uint32_t permute_hash(uint32_t i, uint32_t w, uint32_t key) {  // bijecti
     return i;
 }
 
+// Blocks of 2^20 strata and more (where the rays are): three multiply / xor-shift rounds whose shifts follow the width k
+// of the domain -- half and a third of it, so that every round folds the high bits, which a multiplication modulo 2^k
+// leaves poorly mixed, onto the low ones.  16 instead of 34 instructions.  On these domain sizes its pairings are
+// indistinguishable from the hash above in chi-square tests of pairs and triples of streams, of a stream against the ray
+// index and against itself at lags 1, 64 and 4096, and for neighbouring keys (tools/experiments/perm_quality.py,
+// profiles/r1/perm_quality.txt); below 2^20 it is measurably weaker, so small blocks keep the longer hash.
+OT_DEV uint32_t permute_pow2_large(uint32_t i, uint32_t w, uint32_t key) {
+    const int k = 32 - __builtin_clz(w);  // wave-uniform, like w and key: the constants below live on the scalar unit
+    const int sA = (k + 1) >> 1, sB = (k + 2) / 3;
+    const uint32_t m2 = (0x0929eb3fu ^ ((key >> 7) << 1)) | 1u;
+    i ^= key & w;
+    i = (i * 0xe170893du) & w;
+    i ^= i >> sA;
+    i = (i * m2) & w;
+    i ^= i >> sB;
+    i ^= (key >> 13) & w;
+    i = (i * 0x6935fa69u) & w;
+    i ^= i >> sA;
+    return (i + ((key >> 3) & w)) & w;
+}
+
 OT_DEV uint32_t permute_index(uint32_t i, uint32_t l, uint32_t key) {
     if (l <= 1) return 0;
     uint32_t w = l - 1;
     if ((l & w) == 0) {  // power of two (what the host cuts long ranges into): no cycle walking, no divergence
+        if (l >= (1u << 20)) return permute_pow2_large(i, w, key);
         i = permute_hash(i, w, key);
         return (i + (key & w)) & w;
     }
