@@ -232,3 +232,27 @@ def test_function_orientation_in_trace():
         p_first = p.copy()
         RT.trace(30_001)
         np.testing.assert_array_equal(RT.rays.p_list, p_first)
+
+
+@pytest.mark.parametrize("N", [1 << 20, (1 << 21) + (1 << 16) + 12345])
+def test_every_stratum_is_used_once_per_block(N):
+    """Stratified sampling on the device: inside each stratification block (RayStorage._source_ranges: powers of two,
+    largest first, one ragged rest) the keyed permutation is a bijection -- every one of the block's n strata of the
+    line source receives exactly one ray (random.py:48-67), for the long hash, the short one (blocks of 2^20 and
+    more) and the cycle-walking rest."""
+    from optrace_amd.ray_storage import RayStorage
+    rs = ot.RaySource(ot.Line(r=1.0), spectrum=ot.LightSpectrum("Monochromatic", wl=550.), divergence="None", pos=[0, 0, 0])
+    st = RayStorage()
+    st.init([rs], N, 1, True)
+    st.generate(seed=11)
+    x = st.p_list[:, 0, 0]
+    assert x.min() >= -1 and x.max() <= 1
+    blocks = [(r.first, r.count) for r in st._source_ranges()]
+    assert sum(c for _, c in blocks) == N
+    for first, n in blocks:
+        k = np.floor((x[first:first + n] + 1.0) / 2.0 * n).astype(np.int64)
+        k = np.clip(k, 0, n - 1)
+        # a dither within 1e-10 of a stratum edge may round across it: allow a handful of such pairs
+        assert n - np.unique(k).shape[0] <= 4, (first, n)
+    # and the order of the rays is not the order of the strata
+    assert abs(np.corrcoef(np.arange(4096), x[:4096])[0, 1]) < 0.1
