@@ -238,3 +238,75 @@ def test_rays_by_mask_gathers_on_the_device():
         for a, b in zip(dev_ss, r.source_sections(1) + r.source_sections()):
             assert a.shape == b.shape and a.dtype == b.dtype
             np.testing.assert_array_equal(a, b)
+
+
+def test_few_rays_every_entry_point():
+    """Like the reference's test_few_rays_action (tests/test_tracer_special.py:419-457): 70, 3 and 1 rays, with and
+    without everything being absorbed before the detector, through every consumer of a trace."""
+    with ot.global_options.no_warnings():
+        RT = scenes.mixed_geometry(ot, seed=2)
+        ap = RT.apertures[0]
+        for el in [*RT.apertures, *RT.filters]:
+            RT.remove(el)
+        for blocked in (False, True):
+            for N in (70, 3, 1):
+                RT.trace(N)
+                assert RT.rays.N == N and not RT.geometry_error
+                assert RT.source_image().power() >= 0
+                img = RT.detector_image()
+                assert np.all(np.isfinite(img._data)) and img.power() >= 0
+                img1 = RT.detector_image(detector_index=1, projection_method="Stereographic")
+                if blocked:  # detector 1 stands behind the stop (detector 0 in the source plane, before it)
+                    assert img1.power() == 0
+                for sp in (RT.source_spectrum(), RT.detector_spectrum()):
+                    assert np.all(np.isfinite(sp._vals))
+                assert len(RT.iterative_render(N)) == 1
+                for fm in RT.focus_search_methods:
+                    res, info = RT.focus_search(fm, z_start=30)
+                    if info["N"] > 1:
+                        assert RT.outline[4] <= res.x <= RT.outline[5]
+                    else:  # placeholder result like the reference's (raytracer.py:1553-1556)
+                        assert "x" not in res and np.all(np.isnan(info["z"]))
+                r = RT.rays
+                assert sum(a.shape[0] for a in (r.source_sections(0)[0], r.source_sections(1)[0])) == N
+                assert r.source_sections()[0].shape == (N, 3)
+                none = r.rays_by_mask(np.zeros(N, dtype=bool))
+                assert none[0].shape[0] == 0 and none[4].shape[0] == 0
+                every = r.rays_by_mask(np.ones(N, dtype=bool))
+                assert every[0].shape == (N, r.Nt, 3) and every[3].shape == (N, r.Nt)
+            # a stop right behind the sources: nothing reaches the detectors or the focus-search region
+            RT.add(ap)
+            RT.apertures[0].move_to(ap.pos + [0.2, 0.2, 0])
+            RT.add(ot.Aperture(ot.CircularSurface(r=4.5), pos=[0, 0, 1]))
+
+
+@pytest.mark.parametrize("pos0", [(5.789, 0.123, -45.6), (0, 16546.789789, -4654), (1e5, -1e6, 15)])
+def test_offset_system_equality(pos0):
+    """The same system shifted by a vector images the same way (reference: tests/test_tracer_special.py:61-124, whose
+    tolerances these are): extent relative to the shift, side lengths and power of the detector image."""
+    def build(p0):
+        p0 = np.array(p0, dtype=float)
+        x0, y0, z0 = p0
+        RT = ot.Raytracer(outline=[-5 + x0, 5 + x0, -5 + y0, 5 + y0, -10 + z0, 50 + z0], seed=17)
+        RT.add(ot.RaySource(ot.CircularSurface(r=0.2), spectrum=ot.LightSpectrum("Monochromatic", wl=555), divergence="None",
+                            pos=p0 + [0, 0, -3]))
+        glass = ot.RefractionIndex("Sellmeier1", coeff=[1.62153902, 0.0122241457, 0.256287842, 0.0595736775, 1.64447552, 147.468793])
+        RT.add(ot.Lens(ot.SphericalSurface(r=3, R=50), ot.ConicSurface(r=3, R=-50, k=-1.5), n=glass, pos=p0 + [0, 0.01, 0]))
+        RT.add(ot.Lens(ot.FunctionSurface1D(r=3, func=lambda r: r ** 2 / 50 + r ** 2 / 5000, parax_roc=25),
+                       ot.CircularSurface(r=2), n=glass, pos=p0 + [0, 0.01, 10]))
+        Y, X = np.mgrid[-1:1:100j, -1:1:100j]
+        RT.add(ot.Lens(ot.DataSurface2D(data=3 - (X ** 2 + Y ** 2), r=4), ot.TiltedSurface(r=4, normal=[0, 0.01, 1]),
+                       n=ot.RefractionIndex("Cauchy", coeff=[1.5, 0.004, 0, 0]), pos=p0 + [0, 0, 20]))
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[10, 10]), pos=p0 + [0., 0., 45]))
+        RT.trace(100_000)
+        assert not RT.geometry_error
+        return RT.detector_image()
+
+    with ot.global_options.no_warnings():
+        ref, im = build((0, 0, 0)), build(pos0)
+    shift = np.array(pos0[:2], dtype=float).repeat(2)
+    assert ref.power() > 0.5
+    np.testing.assert_allclose(ref.extent - im.extent + shift, 0, atol=0.001, rtol=0)
+    assert abs((ref.extent[1] - ref.extent[0]) - (im.extent[1] - im.extent[0])) < 0.001
+    assert abs((ref.extent[3] - ref.extent[2]) - (im.extent[3] - im.extent[2])) < 0.001
+    assert abs(ref.power() - im.power()) < 5e-5
