@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import optrace_amd as ot
+import scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -212,3 +213,41 @@ def test_scene_is_recompiled_only_when_it_changes():
     RT.no_pol = True
     with pytest.raises(RuntimeError, match="retrace"):
         RT.detector_image()
+
+
+def test_polarisation_stays_transverse_and_normalised():
+    """After the reference's test_polarization (tests/test_tracer.py:1183-1196): in a system with flat, conic and
+    spherical lenses, a filter, an aperture and an ideal lens the stored polarisation of every living section is
+    perpendicular to the section's direction and has unit length."""
+    with ot.global_options.no_warnings():
+        RT = scenes.mixed_geometry(ot, seed=12)
+        RT.trace(200_000)
+    _, s, pol, _, _, _, _ = RT.rays.rays_by_mask(ret=[0, 1, 1, 0, 0, 0, 0])
+    scal = np.sum(s * pol, axis=2)
+    scal = scal[~np.isnan(scal)]
+    assert scal.size > 1_000_000
+    assert np.ptp(scal) < 4e-7                    # float32 storage of pol: 6e-8 per component
+    polpol = np.sum(pol.astype(np.float64) ** 2, axis=2)
+    polpol = polpol[~np.isnan(polpol)]
+    assert np.allclose(polpol, 1, rtol=2e-5)
+
+
+@pytest.mark.parametrize("spectrum", ["d65", "mono", "led_b1"])
+def test_grayscale_image_source_is_emitted_linearly(spectrum):
+    """After the reference's test_grayscale_image_source (tests/test_tracer.py:1198-1237): the irradiance a detector
+    right behind a GrayscaleImage source sees is the (linearised) image, whatever the spectrum."""
+    spec = {"d65": ot.presets.light_spectrum.d65, "mono": ot.LightSpectrum("Monochromatic", wl=540),
+            "led_b1": ot.presets.light_spectrum.led_b1}[spectrum]
+    X, Y = np.mgrid[-1:1:63j, -1:1:63j]
+    img = ot.GrayscaleImage(np.sin(5 * X + Y) ** 2, [1, 1])
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer([-10, 10, -10, 10, -10, 200], seed=3)
+        RT.add(ot.RaySource(img, divergence="None", pos=[0, 0, 0], spectrum=spec))
+        RT.add(ot.Detector(ot.RectangularSurface(img.s), pos=[0, 0, 1]))
+        RT.trace(5_000_000)
+        got = RT.detector_image().get("Irradiance", 63)
+    a = got.data / np.max(got.data)
+    v = img.data
+    lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4)  # sRGB -> linear (color/srgb.py:30-47)
+    lin = lin / np.max(lin)
+    assert np.mean(np.abs(a - lin)) < 0.003
