@@ -251,3 +251,20 @@ def test_grayscale_image_source_is_emitted_linearly(spectrum):
     lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4)  # sRGB -> linear (color/srgb.py:30-47)
     lin = lin / np.max(lin)
     assert np.mean(np.abs(a - lin)) < 0.003
+
+
+def test_hurb_backward_directions_are_absorbed():
+    """After the reference's test_hurb_negative_sz (tests/test_tracer_hurb.py:230-250): steep rays bent at a pinhole can
+    come out with s_z < 0; they are absorbed and counted, no stored direction points backwards."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer([-5, 5, -5, 5, 0, 10], use_hurb=True, seed=8)
+        RT.add(ot.RaySource(ot.Point(), pos=[0, -5, 0], s=[0, 0, 1], orientation="Converging", conv_pos=[0, 0, 0.01]))
+        RT.add(ot.Aperture(ot.RingSurface(r=3, ri=0.001), pos=[0, 0, 0.01]))
+        RT.trace(100_000)
+    assert RT._msgs[RT.INFOS.HURB_NEG_DIR, 1] > 0
+    s = RT.rays.direction_vectors()
+    assert not np.any(s[:, :, 2] < 0)
+    # the absorbed rays carry no power behind the aperture, the others keep theirs
+    w = RT.rays.w_list
+    lost = RT._msgs[RT.INFOS.HURB_NEG_DIR, 1] + RT._msgs[RT.INFOS.ABSORB_MISSING, 1]
+    assert np.count_nonzero(w[:, 1] == 0) == lost + np.count_nonzero(w[:, 0] == 0)
