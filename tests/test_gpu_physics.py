@@ -268,3 +268,22 @@ def test_hurb_backward_directions_are_absorbed():
     w = RT.rays.w_list
     lost = RT._msgs[RT.INFOS.HURB_NEG_DIR, 1] + RT._msgs[RT.INFOS.ABSORB_MISSING, 1]
     assert np.count_nonzero(w[:, 1] == 0) == lost + np.count_nonzero(w[:, 0] == 0)
+
+
+def test_hurb_tilted_beam_sees_the_projected_slit():
+    """After the reference's test_hurb_aperture_projection (tests/test_tracer_hurb.py:252-289): a beam that meets a slit
+    at an angle sees it narrower by cos(angle), so the spread of the bending angle grows with 1 / cos(angle)."""
+    products = []
+    for ang0 in (5, 40, 60, 80):
+        ang = np.deg2rad(ang0)
+        za = 5 / np.tan(ang)
+        with ot.global_options.no_warnings():
+            RT = ot.Raytracer([-5, 5, -5, 5, 0, 10 * za], use_hurb=True, seed=21)
+            RT.add(ot.RaySource(ot.Point(), pos=[-5, 0, 0], orientation="Converging", conv_pos=[0, 0, za]))
+            RT.add(ot.Aperture(ot.SlitSurface(dim=[2, 2], dimi=[0.03, 1.9]), pos=[0, 0, za]))
+            RT.trace(1_000_000)
+        s = RT.rays.direction_vectors(normalize=True)
+        angs = np.arccos(np.clip(np.sum(s[:, 0] * s[:, 1], axis=1), -1, 1))
+        products.append(np.rad2deg(np.nanstd(angs)) * np.cos(ang))
+    products = np.array(products)
+    assert np.std(products / products[0]) < 0.002
