@@ -93,3 +93,43 @@ def test_spline_tables_survive_scene_lifetime_and_large_bundle():
         p1 = RT.rays.p_list[:1000].copy()
         RT.trace(1_000_000)
         assert np.array_equal(p1, RT.rays.p_list[:1000])
+
+
+@pytest.mark.parametrize("R_", [3, 10.2, 100])
+def test_one_shape_through_every_surface_type(R_):
+    """After the reference's test_same_surface_behavior (tests/test_tracer_special.py:172-249): a paraboloid written as
+    conic, asphere (two ways), function surface (two ways) and 1-D / 2-D data surfaces of several resolutions focuses
+    a narrow beam at the same place (the reference's tolerance: 0.001 mm between the numeric variants, 0.2 mm to the
+    sphere and to the lens-maker value)."""
+    r, n = 2, 1.5
+    func = lambda x, y, R: 1 / 2 / R * (x ** 2 + y ** 2)  # noqa: E731
+    func2 = lambda x, y: 0.78785 + 1 / 2 / R_ * (x ** 2 + y ** 2)  # noqa: E731
+    with ot.global_options.no_warnings():
+        surfs = [ot.SphericalSurface(R=R_, r=r), ot.ConicSurface(R=R_, k=-1, r=r),
+                 ot.FunctionSurface2D(func=func2, r=r),
+                 ot.FunctionSurface2D(func=func, r=r, z_min=0, z_max=func(0, r, R_), func_args=dict(R=R_)),
+                 ot.AsphericSurface(R=R_, r=r, k=-1, coeff=[0.]), ot.AsphericSurface(R=1e9, r=r, k=-1, coeff=[1 / 2 / R_])]
+        for N in (900, 51, 201):
+            Y, X = np.mgrid[-r:r:N * 1j, -r:r:N * 1j]
+            surfs.append(ot.DataSurface2D(r=r, data=4.657165 + 1 / 2 / R_ * (X ** 2 + Y ** 2)))
+            surfs.append(ot.DataSurface1D(r=r, data=4.657165 + 1 / 2 / R_ * np.linspace(0, r, N) ** 2))
+        d = 0.1 + func(0, r, R_)
+        f_lensmaker = 1 / ((n - 1) * (1 / R_))  # plano-convex: the thickness does not enter the focal length
+        for RS_r in (0.01, 0.5):
+            RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 500], no_pol=True, seed=4)
+            RT.add(ot.RaySource(ot.CircularSurface(r=RS_r), spectrum=ot.LightSpectrum("Monochromatic", wl=555),
+                                divergence="None", pos=[0, 0, -3]))
+            f_list = []
+            for surf in surfs:
+                L = ot.Lens(surf, ot.CircularSurface(r=r), n=ot.RefractionIndex("Constant", n=n), pos=[0, 0, d / 2], d=d)
+                RT.add(L)
+                RT.trace(100_000)
+                res, _ = RT.focus_search(RT.focus_search_methods[0], 5)
+                f_list.append(float(res.x))
+                back_z, dv = L.back.pos[2], L.back.pos[2] - L.front.pos[2]
+                RT.remove(L)
+            # thick plano-convex lens, curved side first: the focus lies f (1 - (n - 1) d / (n R)) behind the flat side
+            assert abs(f_list[1] - (back_z + f_lensmaker * (1 - (n - 1) * dv / (n * R_)))) < (0.002 if RS_r < 0.1 else 0.2)
+            assert abs(f_list[0] - f_list[1]) < 0.2
+            numeric = f_list[1:]
+            assert max(numeric) - min(numeric) < 0.001, (RS_r, f_list)
