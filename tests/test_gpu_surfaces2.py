@@ -133,3 +133,39 @@ def test_one_shape_through_every_surface_type(R_):
             assert abs(f_list[0] - f_list[1]) < 0.2
             numeric = f_list[1:]
             assert max(numeric) - min(numeric) < 0.001, (RS_r, f_list)
+
+
+def test_brewster_plate_through_three_surface_types():
+    """After the reference's test_tilted_plane_different_surface_types (tests/test_tracer_special.py:318-365): a plate
+    tilted at Brewster's angle, written as function, tilted and data surface, leaves every ray straight and shifts it
+    sideways by the same 0.0531867 mm."""
+    n = ot.RefractionIndex("Constant", n=1.55)
+    b_ang = np.arctan(1.55 / 1)
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -8, 12], seed=6)
+        spectrum = ot.LightSpectrum("Monochromatic", wl=550.)
+        for x0, pol in ((0.5, "x"), (0, "y"), (-0.5, "Uniform")):
+            RT.add(ot.RaySource(ot.CircularSurface(r=0.05), divergence="None", spectrum=spectrum, pos=[x0, 0, -4],
+                                polarization=pol))
+        Y, X = np.mgrid[-0.7:0.7:100j, -0.7:0.7:100j]
+        surfs = [ot.FunctionSurface2D(func=lambda x, y: np.tan(b_ang) * x, r=0.7),
+                 ot.TiltedSurface(r=0.7, normal=[-np.sin(b_ang), 0, np.cos(b_ang)]),
+                 ot.DataSurface2D(r=0.7, data=np.tan(b_ang) * Y)]
+        for surf in surfs:
+            L = ot.Lens(surf, surf, d=0.2, pos=[0, 0, 0.5], n=n)
+            RT.add(L)
+            RT.trace(10_000)
+            RT.remove(L)
+            assert not RT.geometry_error
+            p, s, _, _, _, _, _ = RT.rays.rays_by_mask(np.ones(RT.rays.N, dtype=bool), ret=[1, 1, 0, 0, 0, 0, 0])
+            assert abs(np.mean(s[:, -2, 2]) - 1) < 1e-7                                   # still straight
+            np.testing.assert_allclose(p[:, -2, 0] - p[:, -3, 0], -0.0531867, atol=1e-5, rtol=0)  # parallel shift
+            # the plane of incidence is xz: x-polarised light is p-polarised and passes a Brewster plate without loss,
+            # y-polarised light loses the Fresnel s-reflection at both faces
+            w = RT.rays.w_list
+            xsrc = slice(int(RT.rays.B_list[0]), int(RT.rays.B_list[1]))
+            ysrc = slice(int(RT.rays.B_list[1]), int(RT.rays.B_list[2]))
+            np.testing.assert_allclose(w[xsrc, -2], w[xsrc, 0], rtol=1e-5)
+            ci, ct = np.cos(b_ang), np.cos(np.arcsin(np.sin(b_ang) / 1.55))
+            Rs = ((ci - 1.55 * ct) / (ci + 1.55 * ct)) ** 2
+            np.testing.assert_allclose(w[ysrc, -2], w[ysrc, 0] * (1 - Rs) ** 2, rtol=1e-5)
