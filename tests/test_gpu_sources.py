@@ -256,3 +256,29 @@ def test_every_stratum_is_used_once_per_block(N):
         assert n - np.unique(k).shape[0] <= 4, (first, n)
     # and the order of the rays is not the order of the strata
     assert abs(np.corrcoef(np.arange(4096), x[:4096])[0, 1]) < 0.1
+
+
+@pytest.mark.parametrize("surf", ["disc", "square", "rect43", "rect31", "line", "line30", "line90", "ring_thin", "ring_wide"])
+def test_emitting_surfaces_emit_uniformly(surf):
+    """After the reference's test_uniform_emittance (tests/test_tracer.py:446-486): the source image of every
+    emitter shape is flat -- standard deviation of the normalised 35-pixel irradiance below 7 % inside the shape."""
+    sf = {"disc": ot.CircularSurface(r=2), "square": ot.RectangularSurface(dim=[1, 1]),
+          "rect43": ot.RectangularSurface(dim=[1, 0.75]), "rect31": ot.RectangularSurface(dim=[1, 1 / 3]),
+          "line": ot.Line(r=3), "line30": ot.Line(r=3, angle=30), "line90": ot.Line(r=3, angle=90),
+          "ring_thin": ot.RingSurface(ri=1.5, r=2), "ring_wide": ot.RingSurface(ri=0.25, r=2)}[surf]
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-5, 5, -5, 5, -10, 10], n0=ot.RefractionIndex("Constant", n=1), seed=13)
+        RT.add(ot.RaySource(sf, pos=[0, 0, 0]))
+        RT.trace(200_000)
+        L = RT.source_image().get("Irradiance", 35).data
+    L = L / np.max(L)
+    if isinstance(sf, ot.Line):
+        L = L[L > 0]
+    elif not isinstance(sf, ot.RectangularSurface):
+        Lx, Ly = L.shape[:2]
+        Y, X = np.mgrid[-Lx / 2:Lx / 2:Lx * 1j, -Ly / 2:Ly / 2:Ly * 1j]
+        m = X ** 2 + Y ** 2 < (Lx / 2 - 1) ** 2
+        if isinstance(sf, ot.RingSurface):
+            m = m & (X ** 2 + Y ** 2 > (Lx / 2 * sf.ri / sf.r + 1) ** 2)
+        L = L[m]
+    assert L.size > 10 and np.std(L) < 0.07
