@@ -282,3 +282,25 @@ def test_emitting_surfaces_emit_uniformly(surf):
             m = m & (X ** 2 + Y ** 2 > (Lx / 2 * sf.ri / sf.r + 1) ** 2)
         L = L[m]
     assert L.size > 10 and np.std(L) < 0.07
+
+
+def test_converging_rectangle_meets_in_one_point():
+    """After the reference's test_ray_source_convergence (tests/test_tracer.py:488-514): every ray of a converging area
+    source passes through conv_pos; a convergence point behind the source raises like `create_rays` does."""
+    conv_pos = [30, -25, 25]
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-100, 100, -100, 100, -10, 100], no_pol=True, seed=2)
+        RS0 = ot.RaySource(ot.RectangularSurface(dim=[50, 50]), divergence="None", orientation="Converging",
+                           conv_pos=conv_pos, pos=[-50, 10, -2.5])
+        RT.add(RS0)
+        RT.add(ot.Aperture(ot.RectangularSurface(dim=[5, 5]), pos=conv_pos))
+        RT.trace(50_000)
+        p = RT.rays.p_list
+        np.testing.assert_allclose(p[:, 1, 2], conv_pos[2], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(p[:, 1, 0], conv_pos[0], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(p[:, 1, 1], conv_pos[1], rtol=0, atol=1e-10)
+        RS0.conv_pos = [-10, 10, -10]
+        with pytest.raises(RuntimeError):
+            RS0.create_rays(200_000)
+        with pytest.raises(RuntimeError):
+            RT.trace(50_000)
