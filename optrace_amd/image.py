@@ -113,6 +113,27 @@ class _BaseImage(BaseClass):
     def Apx(self) -> float:
         return float(self.s[0] * self.s[1] / (self.shape[1] * self.shape[0]))
 
+    def profile(self, x: float = None, y: float = None):
+        """Cut through the image at one x or one y position (base_image.py:149-186): the pixel column / row that
+        contains the position, no interpolation.  -> (bin edges along the cut, [one cut per channel])."""
+        if (x is None) == (y is None):
+            raise ValueError("Either x or y parameter must be provided.")
+        ext, img = self.extent, self._data
+        rows, cols = self.shape[0], self.shape[1]
+        if x is not None:
+            if not ext[0] <= x <= ext[1]:
+                raise ValueError(f"Position x={x} is outside the image x-extent of {ext[:2]}")
+            edges = np.linspace(ext[2], ext[3], rows + 1)
+            k = int((x - ext[0]) / self.s[0] * cols * (1 - 1e-12))
+            cut = img[:, k]
+        else:
+            if not ext[2] <= y <= ext[3]:
+                raise ValueError(f"Position y={y} is outside the image y-extent of {ext[2:]}")
+            edges = np.linspace(ext[0], ext[1], cols + 1)
+            k = int((y - ext[2]) / self.s[1] * rows * (1 - 1e-12))
+            cut = img[k]
+        return edges, ([cut] if cut.ndim == 1 else [cut[:, c] for c in range(cut.shape[1])])
+
     def __setattr__(self, key, val):
         if key == "_data":
             check_type(key, val, np.ndarray)

@@ -304,3 +304,70 @@ def test_converging_rectangle_meets_in_one_point():
             RS0.create_rays(200_000)
         with pytest.raises(RuntimeError):
             RT.trace(50_000)
+
+
+def test_divergence_modes_illuminate_a_plane_as_predicted():
+    """After the reference's test_ray_source_divergence (tests/test_tracer.py:516-636): the irradiance a small source
+    puts on a plane at distance 10, divided by the law its divergence mode predicts, is flat -- in the 2-D modes along
+    the cut y = 0, in the 3-D modes over the whole image.  Same sample sizes and tolerances as the reference."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-100, 100, -100, 100, -10, 100], no_pol=True, seed=1)
+        RS0 = ot.RaySource(ot.RectangularSurface(dim=[0.02, 0.02]), divergence="Isotropic", div_2d=True, pos=[0, 0, 0],
+                           s=[0, 0, 1], div_angle=82, spectrum=ot.LightSpectrum("Monochromatic", wl=550))
+        RT.add(RS0)
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[100, 100]), pos=[0, 0, 10]))
+
+        def cut():
+            x, y = RT.detector_image().get("Irradiance", 63).profile(y=0)
+            return x[:-1] + (x[1] - x[0]) / 2, y[0]
+
+        def flat(v):
+            return np.std(v / np.max(v))
+
+        RS0.divergence = "None"                       # parallel light
+        RT.trace(2_000_000)
+        assert flat(cut()[1]) < 0.025
+        RS0.divergence = "Isotropic"                  # equal angles in the plane: 1 / cos^2 on the detector
+        RT.trace(2_000_000)
+        x, y = cut()
+        assert flat(y / np.cos(np.arctan(x / 10)) ** 2) < 0.05
+        RS0.divergence = "Lambertian"                 # 1 / cos^3
+        RT.trace(2_000_000)
+        x, y = cut()
+        assert flat(y / np.cos(np.arctan(x / 10)) ** 3) < 0.05
+        RS0.divergence = "Function"                   # 1 / cos^2 emission: uniform on the detector
+        RS0.div_func = lambda e: 1 / np.cos(e) ** 2
+        RT.trace(2_000_000)
+        assert flat(cut()[1]) < 0.025
+        RS0.div_func = lambda e: 1 + np.sqrt(e)
+        RT.trace(2_000_000)
+        x, y = cut()
+        assert flat(y / (1 + np.sqrt(np.arctan(np.abs(x) / 10))) / np.cos(np.arctan(x / 10)) ** 2) < 0.025
+
+        RS0.div_2d = False
+
+        def image():
+            img0 = RT.detector_image()
+            x0, x1, y0, y1 = img0.extent
+            Y, X = np.mgrid[x0:x1:63j, y0:y1:63j]
+            return img0.get("Irradiance", 63).data, np.sqrt(X ** 2 + Y ** 2)
+
+        RS0.divergence = "None"
+        RT.trace(2_000_000)
+        assert flat(image()[0]) < 0.025
+        RS0.divergence = "Isotropic"                  # 1 / cos^3 in three dimensions
+        RT.trace(2_000_000)
+        img, r = image()
+        assert flat(img / np.cos(np.arctan(r / 10)) ** 3) < 0.075
+        RS0.divergence = "Lambertian"                 # 1 / cos^4
+        RT.trace(4_000_000)
+        img, r = image()
+        assert flat(img / np.cos(np.arctan(r / 10)) ** 4) < 0.075
+        RS0.divergence = "Function"
+        RS0.div_func = lambda e: 1 / np.cos(e) ** 3   # uniform on the detector
+        RT.trace(2_000_000)
+        assert flat(image()[0]) < 0.075
+        RS0.div_func = lambda e: 1 + np.sqrt(e)
+        RT.trace(2_000_000)
+        img, r = image()
+        assert flat(img / (1 + np.sqrt(np.arctan(r / 10))) / np.cos(np.arctan(r / 10)) ** 3) < 0.05

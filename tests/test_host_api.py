@@ -351,3 +351,23 @@ def test_source_ranges_are_power_of_two_blocks(N_list):
         if len(blocks) > 1:  # the ragged rest is smaller than every power-of-two block before it or the cap was hit
             assert blocks[-1].count < sizes[-1] or len(blocks) == max(1, 64 // len(N_list))
     assert pos == sum(N_list)
+
+
+def test_image_profile_cuts():
+    """BaseImage.profile (base_image.py:149-186): nearest pixel column / row, bin edges along the cut."""
+    data = np.arange(12, dtype=float).reshape(3, 4) / 12
+    im = ot.ScalarImage(data, extent=[0, 4, 10, 13])
+    edges, (cut,) = im.profile(y=11.5)
+    np.testing.assert_array_equal(edges, [0, 1, 2, 3, 4])
+    np.testing.assert_array_equal(cut, data[1])
+    edges, (cut,) = im.profile(x=4)           # the upper edge belongs to the last column
+    np.testing.assert_array_equal(edges, [10, 11, 12, 13])
+    np.testing.assert_array_equal(cut, data[:, 3])
+    rgb = ot.RGBImage(np.stack([data, data / 2, data / 3], axis=2), extent=[0, 4, 10, 13])
+    _, cuts = rgb.profile(x=0.5)
+    assert len(cuts) == 3
+    np.testing.assert_array_equal(cuts[1], data[:, 0] / 2)
+    with pytest.raises(ValueError):
+        im.profile()
+    with pytest.raises(ValueError):
+        im.profile(x=5)
