@@ -287,3 +287,52 @@ def test_hurb_tilted_beam_sees_the_projected_slit():
         products.append(np.rad2deg(np.nanstd(angs)) * np.cos(ang))
     products = np.array(products)
     assert np.std(products / products[0]) < 0.002
+
+
+def test_sphere_projections_keep_their_promises():
+    """After the reference's test_sphere_projections (tests/test_tracer.py:636-740): on a hemispherical detector around
+    an isotropic point source the Equal-Area image is flat; parallel pencils 30 degrees apart land equally spaced in
+    the Equidistant image; small cones stay round in the Stereographic image wherever they hit; and for parallel light
+    the Orthographic image of the sphere equals the image on a disc."""
+    R = 90
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-100, 100, -100, 100, -10, 100], seed=5)
+        RT.add(ot.Detector(ot.SphericalSurface(r=(1 - 1e-10) * R, R=-R), pos=[0, 0, R]))
+        RS0 = ot.RaySource(ot.Point(), divergence="Isotropic", div_2d=False, pos=[0, 0, 0], s=[0, 0, 1], div_angle=89)
+        RT.add(RS0)
+        RT.trace(2_000_000)
+        Z = RT.detector_image(projection_method="Equal-Area").get("Irradiance", 63).data
+        Y, X = np.mgrid[-32:32:63j, -32:32:63j]
+        Z = Z[np.sqrt(X ** 2 + Y ** 2) < 29]
+        assert np.std(Z / np.max(Z)) < 0.015
+        RT.remove(RS0)
+
+        small = ot.RectangularSurface(dim=[0.0001, 0.0001])
+        for theta in (-89.99, -60, -30, 0.001, 30, 60, 89.99):
+            RT.add(ot.RaySource(small, divergence="None", div_2d=False, pos=[0, 0, 0], s_sph=[theta, 0]))
+        RT.trace(20_000)
+        z = RT.detector_image(projection_method="Equidistant").get("Irradiance", 256).profile(y=0)[1][0]
+        fact = z.shape[0] / 6
+        zp = (z > 0).nonzero()[0]
+        assert zp.shape[0] >= 7
+        assert np.all(np.abs(zp / fact - np.round(zp / fact)) < 1 / fact * 1.1)
+        for rs in RT.ray_sources.copy():
+            RT.remove(rs)
+
+        for phi in np.linspace(0, 360, 5):
+            for theta in np.linspace(0, 1, 4) * 87:
+                rs = ot.RaySource(ot.Point(), divergence="Isotropic", div_2d=False, pos=[0, 0, 0], s_sph=[theta, phi], div_angle=2)
+                RT.add(rs)
+                RT.trace(40_000)
+                x0, x1, y0, y1 = RT.detector_image(projection_method="Stereographic").extent
+                RT.remove(rs)
+                assert abs((x1 - x0) / (y1 - y0) - 1) < 0.004
+
+        RT.clear()
+        RT.add(ot.RaySource(ot.CircularSurface(r=3), pos=[0, 0, 0], divergence="None", s=[0, 0, 1]))
+        RT.add(ot.Detector(ot.CircularSurface(r=3.01), pos=[0, 0, 10]))
+        RT.add(ot.Detector(ot.SphericalSurface(r=3.01, R=-10), pos=[0, 0, 10]))
+        RT.trace(200_000)
+        a = RT.detector_image(detector_index=0, extent=[-3, 3, -3, 3])
+        b = RT.detector_image(detector_index=1, extent=[-3, 3, -3, 3], projection_method="Orthographic")
+        np.testing.assert_allclose(b._data, a._data, rtol=0, atol=1e-12 * a._data.max())
