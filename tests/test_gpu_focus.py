@@ -155,3 +155,45 @@ def test_rms_closed_form_equals_per_sample_kernel():
     ref = out.cpu().numpy()
     assert np.all(np.abs(d["cost"] - ref) <= 1e-9 * ref), np.abs(d["cost"] / ref - 1).max()
     assert d["cost"].min() >= res.fun * (1 - 1e-9)
+
+
+def test_all_methods_find_the_focus_of_a_lens():
+    """After the reference's test_focus (tests/test_tracer.py:295-366): every method finds the focal point of a biconvex
+    lens in n0 = 1.1 (33.084 mm behind it) within 0.15 mm, per source as well; a second source at g = 60 mm is imaged
+    at b = 73.73 mm; wrong arguments raise like the reference."""
+    fs = 33.08433714
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 40], n0=ot.RefractionIndex("Constant", n=1.1), seed=3)
+        RT.add(ot.RaySource(ot.CircularSurface(r=0.5), pos=[0, 0, -3]))
+        RT.add(ot.Lens(ot.SphericalSurface(r=3, R=30), ot.ConicSurface(r=3, R=-20, k=1), ot.RefractionIndex("Constant", n=1.5),
+                       de=0.1, pos=[0, 0, 0]))
+        with pytest.raises(RuntimeError):
+            RT.focus_search(RT.focus_search_methods[0], z_start=5)  # nothing traced yet
+        RT.trace(200_000)
+        for method in RT.focus_search_methods:
+            res, _ = RT.focus_search(method, z_start=5.0)
+            assert abs(res.x - fs) < 0.15, method
+        res, _ = RT.focus_search(RT.focus_search_methods[0], z_start=5.0, source_index=0)
+        assert abs(res.x - fs) < 0.15
+
+        RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=0.5, pos=[0, 0, -60]))
+        RT.outline = [-3, 3, -3, 3, -70, 80]
+        RT.trace(100_000)
+        res, _ = RT.focus_search(RT.focus_search_methods[0], z_start=5.0, source_index=0)
+        assert abs(res.x - fs) < 0.15
+        res, _ = RT.focus_search(RT.focus_search_methods[0], z_start=5.0, source_index=1)
+        assert abs(res.x - 73.73) < 0.1
+
+        with pytest.raises(ValueError):
+            RT.focus_search(RT.focus_search_methods[0], z_start=-100)
+        with pytest.raises(ValueError):
+            RT.focus_search("AA", z_start=10)
+        for bad in (-1, 10):
+            with pytest.raises(IndexError):
+                RT.focus_search(RT.focus_search_methods[0], z_start=10, source_index=bad)
+        # search regions before, between and behind the elements
+        RT.focus_search(RT.focus_search_methods[0], z_start=RT.outline[4])
+        RT.focus_search(RT.focus_search_methods[0], z_start=RT.outline[4], source_index=0)
+        RT.focus_search(RT.focus_search_methods[0], z_start=RT.outline[5])
+        RT.focus_search(RT.focus_search_methods[0], z_start=RT.lenses[0].extent[5] + 0.01)
+        RT.focus_search("Irradiance Variance", z_start=RT.outline[5])
