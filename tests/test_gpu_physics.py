@@ -336,3 +336,20 @@ def test_sphere_projections_keep_their_promises():
         a = RT.detector_image(detector_index=0, extent=[-3, 3, -3, 3])
         b = RT.detector_image(detector_index=1, extent=[-3, 3, -3, 3], projection_method="Orthographic")
         np.testing.assert_allclose(b._data, a._data, rtol=0, atol=1e-12 * a._data.max())
+
+
+def test_ideal_lenses_keep_polarisation_transverse():
+    """After the reference's test_ideal_lens_polarization (tests/test_tracer.py:1163-1181): behind a converging and a
+    diverging ideal lens the polarisation is still perpendicular to the direction and of unit length."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, 0, 40], seed=14)
+        RT.add(ot.RaySource(ot.RectangularSurface(dim=[4, 4]), divergence="None", s=[0, 0, 1], pos=[0, 0, 0]))
+        RT.add(ot.IdealLens(r=5, D=120, pos=[0, 0, 12]))
+        RT.add(ot.IdealLens(r=6, D=-50, pos=[0, 0, 24]))
+        RT.trace(200_000)
+    _, s, pol, _, _, _, _ = RT.rays.rays_by_mask(ret=[0, 1, 1, 0, 0, 0, 0])
+    scal = np.sum(s * pol, axis=2)[:, :-1]
+    assert np.ptp(scal) < 4e-7
+    assert np.allclose(np.sum(pol.astype(np.float64) ** 2, axis=2)[:, :-1], 1, rtol=2e-5)
+    # and the two lenses do what their powers say: the beam converges (1 / 120 mm), then diverges again
+    assert np.all(s[:, 0, 2] == 1) and np.mean(s[:, 1, 2]) < 1 and np.mean(s[:, 2, 2]) < 1
