@@ -310,3 +310,36 @@ def test_offset_system_equality(pos0):
     assert abs((ref.extent[1] - ref.extent[0]) - (im.extent[1] - im.extent[0])) < 0.001
     assert abs((ref.extent[3] - ref.extent[2]) - (im.extent[3] - im.extent[2])) < 0.001
     assert abs(ref.power() - im.power()) < 5e-5
+
+
+def test_render_entry_points_reject_what_the_reference_rejects():
+    """After the reference's test_image_render_parameter (tests/test_tracer.py:919-953): error behaviour of the image
+    and spectrum calls -- nothing traced, indices out of range, malformed extents, no detectors, no sources."""
+    with ot.global_options.no_warnings():
+        RT = scenes.mixed_geometry(ot, seed=1)
+        for f in (RT.detector_image, RT.detector_spectrum, RT.source_image, RT.source_spectrum):
+            with pytest.raises(RuntimeError):
+                f()
+        RT.trace(10_000)
+        for bad in (3, -3):
+            for f in (RT.detector_image, RT.detector_spectrum):
+                with pytest.raises(IndexError):
+                    f(detector_index=bad)
+                with pytest.raises(IndexError):
+                    f(source_index=bad)
+            for f in (RT.source_image, RT.source_spectrum):
+                with pytest.raises(IndexError):
+                    f(source_index=bad)
+        for f in (RT.detector_image, RT.detector_spectrum):
+            with pytest.raises(ValueError):
+                f(extent="abc")
+            with pytest.raises(ValueError):
+                f(extent=[1, 2, 1, np.inf])
+        RT.detectors = []
+        for f in (RT.detector_image, RT.detector_spectrum):
+            with pytest.raises(RuntimeError):
+                f()
+        RT.ray_sources = []
+        for f in (RT.source_image, RT.source_spectrum):
+            with pytest.raises(RuntimeError):
+                f()
