@@ -343,3 +343,70 @@ def test_render_entry_points_reject_what_the_reference_rejects():
         for f in (RT.source_image, RT.source_spectrum):
             with pytest.raises(RuntimeError):
                 f()
+
+
+def test_iterative_render_arguments():
+    """After the reference's test_iterative_render (tests/test_tracer.py:956-1075): single values and per-position lists
+    of positions, detector indices, extents, projections and limits; mismatched lists, missing detectors / sources and
+    colliding geometry raise; chunks add up, also with an odd-sized last chunk; counters add up over the chunks."""
+    with ot.global_options.no_warnings():
+        RT = scenes.mixed_geometry(ot, seed=7)
+        RT.ITER_RAYS_STEP = 40_000
+        N = 4000
+        dim = RT.iterative_render(N)
+        assert len(dim) == 1 and dim[0].limit is None
+        RT.iterative_render(N, pos=[0, 0, 13.3])
+        ext2 = [0, *RT.detectors[0].extent[1:4]]
+        assert np.all(RT.iterative_render(N, extent=ext2)[0].extent == ext2)
+        RT.iterative_render(N, detector_index=1)
+        assert RT.iterative_render(N, detector_index=1, projection_method="Stereographic")[0].projection == "Stereographic"
+        assert RT.iterative_render(N, detector_index=0, limit=5)[0].limit == 5
+        assert len(RT.iterative_render(N, pos=[[0, 0, 0], [0, 0, 5]])) == 2
+        dim = RT.iterative_render(N, pos=[[0, 0, 0], [0, 0, 5]], detector_index=[0, 1])
+        assert len(dim) == 2 and dim[0].projection != dim[1].projection
+        dim = RT.iterative_render(10_000, pos=[[0, 0, 0], [0, 0, 5]], detector_index=1,
+                                  projection_method=["Equidistant", "Equal-Area"])
+        assert dim[0].projection != dim[1].projection
+        dim = RT.iterative_render(10_000, pos=[[0, 0, 0], [0, 0, 5]], detector_index=0, limit=[10, 12])
+        assert dim[0].limit != dim[1].limit
+
+        for bad in (0, -10):
+            with pytest.raises(ValueError):
+                RT.iterative_render(bad)
+        for kw in (dict(extent=[None, None]), dict(projection_method=["Equidistant", "Equal-Area"]),
+                   dict(detector_index=[0, 1]), dict(detector_index=[0, 1], pos=[0, 0, 0]), dict(limit=[4, 1], pos=[0, 0, 0])):
+            with pytest.raises(ValueError):
+                RT.iterative_render(10_000, **kw)
+
+        # whole chunks and an odd-sized last one: the power of the image does not depend on the chunking
+        RT.detectors[0].move_to([0, 0, 0])
+        one = RT.iterative_render(80_000)[0].power()
+        odd = RT.iterative_render(80_100)[0].power()
+        RT.ITER_RAYS_STEP = None
+        whole = RT.iterative_render(80_000)[0].power()
+        assert abs(one - whole) < 2e-2 * whole and abs(odd - whole) < 2e-2 * whole
+
+        det_backup = RT.detectors.copy()
+        RT.remove(RT.detectors)
+        with pytest.raises(RuntimeError):
+            RT.iterative_render(N)
+        RT.add(det_backup)
+        RT.remove(RT.ray_sources)
+        with pytest.raises(RuntimeError):
+            RT.iterative_render(N)
+
+        RT = scenes.mixed_geometry(ot, seed=7)
+        RT.lenses[0].move_to(RT.lenses[1].pos)  # collision
+        with pytest.raises(RuntimeError):
+            RT.iterative_render(1000)
+
+        # counters are summed over the chunks: every ray misses the hair-thin lens in every chunk
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 50], seed=7)
+        RT.add(ot.RaySource(ot.CircularSurface(r=2), spectrum=ot.LightSpectrum("Monochromatic", wl=555), divergence="None",
+                            pos=[0, 0, -3]))
+        RT.add(ot.Lens(ot.CircularSurface(r=1e-6), ot.CircularSurface(r=1e-6), n=ot.RefractionIndex("Constant", n=1.5),
+                       pos=[0, 0, 0], d=0.1))
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[2, 2]), pos=[0, 0, 10]))
+        RT.ITER_RAYS_STEP = 10_000
+        RT.iterative_render(30_000)
+        assert RT._msgs[RT.INFOS.ABSORB_MISSING, 1] >= 30_000 - 3
