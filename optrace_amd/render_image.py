@@ -238,11 +238,29 @@ class RenderImage(BaseClass):
         dev = require_device()
         Ny, Nx, _ = self.shape
         src = (self._dev if self._dev is not None else to_dev(self._data, np.float64)).reshape(-1)
-        out = torch.empty_like(src)
         dpsf = to_dev(psf, np.float64)
-        _capi.check(lib.ot_image_convolve(ptr(src), Nx, Ny, ptr(dpsf), ps, ptr(out), stream_ptr()))
+        if ps <= self._DIRECT_PSF_MAX:
+            out = torch.empty_like(src)
+            _capi.check(lib.ot_image_convolve(ptr(src), Nx, Ny, ptr(dpsf), ps, ptr(out), stream_ptr()))
+        else:
+            out = self._fft_convolve(src.view(Ny, Nx, 4), dpsf.view(2 * ps + 1, 2 * ps + 1), ps).reshape(-1)
         self._dev = out.view(Ny, Nx, 4)
         self._host = None
+
+    _DIRECT_PSF_MAX = 68  # (2 * 68 + 1)^2 taps fit the LDS of the direct kernel (`ot_image_convolve`)
+
+    @staticmethod
+    def _fft_convolve(img: "torch.Tensor", psf: "torch.Tensor", ps: int) -> "torch.Tensor":
+        """"same"-size zero-padded convolution of the four planes with a kernel too large for the direct kernel
+        (a resolution limit of many pixels, e.g. with a tiny extent): through the FFT, like the reference's
+        scipy.signal.fftconvolve (render_image.py:292); rocFFT through torch.fft.  Negative round-off is clamped."""
+        Ny, Nx, _ = img.shape
+        fh, fw = Ny + 2 * ps, Nx + 2 * ps  # size of the full convolution
+        fh, fw = fh + fh % 2, fw + fw % 2
+        A = torch.fft.rfft2(img.permute(2, 0, 1), s=(fh, fw))
+        B = torch.fft.rfft2(psf, s=(fh, fw))
+        full = torch.fft.irfft2(A * B, s=(fh, fw))
+        return full[:, ps:ps + Ny, ps:ps + Nx].clamp_min(0).permute(1, 2, 0).contiguous()
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key == "extent" and val is not None:

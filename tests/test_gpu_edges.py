@@ -410,3 +410,19 @@ def test_iterative_render_arguments():
         RT.ITER_RAYS_STEP = 10_000
         RT.iterative_render(30_000)
         assert RT._msgs[RT.INFOS.ABSORB_MISSING, 1] >= 30_000 - 3
+
+
+def test_stale_rays_are_refused():
+    """After the reference's test_source_detector_image_spectrum (tests/test_tracer.py:1067-1080): changing the
+    geometry without retracing makes every consumer of the rays raise."""
+    with ot.global_options.no_warnings():
+        RT = scenes.mixed_geometry(ot, seed=1)
+        RT.trace(10_000)
+        RT.remove(RT.lenses[0])
+        for f in (RT.detector_image, RT.detector_spectrum, RT.source_image, RT.source_spectrum):
+            with pytest.raises(RuntimeError):
+                f()
+        with pytest.raises(RuntimeError):
+            RT.focus_search(RT.focus_search_methods[0], z_start=30)
+        RT.trace(10_000)
+        RT.detector_image(limit=4, extent=[-0.01, 0.01, -0.01, 0.01])  # limit together with an extent only warns

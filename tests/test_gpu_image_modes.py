@@ -92,3 +92,32 @@ def test_rayleigh_filter_matches_reference(gm, limit):
     plain.render(gm["filter/ph"], gm["filter/w"], gm["filter/wl"])
     assert abs(plain.power() - img.power()) < 1e-6 * plain.power()
     assert img._data[..., 3].max() < plain._data[..., 3].max()
+
+
+def test_large_resolution_kernels_go_through_the_fft():
+    """A resolution limit of many pixels (a tiny extent) needs a kernel beyond the direct convolution's 137 x 137 taps:
+    the FFT path gives what the direct kernel gives where both apply, and handles the reference's own case
+    (tests/test_tracer.py:1083: limit=4 with a 0.02 mm extent)."""
+    import torch
+    import optrace_amd as ot
+    from optrace_amd.render_image import RenderImage
+    rng = np.random.default_rng(3)
+    img = RenderImage(extent=[-1, 1, -1, 1])
+    img._data = np.zeros((945, 945, 4))
+    d = rng.random((945, 945, 4)) * (rng.random((945, 945, 1)) < 0.02)
+    img._data = d
+    img._limit = 2000 * 2 / 945 * 20          # first zero 20 pixels out: ps = 54, the direct kernel
+    a = RenderImage(extent=[-1, 1, -1, 1]); a._data = d.copy(); a._limit = img._limit
+    a._apply_rayleigh_filter()
+    b = RenderImage(extent=[-1, 1, -1, 1]); b._data = d.copy(); b._limit = img._limit
+    old = RenderImage._DIRECT_PSF_MAX
+    try:
+        RenderImage._DIRECT_PSF_MAX = 0         # force the FFT
+        b._apply_rayleigh_filter()
+    finally:
+        RenderImage._DIRECT_PSF_MAX = old
+    assert np.abs(a._data - b._data).max() < 1e-11 * a._data.max()
+    assert abs(b._data[..., 3].sum() / d[..., 3].sum() - 1) < 0.05  # power stays (edges lose a little)
+    c = RenderImage(extent=[-1, 1, -1, 1]); c._data = d.copy(); c._limit = 2000 * 2 / 945 * 120   # ps = 324
+    c._apply_rayleigh_filter()
+    assert np.all(np.isfinite(c._data)) and c._data.min() >= 0 and c._data[..., 3].sum() > 0.5 * d[..., 3].sum()
