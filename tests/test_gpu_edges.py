@@ -426,3 +426,39 @@ def test_stale_rays_are_refused():
             RT.focus_search(RT.focus_search_methods[0], z_start=30)
         RT.trace(10_000)
         RT.detector_image(limit=4, extent=[-0.01, 0.01, -0.01, 0.01])  # limit together with an extent only warns
+
+
+def test_meniscus_lenses_whose_surfaces_embrace_each_other():
+    """After the reference's test_non_sequental_surface_extent (tests/test_tracer_special.py:366-417): near-hemispherical
+    meniscus lenses, one surface reaching past the other in z -- no geometry error, a beam through the middle passes
+    completely, a ring of rays aimed at the gap between the surfaces' edges is absorbed completely."""
+    N = 100_000
+    R1, R2 = 5, 10
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-15, 15, -15, 15, -20, 50], seed=10)
+        RS = ot.RaySource(ot.CircularSurface(r=4), pos=[0, 0, -20])
+        RT.add(RS)
+        L = ot.Lens(ot.SphericalSurface(r=0.999 * R1, R=-R1), ot.SphericalSurface(r=0.999 * R2, R=-R2), pos=[0, 0, 0],
+                    n=ot.RefractionIndex(), d=0.5)                                    # )): second embraces first
+        RT.add(L)
+        RT.add(ot.Filter(ot.CircularSurface(r=3), spectrum=ot.TransmissionSpectrum("Constant", val=1), pos=[0, 0, 20]))
+        RT.trace(N)
+        assert not RT.geometry_error and np.all(RT.rays.w_list[:, -2] > 0)
+
+        RT.remove(L)
+        L = ot.Lens(ot.SphericalSurface(r=0.999 * R2, R=R2), ot.SphericalSurface(r=0.999 * R1, R=R1), pos=[0, 0, 0],
+                    n=ot.RefractionIndex(), d=0.5)                                    # ((: first embraces second
+        RT.add(L)
+        RT.trace(N)
+        assert not RT.geometry_error and np.all(RT.rays.w_list[:, -2] > 0)
+
+        RT.remove(RS)
+        RT.add(ot.RaySource(ot.RingSurface(r=7, ri=6), pos=[0, 0, -20]))             # aimed at the edge gap
+        RT.trace(N)
+        assert not RT.geometry_error and np.all(RT.rays.w_list[:, -2] == 0)
+
+        RT.remove(L)
+        RT.add(ot.Lens(ot.SphericalSurface(r=0.999 * R1, R=-R1), ot.SphericalSurface(r=0.999 * R2, R=-R2), pos=[0, 0, 0],
+                       n=ot.RefractionIndex(), d=0.5))
+        RT.trace(N)
+        assert not RT.geometry_error and np.all(RT.rays.w_list[:, -2] == 0)
