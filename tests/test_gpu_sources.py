@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import optrace_amd as ot
+import scenes
 from helpers import load
 
 pytestmark = pytest.mark.gpu
@@ -371,3 +372,44 @@ def test_divergence_modes_illuminate_a_plane_as_predicted():
         RT.trace(2_000_000)
         img, r = image()
         assert flat(img / (1 + np.sqrt(np.arctan(r / 10))) / np.cos(np.arctan(r / 10)) ** 3) < 0.05
+
+
+def test_every_combination_of_source_options():
+    """After the reference's test_ray_source_behavior (tests/test_geometry.py:474-548): every emitter shape x divergence
+    x 2-D / 3-D x orientation x polarisation mode creates rays that point forward, carry the source power, start on
+    the emitter inside its extent, and have unit direction and polarisation vectors; one-pixel-wide images work."""
+    def or_func(x, y):
+        s = np.column_stack((-x, -y, np.ones_like(x) * 5))
+        return s / np.linalg.norm(s, axis=1)[:, None]
+
+    rargs = dict(spectrum=ot.presets.light_spectrum.d50, or_func=or_func, pos=[0.5, -2, 3], power=2.5, s=[0, 0.5, 1],
+                 pol_angle=0.5, div_func=lambda e: np.cos(e), pol_func=lambda x: x, pol_angles=[10, 30], pol_probs=[1, 2],
+                 conv_pos=[1, 2, 10])
+    rgb = ot.RGBImage(scenes.synthetic_rgb_image(), [2, 2])
+    gray = ot.GrayscaleImage(scenes.synthetic_gray_image(), [2, 2])
+    surfaces = [ot.Point(), ot.Line(r=3), ot.CircularSurface(r=2), rgb, ot.RectangularSurface(dim=[2, 2]),
+                ot.RingSurface(r=2, ri=0.2), gray]
+    n = 0
+    for surf in surfaces:
+        for div in ot.RaySource.divergences:
+            for div_2d in (False, True):
+                if div == "None" and div_2d:
+                    continue
+                for orient in ot.RaySource.orientations:
+                    for pol in ot.RaySource.polarizations:
+                        RS = ot.RaySource(surf, divergence=div, orientation=orient, div_2d=div_2d, polarization=pol, **rargs)
+                        p, s, pols, w, wl = RS.create_rays(4000)
+                        what = (type(surf).__name__, div, div_2d, orient, pol)
+                        assert np.min(s[:, 2]) > 0, what
+                        assert np.min(w) > 0 and abs(np.sum(w.astype(np.float64)) - rargs["power"]) < 1e-5, what
+                        assert 380 <= np.min(wl) and np.max(wl) <= 780, what
+                        assert np.all(p[:, 2] == rargs["pos"][2]), what
+                        ext = RS.surface.extent
+                        assert ext[0] - 1e-12 <= np.min(p[:, 0]) and np.max(p[:, 0]) <= ext[1] + 1e-12, what
+                        assert ext[2] - 1e-12 <= np.min(p[:, 1]) and np.max(p[:, 1]) <= ext[3] + 1e-12, what
+                        assert np.allclose(np.sum(s ** 2, axis=1), 1, atol=2e-5, rtol=0), what
+                        assert np.allclose(np.sum(pols ** 2, axis=1), 1, atol=2e-5, rtol=0), what
+                        n += 1
+    assert n == 7 * 7 * 3 * 7
+    for arr in (np.array([[[0., 1., 0.]]]), np.array([[[0., 1., 0.], [1., 1., 0.]]]), np.array([[[0., 1., 0.]], [[1., 1., 0.]]])):
+        ot.RaySource(ot.RGBImage(arr, [2, 2]), divergence="Lambertian", pos=[0, 0, 0], s=[0, 0, 1], div_angle=75).create_rays(10_000)
