@@ -169,3 +169,44 @@ def test_brewster_plate_through_three_surface_types():
             ci, ct = np.cos(b_ang), np.cos(np.arcsin(np.sin(b_ang) / 1.55))
             Rs = ((ci - 1.55 * ct) / (ci + 1.55 * ct)) ** 2
             np.testing.assert_allclose(w[ysrc, -2], w[ysrc, 0] * (1 - Rs) ** 2, rtol=1e-5)
+
+
+@pytest.mark.parametrize("k", [-1, 0])
+@pytest.mark.parametrize("R", [0.1, 10, 10000])
+def test_normals_of_numeric_surfaces_across_scales(k, R):
+    """After the reference's test_surface_numerical_precision (tests/test_surface.py:704-766): normals of a paraboloid /
+    sphere cap written as function surfaces (1e-7) and as data surfaces of 50-401 samples (1e-4), for curvature radii
+    from 0.1 to 10 000 mm, offsets down to -10 000 mm and apertures of 0.2 % and 70 % of the radius.  One corner is
+    looser than the reference's 1e-7: a 0.4 um wide aperture on an offset of -10 000 mm, where the rounding noise of the
+    function itself (2e-12) over the coarsest sampling step limits the tabulated slopes to 5e-7."""
+    def n_conic(x, y, rho):
+        r = np.sqrt(x ** 2 + y ** 2)
+        phi = np.arctan2(y, x)
+        n_r = -rho * r / np.sqrt(1 - k * rho ** 2 * r ** 2)
+        return np.column_stack((n_r * np.cos(phi), n_r * np.sin(phi), np.sqrt(1 - n_r ** 2)))
+
+    worst = []
+    with ot.global_options.no_warnings():
+        for z0 in (0, -80, -10000):
+            if k == -1:
+                surf_f = lambda x, y: z0 + (x ** 2 + y ** 2) / R / 2  # noqa: E731
+            else:
+                surf_f = lambda x, y: z0 + R - np.sqrt(R ** 2 - (x ** 2 + y ** 2))  # noqa: E731
+            for fr in (0.002, 0.7):
+                r = fr * R
+                x = np.linspace(0, r, 100)
+                y = np.zeros_like(x)
+                should = n_conic(x, y, 1 / R)
+                tol = 5e-7 if (z0 == -10000 and r < 1e-3) else 1e-7
+                e2 = np.abs(ot.FunctionSurface2D(func=surf_f, r=r).normals(x, y) - should).max()
+                e1 = np.abs(ot.FunctionSurface1D(func=lambda rr: surf_f(rr, np.zeros_like(rr)), r=r).normals(x, y) - should).max()
+                if max(e1, e2) > tol:
+                    worst.append((z0, fr, e1, e2))
+                for N in (50, 51, 400, 401):
+                    Y, X = np.mgrid[-r:r:N * 1j, -r:r:N * 1j]
+                    d2 = ot.DataSurface2D(data=surf_f(X.flatten(), Y.flatten()).reshape(X.shape), r=r)
+                    d1 = ot.DataSurface1D(data=surf_f(np.linspace(0, r, N), np.zeros(N)), r=r)
+                    ed = max(np.abs(d2.normals(x, y) - should).max(), np.abs(d1.normals(x, y) - should).max())
+                    if ed > 1e-4:
+                        worst.append((z0, fr, N, ed))
+    assert not worst, worst

@@ -316,7 +316,8 @@ def test_tilted_data_function_surfaces_host_logic():
         f1 = ot.FunctionSurface1D(r=2, func=lambda r: 0.5 + r ** 2 / 10, z_min=0.5, z_max=0.9)
         assert abs(f1.z_min) < 1e-12 and abs(f1.z_max - 0.4) < 1e-12 and f1._tab_residual < 1e-12
         f2 = ot.FunctionSurface2D(r=2, func=lambda x, y: x ** 2 / 10 + y ** 2 / 25)
-        assert f2._nknots == 401 + _capi.SPL_K + 1 and f2._tab_residual < 1e-12 and f2._grad_residual < 1e-9
+        # a quadratic is exact on the coarsest grid tried
+        assert f2._nknots == 17 + _capi.SPL_K + 1 and f2._tab_residual < 1e-12 and f2._grad_residual < 1e-9
         f2.rotate(45)
         f2.flip()
         assert f2._sign == -1 and abs(f2._angle - np.pi / 4) < 1e-15 and f2._desc().flags == 0
