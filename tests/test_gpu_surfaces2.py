@@ -210,3 +210,32 @@ def test_normals_of_numeric_surfaces_across_scales(k, R):
                     if ed > 1e-4:
                         worst.append((z0, fr, N, ed))
     assert not worst, worst
+
+
+def test_hit_finding_properties_on_every_surface():
+    """After the reference's test_surface_hit_finding (tests/test_surface.py:237-268), over every surface flavour of the
+    device kernels: hits lie on the surface (C_EPS) and on their ray; rays that miss above valid surface coordinates
+    end behind the surface; rays that start behind the surface stay where they are and do not hit."""
+    rng = np.random.default_rng(11)
+    p = rng.uniform(-2, -1, size=(10000, 3))
+    s = rng.uniform(-1, 1, size=(10000, 3))
+    s /= np.linalg.norm(s, axis=1)[:, None]
+    s[:, 2] = np.abs(s[:, 2])
+    s[s[:, 2] < 1e-3, 2] = 1e-3  # grazing directions: keep the ray parameter finite
+    s /= np.linalg.norm(s, axis=1)[:, None]
+    with ot.global_options.no_warnings():
+        zoo = {**scenes.surface_zoo(ot), **scenes.surface_zoo2(ot)}
+        for name, S in zoo.items():
+            C = S.C_EPS
+            p_hit, is_hit, _ = S.find_hit(p, s)
+            z_hit = S.values(p_hit[is_hit, 0], p_hit[is_hit, 1])
+            assert np.allclose(p_hit[is_hit, 2] - z_hit, 0, rtol=0, atol=C), name
+            zs = S.values(p_hit[~is_hit, 0], p_hit[~is_hit, 1])
+            ms = S.mask(p_hit[~is_hit, 0], p_hit[~is_hit, 1])
+            assert np.all(p_hit[~is_hit, 2][ms] > zs[ms] - 1e-12), name
+            t = (p_hit[:, 2] - p[:, 2]) / s[:, 2]
+            assert np.allclose(p + s * t[:, None] - p_hit, 0, atol=C), name
+            behind = p_hit.copy()
+            behind[:, 2] = S.z_max + 2
+            p2, hit2, _ = S.find_hit(behind, s)
+            assert np.allclose(p2 - behind, 0) and not np.any(hit2), name
