@@ -372,3 +372,31 @@ def test_image_profile_cuts():
         im.profile()
     with pytest.raises(ValueError):
         im.profile(x=5)
+
+
+def test_function_surface_z_bounds_like_the_reference():
+    """After the reference's test_surface_zmin_zmax_cases (tests/test_surface.py:508-542): user z bounds of a function
+    surface are taken when they enclose the measured range (also generously), and ignored with a warning when they are
+    too narrow or shifted."""
+    with ot.global_options.no_warnings():
+        lin = lambda x, y: x  # noqa: E731
+        for kw in (dict(z_max=5), dict(z_min=5)):
+            with pytest.raises(ValueError):
+                ot.FunctionSurface2D(r=2, func=lin, **kw)
+        sfunc = lambda x, y: x ** 2 + y ** 2 / 10  # noqa: E731
+        z_min, z_max = ot.FunctionSurface2D(func=sfunc, r=3).extent[4:]
+        assert abs(z_min) < 1e-9 and abs(z_max - 9) < 1e-6
+
+        def bounds(dz0, dz1):
+            sf = ot.FunctionSurface2D(func=sfunc, r=3, z_min=z_min + dz0, z_max=z_max + dz1)
+            return sf.z_min, sf.z_max
+
+        a = bounds(0, 0)
+        assert abs(a[0] - z_min) < 1e-7 and abs(a[1] - z_max) < 1e-7
+        a = bounds(-1e-9, 1e-9)
+        assert abs(a[0] - (z_min - 1e-9)) < 1e-12 and abs(a[1] - (z_max + 1e-9)) < 1e-12          # taken
+        for dz in ((1e-3, -1e-3), (1e-3, 1e-3), (-1e-3, -1e-3)):                                  # too narrow / shifted
+            a = bounds(*dz)
+            assert abs(a[0] - (z_min + dz[0])) > 1e-4 and abs(a[1] - (z_max + dz[1])) > 1e-4
+        a = bounds(0, 5)                                                                          # generous: taken
+        assert abs(a[0] - z_min) < 1e-7 and abs(a[1] - (z_max + 5)) < 1e-12
