@@ -121,3 +121,26 @@ def test_large_resolution_kernels_go_through_the_fft():
     c = RenderImage(extent=[-1, 1, -1, 1]); c._data = d.copy(); c._limit = 2000 * 2 / 945 * 120   # ps = 324
     c._apply_rayleigh_filter()
     assert np.all(np.isfinite(c._data)) and c._data.min() >= 0 and c._data[..., 3].sum() > 0.5 * d[..., 3].sum()
+
+
+@pytest.mark.parametrize("k", [1, 0.3, 5])
+def test_resolution_filter_turns_a_point_into_an_airy_disc(k):
+    """After the reference's test_r_image_filter (tests/test_image.py:216-253): a point rendered with a resolution limit
+    becomes an Airy disc whose radial centroid is 1.10861 / 3.8317 of the limit, for square and elongated images and
+    for limits of a few and of very many pixels (direct kernel and FFT)."""
+    import optrace_amd as ot
+    p = np.zeros((1000, 3))
+    w = np.ones(1000)
+    wl = np.full(1000, 500)
+    r0 = 1e-4  # smaller than the resolution limit
+    img = ot.RenderImage([-r0, r0, -k / 2 * r0, k / 2 * r0])
+    for limit in (0.3, 20):
+        img.render(p, w, wl, limit=limit)
+        irr = img._data[:, :, 3]
+        ny, nx = irr.shape[:2]
+        x = np.linspace(0, img.extent[1], nx // 2 + 1)
+        cut = irr[ny // 2 + 1, nx // 2:]
+        centroid = 3.8317 * np.sum(x * cut) / np.sum(cut)
+        assert abs(centroid / 1.10861 - limit / 1000) < 0.0002, (k, limit)
+    with pytest.raises(RuntimeError):
+        ot.RenderImage([-1, 1, -1, 1], projection="abc").render(limit=1)
