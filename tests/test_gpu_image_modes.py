@@ -144,3 +144,45 @@ def test_resolution_filter_turns_a_point_into_an_airy_disc(k):
         assert abs(centroid / 1.10861 - limit / 1000) < 0.0002, (k, limit)
     with pytest.raises(RuntimeError):
         ot.RenderImage([-1, 1, -1, 1], projection="abc").render(limit=1)
+
+
+def test_render_and_rescale_keep_power_and_shape():
+    """After the reference's test_render_image_render_and_rescaling (tests/test_image.py:108-172): power and luminous
+    power of rendered random hits, with and without the resolution filter and for four side ratios; every image size
+    keeps the integrated power, the side ratio, and picks the nearest of SIZES; extents that are too small or too
+    elongated are adjusted; impossible sizes raise."""
+    import optrace_amd as ot
+    rng = np.random.default_rng(8)
+    for limit in (None, 20):
+        for ratio in (1 / 6, 0.38, 1, 5):
+            img = ot.RenderImage([-1, 1, -1 * ratio, 1 * ratio])
+            N = 10_000
+            p = np.zeros((N, 3))
+            p[:, 0] = rng.uniform(img.extent[0], img.extent[1], N)
+            p[:, 1] = rng.uniform(img.extent[2], img.extent[3], N)
+            w = rng.uniform(1e-9, 1, N)
+            wl = rng.uniform(380, 780, N)
+            img.render(p, w, wl, limit=limit)
+            P0, L0 = img.power(), img.luminous_power()
+            tol = 1e-6 if limit is None else 2e-2   # the filter loses what it spreads over the image border
+            assert abs(P0 / np.sum(w) - 1) < tol
+            assert L0 > 0
+            ratio_act = img.shape[1] / img.shape[0]
+            for Npx in [*ot.RenderImage.SIZES, *rng.integers(1, ot.RenderImage.SIZES[-1], 3)]:
+                for Q, mode in ((P0, "Irradiance"), (L0, "Illuminance")):
+                    data = img.get(mode, int(Npx))
+                    siz = ot.RenderImage.SIZES
+                    near = siz[int(np.argmin(np.abs(Npx - np.array(siz))))]
+                    assert near == (data.shape[1] if ratio_act < 1 else data.shape[0])
+                    assert abs(Q / np.sum(data.data) / data.Apx - 1) < 1e-6
+                    assert abs(ratio_act - data.shape[1] / data.shape[0]) < 1e-12
+    img.render()
+    for bad in (ot.RenderImage.MAX_IMAGE_SIDE * 1.2, -2, 0):
+        with pytest.raises(ValueError):
+            img.get("Irradiance", N=bad)
+    for ext in ([0, ot.RenderImage.EPS / 2, 0, ot.RenderImage.EPS / 2], [0, 1, 0, 1.2 * ot.RenderImage.MAX_IMAGE_RATIO],
+                [0, 1.2 * ot.RenderImage.MAX_IMAGE_RATIO, 0, 1]):
+        im = ot.RenderImage(extent=ext)
+        before = im.extent.copy()
+        im.render()
+        assert not np.all(im.extent == before)
