@@ -349,7 +349,14 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 int prim = (choice < c_r) ? 0 : ((choice > c_rg) ? 2 : 1);
                 const double* tab = src.prim_tab + (size_t)prim * 2 * OT_PRIM_N;
                 const double* F = tab + OT_PRIM_N;
-                double X = strat_interval(g, ST_RGB_WL, F[0], F[OT_PRIM_N - 1]);
+                // The reference stratifies the wavelengths of each primary over exactly the rays that got that primary
+                // (srgb.py:549-551), which keeps the colour noise of an image far below 1 / sqrt(rays per primary).  The
+                // stratified choice variable carries that for free: inside the sub-interval that selected the primary it is
+                // itself a stratified uniform variable over that primary's rays (exactly so for equal pixel colours).
+                const double lo = (prim == 0) ? 0.0 : ((prim == 1) ? c_r : c_rg);
+                const double hi = (prim == 0) ? c_r : ((prim == 1) ? c_rg : 1.0);
+                const double t = (hi > lo) ? ot_div(choice - lo, hi - lo) : 0.5;
+                double X = F[0] + t * (F[OT_PRIM_N - 1] - F[0]);
                 wl = inv_cdf_linear(src.prim_pairs + (size_t)prim * 2 * OT_PRIM_N, OT_PRIM_N, X, src.g_prim[prim]);
             }
         }

@@ -413,3 +413,24 @@ def test_every_combination_of_source_options():
     assert n == 7 * 7 * 3 * 7
     for arr in (np.array([[[0., 1., 0.]]]), np.array([[[0., 1., 0.], [1., 1., 0.]]]), np.array([[[0., 1., 0.]], [[1., 1., 0.]]])):
         ot.RaySource(ot.RGBImage(arr, [2, 2]), divergence="Lambertian", pos=[0, 0, 0], s=[0, 0, 1], div_angle=75).create_rays(10_000)
+
+
+def test_image_orientation_is_consistent():
+    """After the reference's test_image_orientation (tests/test_image.py:400-424): the one bright pixel [0, 0] of an image
+    source appears at [0, 0] of the source image, of the detector image and of an image rebuilt from the rendered data."""
+    im_data = np.zeros((5, 5, 3))
+    im_data[0, 0] = 1
+    img = ot.RGBImage(im_data, [1, 1])
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer([-2, 2, -2, 2, -10, 10], seed=3)
+        RT.add(ot.RaySource(img, pos=[0, 0, 0], s=[0, 0, 1], divergence="None"))
+        RT.add(ot.Detector(ot.RectangularSurface([1, 1]), pos=[0, 0, 1]))
+        RT.trace(10_000)
+        simg = RT.source_image().get("sRGB (Absolute RI)", 5).data
+        dimg = RT.detector_image(extent=img.extent).get("sRGB (Absolute RI)", 5).data
+    assert abs(np.mean(simg[0, 0]) - 1) < 0.001 and abs(np.mean(dimg[0, 0]) - 1) < 0.001
+    assert np.mean(simg[1:, 1:]) < 1e-6 and np.mean(dimg[1:, 1:]) < 1e-6
+    assert abs(np.mean(ot.RGBImage(dimg, [1, 1]).data[0, 0]) - 1) < 0.001
+    # and the first row / column of the array is the low-y / low-x side of the source plane
+    p = RT.rays.p_list[:, 0]
+    assert p[:, 0].max() < -0.3 + 1e-12 and p[:, 1].max() < -0.3 + 1e-12
