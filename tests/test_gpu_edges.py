@@ -462,3 +462,52 @@ def test_meniscus_lenses_whose_surfaces_embrace_each_other():
                        n=ot.RefractionIndex(), d=0.5))
         RT.trace(N)
         assert not RT.geometry_error and np.all(RT.rays.w_list[:, -2] == 0)
+
+
+def test_ray_storage_bookkeeping():
+    """After the reference's test_ray_storage (tests/test_tracer.py:738-832): ray counts and powers per source for
+    several power ratios, ray numbers and numbers of sources; source_sections and rays_by_mask shapes, omitted
+    properties, unit directions; direction_vectors and source_numbers agree with rays_by_mask."""
+    rng = np.random.default_rng(5)
+    with ot.global_options.no_warnings():
+        RT = scenes.mixed_geometry(ot, seed=9)
+        RT.add(ot.RaySource(ot.Point(), spectrum=ot.LightSpectrum("Monochromatic", wl=550), pos=[0, 0, 0]))
+        assert len(RT.ray_sources) == 3
+        for _ in range(2):
+            for powers in ((1, 1, 1), (2, 1, 1), (0.3456465, 4.57687168, np.pi / 2)):
+                for N in (30000, 30001, 52657):
+                    for rs, pw in zip(RT.ray_sources, powers):
+                        rs.power = pw
+                    RT.trace(N)
+                    r = RT.rays
+                    assert N == r.N
+                    P_s = sum(rs.power for rs in RT.ray_sources)
+                    assert abs(P_s - np.sum(r.w_list[:, 0].astype(np.float64))) < 10 / N
+                    for Ni, rs in enumerate(RT.ray_sources):
+                        assert r.source_sections(Ni)[0].shape[0] == r.N_list[Ni]
+                        assert abs(r.N_list[Ni] / r.N - rs.power / P_s) < 10 / N
+                    assert r.source_sections()[0].shape[0] == N
+                    for t1, t2 in zip(r.rays_by_mask(), r.rays_by_mask(np.ones(N, dtype=bool))):
+                        np.testing.assert_array_equal(t1, t2)
+                    ch = rng.integers(0, 2, size=N).astype(bool)
+                    N2 = int(np.count_nonzero(ch))
+                    ch2 = rng.integers(0, r.Nt, size=N2)
+                    for ch2li in (None, ch2):
+                        for retli in (None, [1, 0, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 0, 0]):
+                            for normli in (False, True):
+                                tup = r.rays_by_mask(ch, ch2li, retli, normli)
+                                assert tup[3].shape[0] == N2 and tup[3].ndim == (1 if ch2li is not None else 2)
+                                for k in (1, 5, 6):
+                                    assert retli is None or retli[k] or tup[k] is None
+                                if normli and (retli is None or retli[1]):
+                                    mask = np.all(np.isfinite(tup[1]), axis=2 if ch2li is None else 1)
+                                    assert np.allclose(np.sum(tup[1][mask] ** 2, axis=-1), 1, rtol=0, atol=1e-4)
+            RT.remove(RT.ray_sources[-1])
+
+        RT = scenes.mixed_geometry(ot, seed=9)
+        RT.trace(100_000)
+        for norm in (False, True):
+            s1 = RT.rays.rays_by_mask(ret=[0, 1, 0, 0, 0, 0, 0], normalize=norm)[1]
+            s2 = RT.rays.direction_vectors(norm)
+            assert np.all((s1 == s2) | np.isnan(s1))
+        assert np.all(RT.rays.rays_by_mask(ret=[0, 0, 0, 0, 0, 1, 0])[5] == RT.rays.source_numbers())
