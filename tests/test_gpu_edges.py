@@ -511,3 +511,31 @@ def test_ray_storage_bookkeeping():
             s2 = RT.rays.direction_vectors(norm)
             assert np.all((s1 == s2) | np.isnan(s1))
         assert np.all(RT.rays.rays_by_mask(ret=[0, 0, 0, 0, 0, 1, 0])[5] == RT.rays.source_numbers())
+
+
+def test_optical_and_geometric_path_lengths():
+    """After the reference's test_optical_lengths_ray_lengths (tests/test_tracer.py:835-886): axial rays through a slab,
+    a clear filter and a stop: section lengths 1, 1.2, 2.8, 4 mm; optical lengths with n(lambda) inside the slab; masked
+    calls pick the same numbers."""
+    rng = np.random.default_rng(2)
+    n = ot.RefractionIndex("Sellmeier1", coeff=[1.62153902, 0.0122241457, 0.256287842, 0.0595736775, 1.64447552, 147.468793])
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -2, 10], seed=4)
+        RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0]))
+        RT.add(ot.Lens(ot.CircularSurface(r=3), ot.CircularSurface(r=3), n=n, pos=[0, 0, 1], d1=0, d2=1.2))
+        RT.add(ot.Filter(ot.CircularSurface(r=3), spectrum=ot.TransmissionSpectrum("Constant", val=1), pos=[0, 0, 5]))
+        RT.add(ot.Aperture(ot.CircularSurface(r=3), pos=[0, 0, 9]))
+        RT.trace(1000)
+        r = RT.rays
+        ol = r.optical_lengths()
+        want = ol.copy()
+        want[:, 0], want[:, 1], want[:, 2], want[:, 3] = 1, n(r.wl_list) * 1.2, 2.8, 4
+        assert np.allclose(ol - want, 0, atol=1e-9, rtol=0)
+        m1 = rng.choice(np.array([0, 1], dtype=bool), size=r.N)
+        m2 = rng.choice(np.arange(r.Nt), size=r.N, replace=True)[m1]
+        assert np.all(ol[m1, m2] == r.optical_lengths(m1, m2))
+        ln = r.ray_lengths()
+        want = ln.copy()
+        want[:, 0], want[:, 1], want[:, 2], want[:, 3] = 1, 1.2, 2.8, 4
+        assert np.allclose(ln - want, 0, atol=1e-9, rtol=0)
+        assert np.all(ln[m1, m2] == r.ray_lengths(m1, m2))
