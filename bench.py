@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: ray-surface-intersections/s of Raytracer.trace() on the double-Gauss scene.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--no-pol]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--no-pol] [--backend nccl|gloo]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one bundle of synthetic rays: on-device ray generation from
-the five point sources, all 15 tracing surfaces, all section stores (what `RT.trace(N)` covers in
-tests/benchmark.py:81-86 of the reference).  Workload = BASELINE.json configs[1]: double_gauss.py geometry,
-10 M rays per GPU, 3 wavelengths (FDC lines), polarisation on.  Ray storage is allocated once and stays
-resident in HBM; every step uses a fresh seed.  Multi-GPU: rays are sharded, every rank traces its own
-bundle (weak scaling), no data-path collective inside the step; after the timed region the detector
-histograms are all-reduced once over RCCL to exercise the exchange step.
+One "step" = one call of `Raytracer.trace(N)` -- the call the reference times in tests/benchmark.py:81-86 -- on one
+bundle of synthetic rays: on-device ray generation from the five point sources, all 15 tracing surfaces, all
+section stores, the event counters back on the host.  Workload = BASELINE.json configs[1]: double_gauss.py
+geometry, 10 M rays per GPU, 3 wavelengths (FDC lines), polarisation on.  Every step draws a fresh seed.
 
-Rank 0 prints ONE JSON line (contract in the task description) carrying `roofline` (dominant kernel:
-algorithmic bytes / HIP-event kernel time against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle,
-a scalar port of the reference, timed on a bounded sample on the host cores).
+`--gpus N` without a torch.distributed environment starts the N ranks itself (a child `torch.distributed.run`,
+before this process makes any GPU call); launched by torch.distributed.run it is one of the ranks.  Rays are
+sharded, every rank traces its own bundle (weak scaling), no data-path collective inside the step; after the
+timed region the detector histograms are all-reduced once (RCCL) to exercise the exchange step.  With fewer
+devices than ranks the ranks share devices and the collectives run over gloo on host copies (a rehearsal of the
+multi-rank code path, labelled as such in the output).
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying `roofline` (dominant kernel: algorithmic
+bytes / HIP-event kernel time against the 8 TB/s HBM peak, plus the f64 issue fraction) and `cpu_baseline` (the
+CPU oracle, a scalar port of the reference, timed on a bounded sample on the host cores).
 """
 from __future__ import annotations
 
@@ -23,6 +27,7 @@ import ctypes as C
 import json
 import os
 import pathlib
+import subprocess
 import sys
 import time
 
@@ -31,10 +36,10 @@ for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# f64 mul/add issue rate of the whole chip, wave64 instructions per second, measured with
+# tools/experiments/op_rate.hip (profiles/r1/op_rate.txt: 4 independent chains, 8 waves per SIMD)
+F64_ISSUE_PEAK = 536.86e9
 
 
 def parse():
@@ -46,9 +51,35 @@ def parse():
     ap.add_argument("--no-pol", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
-                                                      "the multi-rank code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: collectives on "
+                                                      "host copies, also picked when ranks have to share a device)")
     return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """Parent of a `--gpus N` run: N ranks as children of one torch.distributed.run.  Nothing here touches the GPU
+    (device_count does not initialise it), so the children start from a clean process."""
+    import socket
+    import torch
+    backend = args.backend
+    if backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        backend = "gloo"  # RCCL refuses two ranks on one device; rehearse the path on host copies instead
+        print(f"bench.py: {torch.cuda.device_count()} device(s) for {args.gpus} ranks: ranks share devices, "
+              "collectives over gloo", file=sys.stderr)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--rays", str(args.rays), "--backend", backend, "--cpu-seconds", str(args.cpu_seconds)]
+    cmd += ["--no-pol"] if args.no_pol else []
+    cmd += ["--skip-cpu"] if args.skip_cpu else []
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(RT, scene, seconds: float) -> dict:
@@ -56,6 +87,7 @@ def cpu_baseline(RT, scene, seconds: float) -> dict:
     pinned to it by tests/test_oracle_golden.py) on a bounded sample of the same workload: rays generated
     by the device kernel for this scene, traced through all 15 surfaces on the host cores (rays split across
     threads like the reference splits them, ray_storage.py:147-171; one core is timed as well)."""
+    import numpy as np
     import oracle_bridge as ob  # checker / baseline only
     M = scene.nt - 2
     r = RT.rays
@@ -98,41 +130,50 @@ def cpu_baseline(RT, scene, seconds: float) -> dict:
                       f"threads; {n1} rays on 1 thread in {t1:.2f} s"}
 
 
-def secondary_no_pol(ot, scenes, lib, N, dev, steps):
-    """The bench scene with no_pol=True: {value, ms_per_step, roofline_frac} from `steps` launches after 10 warm-up ones."""
+def raw_launches(RT, lib, N, steps, warmup=10):
+    """`steps` asynchronous ot_generate_and_trace launches on the resident storage of RT, no host work in between:
+    (mean wall ms per launch, mean kernel ms from the library's events of the last launch)."""
+    import torch
     from optrace_amd import _capi
     from optrace_amd._device import ptr, stream_ptr
-    with ot.global_options.no_warnings():
-        RT = scenes.double_gauss(ot, no_pol=True, seed=77)
-        RT._geometry_checks()
-        scene = RT._compile()
-        nt = scene.nt
-        RT.rays.init(RT.ray_sources, N, nt, True)
-    rays, tab, rng = RT.rays._rays_struct(), RT.rays._source_table(), RT.rays._source_ranges()
-    msgs = torch.zeros(5 * nt + 1, dtype=torch.int64, device=dev)
-    for i in range(10 + steps):
-        if i == 10:
+    nt = RT.rays.Nt
+    rays, tab, rng = RT.rays._rays_struct(), RT._source_cache[1], RT.rays._source_ranges()
+    msgs = torch.zeros(5 * nt + 1, dtype=torch.int64, device=RT.rays._dev["p"].device)
+    for i in range(warmup + steps):
+        if i == warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         _capi.check(lib.ot_generate_and_trace(RT._scene_handle, tab.handle, rng, len(rng), 500 + i, C.byref(rays),
                                               ptr(msgs), stream_ptr()))
     torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def secondary_no_pol(ot, scenes, lib, N, steps):
+    """The bench scene with no_pol=True through the same API: {value, ms_per_step, roofline_frac}."""
+    import torch
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, no_pol=True, seed=None)
+        for i in range(10 + steps):
+            if i == 10:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            RT.trace(N)
     t = (time.perf_counter() - t0) / steps
+    nt = RT.rays.Nt
     b = N * (nt * 36 + 28)
     return {"value": N * (nt - 2) / t, "ms_per_step": 1e3 * t, "roofline_frac": b / t / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": b}
 
 
-def measured_traffic(pol: bool, N: int):
-    """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/<round>/trace_kernel_pmc.json; FETCH_SIZE
-    doubled as the gfx950 correction of MI355X_MICROARCH.md prescribes).  None if no profile matches."""
-    best = None
-    for f in sorted((ROOT / "profiles").glob("*/trace_kernel_pmc.json")):
+def committed_profile(name: str, pol: bool, N: int):
+    """Newest profiles/<round>/<name> recorded for this configuration, or (None, None)."""
+    best = (None, None)
+    for f in sorted((ROOT / "profiles").glob("*/" + name)):
         try:
             d = json.loads(f.read_text())
-            if d.get("rays") == N and d.get("pol") == pol:
-                best = (2 * float(np.median(d["FETCH_SIZE"])) + float(np.median(d["WRITE_SIZE"]))) * 1024
+            if d.get("rays", N) == N and d.get("pol", pol) == pol:
+                best = (d, str(f.relative_to(ROOT)))
         except Exception:
             pass
     return best
@@ -140,49 +181,49 @@ def measured_traffic(pol: bool, N: int):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # launched by torch.distributed.run (also with one rank: the same RCCL path as the N > 1 runs)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    ndev = max(torch.cuda.device_count(), 1)
+    backend = args.backend
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ndev = torch.cuda.device_count()
-        if args.backend == "nccl":
+        if backend == "nccl" and world > ndev:
+            backend = "gloo"
+        if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % ndev))
         else:
-            dist.init_process_group(backend=args.backend)
-        local_rank = local_rank % ndev
+            dist.init_process_group(backend=backend)
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    on_host = use_dist and args.backend != "nccl"  # gloo rehearsal: collectives on host copies
 
     import optrace_amd as ot
     from optrace_amd import _capi
-    from optrace_amd._device import ptr, stream_ptr
     from optrace_amd import distributed as D
     import scenes
 
     lib = _capi.load_library()
     N = args.rays
     with ot.global_options.no_warnings():
-        RT = scenes.double_gauss(ot, no_pol=args.no_pol, seed=1000 + rank)
-        RT._geometry_checks()
-        assert not RT.geometry_error
-        scene = RT._compile()
-        nt = scene.nt
-        M = nt - 2
-        RT.rays.init(RT.ray_sources, N, nt, RT.no_pol)
-    rays = RT.rays._rays_struct()
-    tab = RT.rays._source_table()
-    rng = RT.rays._source_ranges()
-    msgs = torch.zeros(5 * nt + 1, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream()
-
-    def step(seed):
-        _capi.check(lib.ot_generate_and_trace(RT._scene_handle, tab.handle, rng, len(rng), seed, C.byref(rays),
-                                              ptr(msgs), stream_ptr()))
+        RT = scenes.double_gauss(ot, no_pol=args.no_pol, seed=None)
+        np.random.seed(1000 + rank)  # an unseeded tracer draws a fresh seed per trace from NumPy's generator
+        RT.trace(min(N, 100_000))    # compiles the scene, uploads the tables
+    assert not RT.geometry_error
+    scene = RT._scene
+    nt = scene.nt
+    M = nt - 2
+    _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 1))
+    ms = C.c_double()
 
     def barrier():
         torch.cuda.synchronize()
@@ -190,31 +231,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(17 + i)
-    barrier()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev0[i].record(stream)  # same stream the kernel is launched on
-        step(1000 + rank + 7919 * i)
-        ev1[i].record(stream)
-    barrier()
-    t_local = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    with ot.global_options.no_warnings():
+        for i in range(args.warmup):
+            RT.trace(N)
+        barrier()
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            RT.trace(N)  # synchronous like the reference's: returns when the rays and the counters are there
+            _capi.check(lib.ot_scene_last_trace_ms(RT._scene_handle, C.byref(ms)))  # events around the kernel
+            kernel_ms.append(ms.value)
+        barrier()
+        t_local = time.perf_counter() - t0
+    kernel_ms = float(np.mean(kernel_ms))
+    _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 0))
 
+    on_host = use_dist and backend != "nccl"  # collectives on host copies
     t = torch.tensor([t_local], dtype=torch.float64, device="cpu" if on_host else dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_max = float(t.item())
 
-    # ---- after the timed region: detector image + the one exchange step (histogram all-reduce) ----------
-    RT.rays.lock()
-    RT._last_trace_snapshot = RT.tracing_snapshot()
-    RT._msgs = msgs.cpu().numpy()[:-1].reshape(5, nt)
-    det_extent = [-45., 45., -45., 45.]
+    # ---- after the timed region: raw launches, detector image + the one exchange step (histogram all-reduce) ----
+    raw_ms = raw_launches(RT, lib, N, args.steps)
     with ot.global_options.no_warnings():
+        RT.trace(N)  # (the raw launches bypassed the tracer's bookkeeping)
+        det_extent = [-45., 45., -45., 45.]
         RT.detector_image(extent=det_extent, _keep_on_device=True)  # first call pays one-off table upload / lazy init
         torch.cuda.synchronize()
         td0 = time.perf_counter()
@@ -226,12 +268,7 @@ def main():
     if use_dist:
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
-        if on_host:
-            h = hist.cpu()
-            D.allreduce_image(h)
-            hist.copy_(h)
-        else:
-            D.allreduce_image(hist)  # the one exchange step: RCCL all-reduce of the (Ny, Nx, 4) f64 histogram
+        D.allreduce_image(hist)  # the one exchange step: all-reduce of the (Ny, Nx, 4) f64 histogram
         torch.cuda.synchronize()
         t_red = time.perf_counter() - tr0
         cnt = D.allreduce_counters(RT._msgs, device=None if on_host else dev)
@@ -240,13 +277,32 @@ def main():
 
     other = None
     if world == 1 and not args.no_pol:  # same scene without polarisation tracking, outside the timed region
-        other = secondary_no_pol(ot, scenes, lib, N, dev, args.steps)
+        other = secondary_no_pol(ot, scenes, lib, N, args.steps)
 
     if rank == 0:
         pol = not args.no_pol
         bytes_per_ray = nt * (48 if pol else 36) + 28  # compulsory RayStorage traffic of trace()
         b_trace = N * bytes_per_ray
         achieved = b_trace / (kernel_ms * 1e-3) / 1e9
+        pmc, pmc_file = committed_profile("trace_kernel_pmc.json", pol, N)
+        sq, sq_file = committed_profile("trace_kernel_sq.json", pol, N)
+        traffic = None
+        if pmc:  # FETCH_SIZE doubled: the gfx950 correction MI355X_MICROARCH.md prescribes; KB -> bytes
+            traffic = (2 * float(np.median(pmc["FETCH_SIZE"])) + float(np.median(pmc["WRITE_SIZE"]))) * 1024
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": None if pmc_file is None else f"{pmc_file} (rocprofv3 --pmc passes of this command, "
+                                                                   "not collected in this run)",
+                "kernel": "trace_kernel (ot_generate_and_trace_host inside Raytracer.trace)", "kernel_ms": kernel_ms,
+                "kernel_ms_source": "HIP events recorded by the library right around the kernel on its launch stream, "
+                                    "every timed step",
+                "algorithmic_bytes_per_launch": b_trace}
+        if sq and N == 10_000_000:
+            valu = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
+            rate = valu * (N / 64) / (kernel_ms * 1e-3)
+            roof.update({"valu_insts_per_wave": valu, "salu_insts_per_wave": sq["SQ_INSTS_SALU"] / sq["SQ_WAVES"],
+                         "valu_frac": rate / F64_ISSUE_PEAK, "valu_peak_wave_insts_per_s": F64_ISSUE_PEAK,
+                         "valu_source": f"{sq_file} (SQ_INSTS_VALU / SQ_WAVES); peak: profiles/r1/op_rate.txt"})
         out = {
             "metric": "ray-surface-intersections/s",
             "value": world * N * M * args.steps / t_max,
@@ -262,16 +318,19 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "double_gauss.py geometry (15 tracing surfaces, 5 point sources, FDC lines), "
-                                   f"{N} rays per GPU, polarisation {'on' if pol else 'off'}, on-device generation",
-                       "rays_per_gpu": N, "surfaces": M, "sections": nt, "parallelism": f"ray-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(pol, N),
-                         "kernel": "trace_kernel (ot_generate_and_trace)", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": b_trace},
+                                   f"{N} rays per GPU, polarisation {'on' if pol else 'off'}, Raytracer.trace(N) with "
+                                   "on-device generation",
+                       "rays_per_gpu": N, "surfaces": M, "sections": nt, "parallelism": f"ray-sharded x{world}",
+                       "backend": backend if use_dist else None,
+                       "ranks_per_device": -(-world // ndev)},
+            "roofline": roof,
+            "api_overhead_ms": 1e3 * t_local / args.steps - kernel_ms,
+            "raw_kernel": {"ms_per_launch": raw_ms, "value": N * M / (raw_ms * 1e-3),
+                           "what": "back-to-back asynchronous ot_generate_and_trace launches, no host work between"},
             "detector": {"rays_per_s": N / t_det, "ms": 1e3 * t_det, "allreduce_ms": 1e3 * t_red,
                          "image_power_all_ranks": total_power},
         }
-        if world == 1 and not args.no_pol:
+        if other is not None:
             out["no_pol"] = other  # BASELINE config C2 is quoted with polarisation on and off: the other setting
         if not args.skip_cpu and world == 1:  # CPU leg on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(RT, scene, args.cpu_seconds)

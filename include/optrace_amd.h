@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 3
+#define OT_ABI_VERSION 4
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -327,6 +327,21 @@ int ot_trace(const ot_scene* scene, const ot_rays* rays, const double* hurb_norm
 int ot_generate_and_trace(const ot_scene* scene, const ot_sources* src,
                           const ot_source_range* ranges, int32_t n_ranges, uint64_t seed,
                           const ot_rays* rays, int64_t* msgs, void* stream);
+
+/* Raytracer.trace (raytracer.py:262-415) as ONE synchronous call: ot_generate_and_trace, then the wait for
+ * `stream`; `msgs_host` (HOST memory, int64[5*nt + 1], layout as above) receives the counters of this
+ * launch alone (the reference builds a fresh msgs array per trace, raytracer.py:289).  The device writes them
+ * into a pinned buffer of the scene, so there is no device-to-host copy and no second synchronisation. */
+int ot_generate_and_trace_host(const ot_scene* scene, const ot_sources* src,
+                               const ot_source_range* ranges, int32_t n_ranges, uint64_t seed,
+                               const ot_rays* rays, int64_t* msgs_host, void* stream);
+
+/* Measurement aid (the reference times `RT.trace` with perf_counter, tests/benchmark.py:81-86): with timing
+ * on, every tracing launch of this scene records one HIP event right before and one right after the tracing
+ * kernel on the launch stream; ot_scene_last_trace_ms waits for the later one and returns the kernel's
+ * duration in milliseconds. */
+int ot_scene_set_timing(ot_scene* scene, int32_t on);
+int ot_scene_last_trace_ms(const ot_scene* scene, double* ms);
 
 /* ---- leaf operators (public Surface / RefractionIndex methods) ---------------------------------- */
 /* Surface.find_hit (surface.py:307, conic_surface.py:126): p, s are (n,3) F-order device arrays;

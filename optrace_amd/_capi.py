@@ -127,6 +127,9 @@ SIGNATURES = {
     "ot_rays_generate": (C.c_int, [vp, C.POINTER(SourceRange), i32, u64, i32, C.POINTER(Rays), vp]),
     "ot_trace": (C.c_int, [vp, C.POINTER(Rays), vp, u64, vp, vp]),
     "ot_generate_and_trace": (C.c_int, [vp, vp, C.POINTER(SourceRange), i32, u64, C.POINTER(Rays), vp, vp]),
+    "ot_generate_and_trace_host": (C.c_int, [vp, vp, C.POINTER(SourceRange), i32, u64, C.POINTER(Rays), vp, vp]),
+    "ot_scene_set_timing": (C.c_int, [vp, i32]),
+    "ot_scene_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "ot_surface_find_hit": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp, vp, vp]),
     "ot_surface_normals": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp]),
     "ot_surface_mask": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp]),
@@ -147,7 +150,7 @@ SIGNATURES = {
 }
 
 FOCUS_WS = 16  # OT_FOCUS_WS
-ABI_VERSION = 3  # OT_ABI_VERSION
+ABI_VERSION = 4  # OT_ABI_VERSION
 
 _lib = None
 

@@ -9,16 +9,26 @@ import torch
 from . import _capi
 
 
+_devices: dict = {}  # index -> torch.device, filled once a device has been seen (these run once per trace)
+
+
 def require_device() -> torch.device:
     """cuda:<current> or a loud failure -- the product path has no CPU fallback."""
-    if not torch.cuda.is_available():
-        raise _capi.BackendError("No HIP device available (torch.cuda.is_available() is False); "
-                                 "optrace_amd has no CPU fallback.")
-    return torch.device("cuda", torch.cuda.current_device())
+    if not _devices:
+        if not torch.cuda.is_available():
+            raise _capi.BackendError("No HIP device available (torch.cuda.is_available() is False); "
+                                     "optrace_amd has no CPU fallback.")
+        torch.cuda.current_device()  # initialises torch's HIP state
+    i = torch._C._cuda_getDevice()
+    d = _devices.get(i)
+    if d is None:
+        d = _devices[i] = torch.device("cuda", i)
+    return d
 
 
 def stream_ptr() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The raw hipStream_t of torch's current stream on the current device."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def ptr(t: torch.Tensor | None) -> C.c_void_p:

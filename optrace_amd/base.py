@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import copy
+import zlib
 from typing import Any
 
 import numpy as np
@@ -35,8 +36,38 @@ def check_in(key: str, val, choices) -> None:
         raise ValueError(f"Property '{key}' needs to be one of {choices}, but is '{val}'.")
 
 
+_EPOCH = [0]
+_SAW_WRITEABLE = [False]  # set by crepr when it meets a large array that can still be edited in place
+
+
+def mutation_epoch() -> int:
+    """Counts attribute assignments on tracked objects (everything a trace depends on is a BaseClass whose arrays
+    are read-only and whose state changes only through `__setattr__`).  While it stands still, nothing a
+    Raytracer compiled or checked can have changed, so `Raytracer.trace` may skip its snapshot comparison."""
+    return _EPOCH[0]
+
+
+def touch() -> None:
+    """Record a state change that does not pass through `__setattr__` (list edits of a Group)."""
+    _EPOCH[0] += 1
+
+
+def _array_token(a: np.ndarray) -> tuple:
+    """Identity of a large array for change detection.  The reference keeps `id(array)` (base_class.py:40-48); an id
+    alone is reused once the old array is freed and says nothing about in-place edits, so the token also carries the
+    shape and a content checksum: of everything while the array is writeable, of 64 evenly spread elements once it is
+    locked read-only (its content cannot change any more, the samples only tell a recycled id apart)."""
+    if a.flags.writeable:
+        _SAW_WRITEABLE[0] = True
+    flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
+    part = flat if a.flags.writeable else flat[::max(1, flat.shape[0] // 64)]
+    return id(a), a.shape, zlib.crc32(np.ascontiguousarray(part).view(np.uint8)) if part.dtype != object else 0
+
+
 class BaseClass:
     """Description strings, copy, read-only locking and a compact state representation."""
+
+    _tracked = True  #: False for result containers (ray storage, images): their attributes never feed a trace
 
     def __init__(self, desc: str = "", long_desc: str = "") -> None:
         self._lock = False
@@ -51,7 +82,7 @@ class BaseClass:
             if isinstance(val, BaseClass):
                 out.append(val.crepr())
             elif isinstance(val, np.ndarray):
-                out.append(tuple(val.flat) if val.size < 20 else id(val))
+                out.append(tuple(val.flat) if val.size < 20 else _array_token(val))
             elif callable(val):
                 out.append(id(val))
             elif isinstance(val, list):
@@ -92,3 +123,5 @@ class BaseClass:
         if key in ("desc", "long_desc"):
             check_type(key, val, str)
         self.__dict__[key] = val
+        if self._tracked:
+            _EPOCH[0] += 1

@@ -437,7 +437,33 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
 extern "C" void ot_scene_destroy(ot_scene* sc) {
     if (!sc) return;
     (void)hipFree(sc->blob);
+    if (sc->pin_msgs) (void)hipHostFree(sc->pin_msgs);
+    if (sc->ev0) (void)hipEventDestroy(sc->ev0);
+    if (sc->ev1) (void)hipEventDestroy(sc->ev1);
     delete sc;
+}
+
+// Kernel timing for measurements (bench.py): with timing on, every trace launch is bracketed by two events on its
+// own stream, recorded right before and right after the tracing kernel (the counter reduction stays outside).
+extern "C" int ot_scene_set_timing(ot_scene* sc, int32_t on) {
+    if (!sc) return fail(OT_ERR_INVALID, "ot_scene_set_timing: null scene");
+    if (on && !sc->ev0) {
+        HIP_TRY(hipEventCreate(&sc->ev0));
+        HIP_TRY(hipEventCreate(&sc->ev1));
+    }
+    sc->timing = on != 0;
+    sc->ev_valid = false;
+    return OT_OK;
+}
+
+extern "C" int ot_scene_last_trace_ms(const ot_scene* sc, double* ms) {
+    if (!sc || !ms) return fail(OT_ERR_INVALID, "ot_scene_last_trace_ms: null argument");
+    if (!sc->ev_valid) return fail(OT_ERR_INVALID, "no timed trace launch on this scene (ot_scene_set_timing)");
+    HIP_TRY(hipEventSynchronize(sc->ev1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, sc->ev0, sc->ev1));
+    *ms = (double)t;
+    return OT_OK;
 }
 
 extern "C" int ot_scene_sections(const ot_scene* sc) { return sc ? sc->h.nt : OT_ERR_INVALID; }
@@ -675,8 +701,11 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
     return OT_OK;
 }
 
+static void drop_range_cache(ot_sources* s);
+
 extern "C" void ot_sources_destroy(ot_sources* s) {
     if (!s) return;
+    drop_range_cache(s);
     (void)hipFree(s->blob);
     delete[] s->n_or;
     delete[] s->power;
@@ -813,11 +842,14 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
 //        2: + surfaces that need the numeric hit search: aspheres, tilted, spline surfaces (206)
 // Event counters go wave -> LDS (per workgroup) -> one of OT_CNT_SLOTS global slot tables (blockIdx % slots) ->
 // reduce_counters_kernel, so that no two workgroups hammer the same address (see count_event).
+// The launch covers the rays [ray_base, ray_base + count) of the bundle; R's pointers are advanced to ray_base by
+// the host (R.N stays the plane stride), so lanes address their ray with a 32-bit offset (count <= 2^28).
 template <bool POL, bool GEN, int SPEC, int FEAT>
 __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
                                                     const SourceDev* __restrict__ sources, RangeArgs rg,
                                                     const double* __restrict__ hurb_normals, uint64_t seed,
-                                                    unsigned int* __restrict__ slots) {
+                                                    unsigned int* __restrict__ slots, int64_t ray_base,
+                                                    uint32_t count) {
     extern __shared__ double lds[];  // [discrete-spectrum table (SPEC == 2)] [event counters + timeout flag]
     auto& sc = *as_const(scp);
     const int n_tab = (SPEC == 2) ? (3 * sc.n_steps + 2) * OT_MAX_LINES : 0;
@@ -829,8 +861,9 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
         for (int k = threadIdx.x; k < n_tab; k += blockDim.x) ltab[k] = sc.line_tab[k];
     __syncthreads();
 
-    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool have = ray < R.N;
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ray = ray_base + (int64_t)local;
+    bool have = local < count;
     RayState r;
     if (have) {
         if (GEN) {
@@ -844,23 +877,23 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
                 r.polx = (float)nr.polx;
                 r.poly = (float)nr.poly;
                 r.polz = (float)nr.polz;
-                R.wl[ray] = r.wl;
+                R.wl[local] = r.wl;
             }
         } else {
             const int64_t N = R.N, nt = R.nt;
-            r.p.x = R.p[ray];
-            r.p.y = R.p[ray + N * nt];
-            r.p.z = R.p[ray + N * 2 * nt];
-            r.s.x = R.s[ray];
-            r.s.y = R.s[ray + N];
-            r.s.z = R.s[ray + 2 * N];
-            r.w = R.w[ray];
-            r.wl = R.wl[ray];
+            r.p.x = R.p[local];
+            r.p.y = R.p[local + N * nt];
+            r.p.z = R.p[local + N * 2 * nt];
+            r.s.x = R.s[local];
+            r.s.y = R.s[local + N];
+            r.s.z = R.s[local + 2 * N];
+            r.w = R.w[local];
+            r.wl = R.wl[local];
             r.polx = r.poly = r.polz = 0.f;
             if (POL) {
-                r.polx = R.pol[ray];
-                r.poly = R.pol[ray + N * nt];
-                r.polz = R.pol[ray + N * 2 * nt];
+                r.polx = R.pol[local];
+                r.poly = R.pol[local + N * nt];
+                r.polz = R.pol[local + N * 2 * nt];
             }
         }
     }
@@ -868,7 +901,12 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
     // counter (HURB_NEG_DIR, section 0), a cell no tracing event can touch; the host turns it into that error.
     if (GEN) count_event(cnt, sc.nt, OT_INFO_HURB_NEG_DIR, 0, have && !(r.s.z > 0));
     if (have) {
-        bool ok = trace_ray<POL, SPEC, FEAT>(sc, R, (uint32_t)ray, r, hurb_normals, seed, cnt, ltab);
+        int lj = 0;  // discrete spectra: which line this ray carries
+        if (SPEC == 2) {
+            for (int j = 1; j < sc.n_lines; j++)
+                if ((float)ltab[j] == r.wl) lj = j;
+        }
+        bool ok = trace_ray<POL, SPEC, FEAT>(sc, R, local, (uint64_t)ray, r, hurb_normals, seed, cnt, ltab, lj);
         if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)
     }
     __syncthreads();
@@ -879,6 +917,7 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
 
 // sums the slot tables into the caller's int64 counters (ADD) and clears them for the next launch:
 // one workgroup per counter, one lane per 4 slots, wave shuffle + LDS reduction
+template <bool ACCUM>  // ACCUM: add to the caller's counters; otherwise overwrite them (pinned host buffer: no read over PCIe)
 __global__ __launch_bounds__(256) void reduce_counters_kernel(unsigned int* __restrict__ slots, int n_cnt,
                                                               unsigned long long* __restrict__ msgs) {
     __shared__ unsigned long long part[4];
@@ -897,7 +936,9 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(unsigned int* __re
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long t = part[0] + part[1] + part[2] + part[3];
-        if (t) {
+        if (!ACCUM) {
+            msgs[k] = (k == n_cnt - 1) ? (t ? 1ull : 0ull) : t;
+        } else if (t) {
             if (k == n_cnt - 1) msgs[k] = 1ull; else msgs[k] += t;
         }
     }
@@ -997,13 +1038,38 @@ __global__ __launch_bounds__(256) void refraction_index_kernel(ot_medium md, con
 // ---------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
-// Fills the kernel argument block; with more than OT_MAX_RANGES ranges the records go to device memory
-// (`ext_out`, to be released with release_ranges after the launch has been enqueued).
-static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot_sources* src, int64_t N, RangeArgs& rg,
-                       RangeRec** ext_out) {
-    *ext_out = nullptr;
-    rg.ext = nullptr;
+// What make_ranges derived from the last range list of a source table.  Chunked rendering and repeated traces
+// pass the same list again and again: the argument block is reused, and for long lists so is the device copy of
+// the records -- no allocation, no upload and no stream synchronisation on the launch path.
+struct RangeCache {
+    std::vector<ot_source_range> key;
+    int64_t N = -1;
+    RangeArgs rg;
+    RangeRec* ext = nullptr;  // device records (n > OT_MAX_RANGES), owned by the cache
+};
+
+static void drop_range_cache(ot_sources* s) {
+    if (!s->rcache) return;
+    if (s->rcache->ext) (void)hipFree(s->rcache->ext);  // hipFree waits for work that may still read the records
+    delete s->rcache;
+    s->rcache = nullptr;
+}
+
+// Fills the kernel argument block; with more than OT_MAX_RANGES ranges the records go to device memory (kept in
+// the source table's cache until a different list arrives).
+static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot_sources* src_c, int64_t N,
+                       const RangeArgs** out) {
+    ot_sources* src = const_cast<ot_sources*>(src_c);
     if (!ranges || n_ranges < 1) return fail(OT_ERR_INVALID, "at least one source range is needed");
+    if (RangeCache* c = src->rcache) {
+        if (c->N == N && (int32_t)c->key.size() == n_ranges &&
+            std::memcmp(c->key.data(), ranges, sizeof(ot_source_range) * (size_t)n_ranges) == 0) {
+            *out = &c->rg;
+            return OT_OK;
+        }
+    }
+    RangeArgs rg;
+    rg.ext = nullptr;
     rg.n = n_ranges;
     const bool big = n_ranges > OT_MAX_RANGES;
     std::vector<RangeRec> recs(big ? n_ranges : 0);
@@ -1045,8 +1111,8 @@ static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot
         covered += ranges[k].count;
     }
     if (covered != N) return fail(OT_ERR_INVALID, "source ranges must cover all N rays exactly once");
+    RangeRec* d = nullptr;
     if (big) {
-        RangeRec* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, sizeof(RangeRec) * recs.size()));
         hipError_t e = hipMemcpy(d, recs.data(), sizeof(RangeRec) * recs.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -1054,15 +1120,16 @@ static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot
             return fail(OT_ERR_HIP, std::string("range upload: ") + hipGetErrorString(e));
         }
         rg.ext = d;
-        *ext_out = d;
     }
+    drop_range_cache(src);  // the previous list (its device records are no longer needed by any new launch)
+    RangeCache* c = new RangeCache;
+    c->key.assign(ranges, ranges + n_ranges);
+    c->N = N;
+    c->rg = rg;
+    c->ext = d;
+    src->rcache = c;
+    *out = &c->rg;
     return OT_OK;
-}
-
-static void release_ranges(RangeRec* ext, hipStream_t st) {
-    if (!ext) return;
-    (void)hipStreamSynchronize(st);  // the launch that reads the records has to finish first
-    (void)hipFree(ext);
 }
 
 static int check_rays(const ot_rays* r, bool need_pol) {
@@ -1076,9 +1143,9 @@ extern "C" int ot_rays_generate(const ot_sources* src, const ot_source_range* ra
                                 int32_t no_pol, const ot_rays* rays, void* stream) {
     if (!src) return fail(OT_ERR_INVALID, "ot_rays_generate: null sources");
     if (int rc = check_rays(rays, !no_pol)) return rc;
-    RangeArgs rg;
-    RangeRec* ext = nullptr;
-    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg, &ext)) return rc;
+    const RangeArgs* rgp = nullptr;
+    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, &rgp)) return rc;
+    const RangeArgs& rg = *rgp;
     hipStream_t st = (hipStream_t)stream;
     if (rays->N > 0) {
         if (no_pol)
@@ -1086,20 +1153,30 @@ extern "C" int ot_rays_generate(const ot_sources* src, const ot_source_range* ra
         else
             hipLaunchKernelGGL(generate_kernel<true>, grid_for(rays->N), dim3(256), 0, st, *rays, src->d, rg, seed);
     }
-    release_ranges(ext, st);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }
 
-static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeArgs* rg, const ot_rays* rays,
+// msgs: device counters the launch ADDS to, or nullptr: the counters of this launch alone go to the scene's pinned
+// host buffer (created on first use)
+static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const RangeArgs* rg, const ot_rays* rays,
                         const double* hurb_normals, uint64_t seed, int64_t* msgs, void* stream) {
-    if (!sc || !msgs) return fail(OT_ERR_INVALID, "ot_trace: null argument");
+    ot_scene* sc = const_cast<ot_scene*>(sc_c);
+    if (!sc) return fail(OT_ERR_INVALID, "ot_trace: null argument");
     bool pol = !sc->h.no_pol;
     if (int rc = check_rays(rays, pol)) return rc;
-    if (rays->N >= (1ll << 32)) return fail(OT_ERR_UNSUPPORTED, "at most 2^32 - 1 rays per launch (32-bit ray index); split the bundle");
     if (rays->nt != sc->h.nt) return fail(OT_ERR_INVALID, "ray storage has " + std::to_string(rays->nt) +
                                                              " sections, the scene needs " + std::to_string(sc->h.nt));
-    if (rays->N == 0) return OT_OK;
+    const int n_cnt = OT_N_INFOS * sc->h.nt + 1;
+    if (!msgs && !sc->pin_msgs) {
+        HIP_TRY(hipHostMalloc((void**)&sc->pin_msgs, sizeof(unsigned long long) * (size_t)n_cnt,
+                              hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(sc->pin_msgs, 0, sizeof(unsigned long long) * (size_t)n_cnt);
+    }
+    if (rays->N == 0) {
+        if (!msgs) std::memset(sc->pin_msgs, 0, sizeof(unsigned long long) * (size_t)n_cnt);
+        return OT_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     RangeArgs none;
     none.n = 0;
@@ -1107,17 +1184,26 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     const RangeArgs& r = rg ? *rg : none;
     const SourceDev* sd = src ? src->d : nullptr;
     unsigned long long* m = (unsigned long long*)msgs;
-    dim3 grid = grid_for(rays->N), block(256);
+    if (!msgs) HIP_TRY(hipHostGetDevicePointer((void**)&m, sc->pin_msgs, 0));
+    dim3 block(256);
     // kernel variant: polarisation x on-device generation x spectrum handling x feature set
     const bool tab = sc->needs_tables || hurb_normals != nullptr;
     const int feat = sc->needs_numeric ? 2 : (sc->needs_full ? 1 : 0);
     const bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr;  // generated rays only
-    const int n_cnt = OT_N_INFOS * sc->h.nt + 1;
     const size_t lds = sizeof(unsigned int) * (size_t)n_cnt +
                        (lines ? sizeof(double) * (size_t)(3 * sc->h.n_steps + 2) * OT_MAX_LINES : 0) + 8;
     unsigned int* slots = sc->cnt_slots;
+    if (sc->timing) HIP_TRY(hipEventRecord(sc->ev0, st));
+    // lanes address their ray with 32-bit byte offsets: launches of at most 2^28 rays, base pointers advanced
+    const int64_t chunk = 1ll << 28;
+    for (int64_t base = 0; base < rays->N; base += chunk) {
+    const uint32_t count = (uint32_t)std::min<int64_t>(chunk, rays->N - base);
+    const dim3 grid = grid_for(count);
+    ot_rays part = *rays;
+    part.p += base; part.s += base; part.w += base; part.n += base; part.wl += base;
+    if (part.pol) part.pol += base;
 #define OT_LAUNCH(P, G, S, F) \
-    hipLaunchKernelGGL((trace_kernel<P, G, S, F>), grid, block, lds, st, sc->d, *rays, sd, r, hurb_normals, seed, slots)
+    hipLaunchKernelGGL((trace_kernel<P, G, S, F>), grid, block, lds, st, sc->d, part, sd, r, hurb_normals, seed, slots, base, count)
 #define OT_LAUNCH_F(P, G, S) do { if (feat == 2) OT_LAUNCH(P, G, S, 2); else if (feat == 1) OT_LAUNCH(P, G, S, 1); else OT_LAUNCH(P, G, S, 0); } while (0)
     if (src) {
         if (lines)    { if (pol) OT_LAUNCH_F(true, true, 2); else OT_LAUNCH_F(false, true, 2); }
@@ -1129,26 +1215,47 @@ static int launch_trace(const ot_scene* sc, const ot_sources* src, const RangeAr
     }
 #undef OT_LAUNCH_F
 #undef OT_LAUNCH
+    }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(reduce_counters_kernel, dim3(n_cnt), dim3(256), 0, st, slots, n_cnt, m);
+    if (sc->timing) {
+        HIP_TRY(hipEventRecord(sc->ev1, st));
+        sc->ev_valid = true;
+    }
+    if (msgs)
+        hipLaunchKernelGGL(reduce_counters_kernel<true>, dim3(n_cnt), dim3(256), 0, st, slots, n_cnt, m);
+    else
+        hipLaunchKernelGGL(reduce_counters_kernel<false>, dim3(n_cnt), dim3(256), 0, st, slots, n_cnt, m);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }
 
 extern "C" int ot_trace(const ot_scene* scene, const ot_rays* rays, const double* hurb_normals, uint64_t seed,
                         int64_t* msgs, void* stream) {
+    if (!msgs) return fail(OT_ERR_INVALID, "ot_trace: null argument");
     return launch_trace(scene, nullptr, nullptr, rays, hurb_normals, seed, msgs, stream);
 }
 
 extern "C" int ot_generate_and_trace(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,
                                      int32_t n_ranges, uint64_t seed, const ot_rays* rays, int64_t* msgs, void* stream) {
-    if (!src || !rays) return fail(OT_ERR_INVALID, "ot_generate_and_trace: null argument");
-    RangeArgs rg;
-    RangeRec* ext = nullptr;
-    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, rg, &ext)) return rc;
-    const int rc = launch_trace(scene, src, &rg, rays, nullptr, seed, msgs, stream);
-    release_ranges(ext, (hipStream_t)stream);
-    return rc;
+    if (!src || !rays || !msgs) return fail(OT_ERR_INVALID, "ot_generate_and_trace: null argument");
+    const RangeArgs* rg = nullptr;
+    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, &rg)) return rc;
+    return launch_trace(scene, src, rg, rays, nullptr, seed, msgs, stream);
+}
+
+// The whole of Raytracer.trace in one synchronous call: launch, wait, counters of this launch in host memory.
+// The counter reduction writes into a pinned host buffer of the scene, so the wait for the stream is the only
+// synchronisation and nothing is copied back.
+extern "C" int ot_generate_and_trace_host(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,
+                                          int32_t n_ranges, uint64_t seed, const ot_rays* rays, int64_t* msgs_host,
+                                          void* stream) {
+    if (!scene || !src || !rays || !msgs_host) return fail(OT_ERR_INVALID, "ot_generate_and_trace_host: null argument");
+    const RangeArgs* rg = nullptr;
+    if (int rc = make_ranges(ranges, n_ranges, src, rays->N, &rg)) return rc;
+    if (int rc = launch_trace(scene, src, rg, rays, nullptr, seed, nullptr, stream)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::memcpy(msgs_host, scene->pin_msgs, sizeof(int64_t) * (size_t)(OT_N_INFOS * scene->h.nt + 1));
+    return OT_OK;
 }
 
 // ---- leaf entry points -------------------------------------------------------------------------------------

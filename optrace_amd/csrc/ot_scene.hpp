@@ -7,6 +7,7 @@
 // read through wave-uniform (scalar, SGPR) loads: every lane of a wavefront is at the same element of the
 // same scene, so a scalar broadcast beats an LDS copy (no LDS traffic, no bank conflicts, no barrier).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/optrace_amd.h"
@@ -94,6 +95,13 @@ struct ot_scene {
     bool needs_full;   // ideal lenses, filters or HURB present: feature level 1 of the kernel variants
     bool needs_numeric; // aspheric / tilted / spline surfaces present: level 2 (numeric hit search)
     bool needs_tables; // some medium / filter is tabulated (DATA / LINES): per-lane global loads in the loop
+    // synchronous entry points (ot_generate_and_trace_host): the counter reduction writes straight into this pinned,
+    // device-mapped host buffer (5*nt + 1 words), so a trace costs one wait and no device-to-host copy
+    unsigned long long* pin_msgs = nullptr;
+    // optional kernel timing (ot_scene_set_timing): events on the launch stream right around the trace kernel
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
 };
 
 // ---- sources -------------------------------------------------------------------------------------------
@@ -145,6 +153,7 @@ struct ot_sources {
     int device;
     int64_t* n_or;  // host, per source: rays a range of this source must hold (OR_ARRAY with an array), else -1
     double* power;  // host, per source
+    struct RangeCache* rcache = nullptr;  // the last range list seen by make_ranges and what was derived from it
 };
 
 #define OT_PRIM_N 5000

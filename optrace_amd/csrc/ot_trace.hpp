@@ -243,32 +243,39 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
     return neg;
 }
 
-// One section of one ray.  The plane base addresses (array + N * plane) are wave-uniform and stay in SGPRs;
-// the lane contributes a 32-bit element index, so every store is `global_store ... v_offset, s[base]` with no
-// per-lane 64-bit address arithmetic (35 -> 8 instructions per section).  The ray index is 32 bits wide: N < 2^32
-// (checked by the host entry points).
+// Stores with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: `global_store ... v_off, v_data,
+// s[base]`.  Written as inline assembly because the compiler otherwise keeps one 64-bit VGPR address per stored plane
+// and advances each of them every section (9 v_lshl_add_u64 per section: 3.5 % of the loop's vector instructions).
+OT_DEV void store_f64(const void* base, uint32_t off, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
+}
+OT_DEV void store_f32(const void* base, uint32_t off, float v) {
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
+}
+
+// One section of one ray.  The plane base addresses (array + N * plane) are wave-uniform and stay in SGPRs; the
+// lane contributes the byte offsets of its ray in an f64 plane (`o8` = 8 * index) and in an f32 plane (`o4`),
+// formed once per ray.  The offsets are 32 bits wide: a launch covers at most 2^28 rays (the host entry points
+// split longer bundles and advance the base pointers).
 template <bool POL>
-OT_DEV void store_section(const ot_rays& R, uint32_t ray, int sec, const V3& p, float w, double n, float px, float py,
-                          float pz) {
-    // Measured alternatives on the bench scene: a workgroup-relative form (SGPR base + threadIdx offset, no
-    // 64-bit vector address add) was 4 % slower (1.93 vs 1.86 ms); a wave-tiled layout ([tile of 64 rays]
-    // [section][component][lane] inside each array) made no difference (1.750 vs 1.755 ms) although it wins in
-    // the store-only experiment (tools/experiments/store_pattern.hip) -- so the reference's planar Fortran layout
-    // stays, and host views need no re-ordering.
+OT_DEV void store_section(const ot_rays& R, uint32_t o8, uint32_t o4, int sec, const V3& p, float w, double n, float px,
+                          float py, float pz) {
+    // Measured alternatives on the bench scene: a workgroup-relative form (SGPR base + threadIdx offset with 64-bit
+    // vector adds) was 4 % slower (1.93 vs 1.86 ms); a wave-tiled layout ([tile of 64 rays][section][component][lane]
+    // inside each array) made no difference (1.750 vs 1.755 ms) although it wins in the store-only experiment
+    // (tools/experiments/store_pattern.hip) -- so the reference's planar Fortran layout stays, and host views need
+    // no re-ordering.
     const int64_t N = R.N;
     const int64_t nt = R.nt;
-    double* __restrict__ p0 = R.p + N * sec;
-    double* __restrict__ p1 = R.p + N * (sec + nt);
-    double* __restrict__ p2 = R.p + N * (sec + 2 * nt);
-    p0[ray] = p.x;
-    p1[ray] = p.y;
-    p2[ray] = p.z;
-    (R.w + N * sec)[ray] = w;
-    (R.n + N * sec)[ray] = n;
+    store_f64(R.p + N * sec, o8, p.x);
+    store_f64(R.p + N * (sec + nt), o8, p.y);
+    store_f64(R.p + N * (sec + 2 * nt), o8, p.z);
+    store_f32(R.w + N * sec, o4, w);
+    store_f64(R.n + N * sec, o8, n);
     if (POL) {
-        (R.pol + N * sec)[ray] = px;
-        (R.pol + N * (sec + nt))[ray] = py;
-        (R.pol + N * (sec + 2 * nt))[ray] = pz;
+        store_f32(R.pol + N * sec, o4, px);
+        store_f32(R.pol + N * (sec + nt), o4, py);
+        store_f32(R.pol + N * (sec + 2 * nt), o4, pz);
     }
 }
 
@@ -281,18 +288,18 @@ OT_DEV void store_section(const ot_rays& R, uint32_t ray, int sec, const V3& p, 
 //   2  discrete spectrum: n, n1/n2 and filter T of every step were tabulated per line on the host and staged in
 //      LDS (`ltab`); the lane only carries its line index.  Saves the IEEE division n1/n2 and the dispersion
 //      formula per ray-surface and covers "Function" media exactly.
+// `local` = index of the ray in this launch (R's pointers start at the launch's first ray), `ray` = its index in the
+// whole bundle (random-number keys, injected HURB normals).
 template <bool POL, int SPEC, int FEAT, class SC>
-OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const double* __restrict__ hurb_normals,
-                      uint64_t seed, unsigned int* msgs, const double* ltab) {
+OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, RayState& r,
+                      const double* __restrict__ hurb_normals, uint64_t seed, unsigned int* msgs, const double* ltab,
+                      int lj) {
     constexpr bool TAB = (SPEC == 1);
     constexpr bool FULL = FEAT >= 1;     // ideal lenses, filters, HURB
     constexpr bool NUMERIC = FEAT >= 2;  // surfaces that need the Illinois search (aspheres, tilted, spline)
-    int lj = 0;  // line index of this ray (SPEC == 2)
-    if (SPEC == 2) {
-        for (int j = 1; j < sc.n_lines; j++)
-            if ((float)ltab[j] == r.wl) lj = j;
-    }
+    // lj = line index of this ray (SPEC == 2), straight from the generator
     const double* lrow = ltab + OT_MAX_LINES + lj;  // row 0 of this lane's column
+    const uint32_t o8 = local * 8u, o4 = local * 4u;
     const int nt = sc.nt;
     const auto surfaces = as_const(sc.surfaces);
     const auto steps = as_const(sc.steps);
@@ -301,7 +308,7 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
     const auto pool = as_const(sc.pool);
     bool ok = true;
     r.n_cur = (SPEC == 2) ? lrow[(3 * sc.n_steps) * OT_MAX_LINES] : medium_n<TAB>(media[sc.n0], pool, r.wl);
-    store_section<POL>(R, ray, 0, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+    store_section<POL>(R, o8, o4, 0, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
 
     for (int i = 0; i < sc.n_steps; i++) {  // i = index of the section the ray starts this step in
         auto& st = steps[i];
@@ -327,7 +334,6 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
                 wn = 0.f;
                 if (kind == OT_STEP_LENS_BACK) pn = r.p;  // absorbed at the front surface, raytracer.py:354
             }
-            count_event(msgs, nt, OT_INFO_ABSORB_MISSING, i + 1, hwnh);
             double Nq;
             if (SPEC == 2) {
                 n_next = lrow[(3 * i + 0) * OT_MAX_LINES];
@@ -342,7 +348,6 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
                 else
                     tir = refract<POL, NUMERIC>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq);
             }
-            count_event(msgs, nt, OT_INFO_TIR, i, tir);
         } else if (FULL && kind == OT_STEP_FILTER) {  // raytracer.py:379-380
             if (hwh) {
                 double T = (SPEC == 2) ? lrow[(3 * i + 2) * OT_MAX_LINES] : filter_T<TAB>(filters[st.filter], pool, r.wl);
@@ -356,7 +361,7 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
                     za = (hurb_normals + (2 * (int64_t)st.hurb_slot + 0) * R.N)[ray];
                     zb = (hurb_normals + (2 * (int64_t)st.hurb_slot + 1) * R.N)[ray];
                 } else {
-                    philox_normal2(seed, (uint64_t)ray, 0x48555242u, (uint32_t)st.hurb_slot, za, zb);
+                    philox_normal2(seed, ray, 0x48555242u, (uint32_t)st.hurb_slot, za, zb);
                 }
                 neg = hurb_bend<POL>(sc, sf, r, pn, wn, npx, npy, npz, hwnh, za, zb);
             }
@@ -364,7 +369,15 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
         }
         // rays that missed the surface may leave the outline box on their way (raytracer.py:338, 367, 389)
         if (hwnh) clip = outline_clip(sc.outline, r.p, r.s, pn, wn);
-        count_event(msgs, nt, OT_INFO_OUTLINE_INTERSECTION, i, clip);
+        // the rare events of a step are counted behind one wave-wide test (a surface that every ray of the wave hits
+        // and passes has none)
+        if (__ballot(hwnh || tir) != 0ull) {
+            if (kind <= OT_STEP_IDEAL) {
+                count_event(msgs, nt, OT_INFO_ABSORB_MISSING, i + 1, hwnh);
+                count_event(msgs, nt, OT_INFO_TIR, i, tir);
+            }
+            count_event(msgs, nt, OT_INFO_OUTLINE_INTERSECTION, i, clip);
+        }
 
         r.p = pn;
         r.w = wn;
@@ -372,11 +385,11 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t ray, RayState& r, const
         r.poly = npy;
         r.polz = npz;
         r.n_cur = n_next;
-        store_section<POL>(R, ray, i + 1, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+        store_section<POL>(R, o8, o4, i + 1, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
     }
     const int64_t N = R.N;
-    R.s[ray] = r.s.x;
-    (R.s + N)[ray] = r.s.y;
-    (R.s + 2 * N)[ray] = r.s.z;
+    store_f64(R.s, o8, r.s.x);
+    store_f64(R.s + N, o8, r.s.y);
+    store_f64(R.s + 2 * N, o8, r.s.z);
     return ok;
 }

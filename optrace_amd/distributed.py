@@ -61,9 +61,21 @@ def shard_source_powers(N: int, powers: list[float], rank: int, world_size: int,
     return counts, shard_p
 
 
+def _device_collectives() -> bool:
+    """True when the process group reduces device tensors in place (nccl = RCCL).  Any other backend (gloo in the
+    tests and in rehearsals where several ranks share a device) reduces host copies."""
+    return dist.get_backend() == "nccl"
+
+
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     """In-place sum over all ranks (no-op without a process group)."""
-    if dist.is_available() and dist.is_initialized():
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    if t.is_cuda and not _device_collectives():
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -73,6 +85,7 @@ def allreduce_extent(ext4: np.ndarray, device=None) -> np.ndarray:
     Ranks without hits pass [+inf, -inf, +inf, -inf]."""
     if world()[1] == 1:
         return ext4
+    device = device if _device_collectives() else None
     lo = torch.tensor([ext4[0], ext4[2]], dtype=torch.float64, device=device)
     hi = torch.tensor([ext4[1], ext4[3]], dtype=torch.float64, device=device)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -92,6 +105,7 @@ def allreduce_counters(msgs: np.ndarray, device=None) -> np.ndarray:
     """Sum the (5, nt) event counters of all ranks (Raytracer._set_messages raytracer.py:181-190)."""
     if world()[1] == 1:
         return msgs
+    device = device if _device_collectives() else None
     t = torch.as_tensor(np.ascontiguousarray(msgs, dtype=np.int64), device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy().astype(int)
@@ -101,31 +115,31 @@ def sharded_detector_image(RT, N: int, detector_index: int = 0, extent=None, pro
                            base_seed: int = 0):
     """Trace this rank's shard of N rays and return the all-reduced detector image (identical on every rank).
 
-    Each rank traces `shard_range(N, rank, world)` rays with seed `base_seed + rank`; source powers are scaled to
-    the shard so that the summed image carries the full source power.
+    Each rank traces `shard_range(N, rank, world)` rays with seed `base_seed + rank`; its rays carry the shard's share
+    of the source powers (`ray_storage.py:160`: a thread's rays carry `n_thread / N_source` of the power), so the
+    summed image carries the full source power.  `RT._msgs` becomes the sum over all ranks.  With an automatic extent
+    the ranks first agree on the common one (raytracer.py:1042-1046); if no ray of any rank reaches the detector it
+    collapses to the detector centre like the reference's (raytracer.py:1048-1049).
     """
     from . import global_options
     rank, ws = world()
     first, end = shard_range(N, rank, ws)
     n_local = end - first
-    scale = n_local / N
-    old = [(rs, rs.power) for rs in RT.ray_sources]
+    seed0 = RT.seed
     RT.seed = base_seed + rank
     try:
-        for rs, p in old:
-            rs.power = p * scale
-        RT.trace(n_local)
+        RT.trace(n_local, _power_scale=n_local / N)
     finally:
-        for rs, p in old:
-            rs.power = p
-    RT._last_trace_snapshot = RT.tracing_snapshot()
+        RT.seed = seed0
     dev = RT.rays._dev["p"].device
+    det = RT.detectors[detector_index]
     if extent is None:
         # agree on the automatic extent first (two-pass: hit search, min/max exchange, then binning)
         ph, hw, wl, ext, proj, ill = RT._hit_detector("Detector Image", detector_index, None, None, projection_method)
         has = bool((hw > 0).any().item())
         e = ext if has else np.array([np.inf, -np.inf, np.inf, -np.inf])
-        extent = list(allreduce_extent(np.asarray(e, dtype=np.float64), device=dev))
+        ext = allreduce_extent(np.asarray(e, dtype=np.float64), device=dev)
+        extent = list(ext) if np.all(np.isfinite(ext)) else list(det.pos[:2].repeat(2))
     with global_options.no_warnings():
         img = RT.detector_image(detector_index=detector_index, extent=extent, projection_method=projection_method,
                                 _keep_on_device=True)

@@ -10,7 +10,7 @@ from typing import Any
 
 import numpy as np
 
-from ..base import BaseClass, check_type
+from ..base import BaseClass, check_type, touch
 from ..refraction_index import RefractionIndex
 from ..spectrum import TransmissionSpectrum
 from .._warn import warning
@@ -329,6 +329,7 @@ class Group(BaseClass):
 
     def add(self, el) -> None:
         from .ray_source import RaySource
+        touch()
         if not isinstance(el, list) and self.has(el):
             warning("Element already included in geometry. Make a copy to include it another time.")
             return
@@ -355,6 +356,7 @@ class Group(BaseClass):
             raise TypeError(f"Unsupported element type {type(el).__name__}.")
 
     def remove(self, el) -> bool:
+        touch()
         success = False
         if isinstance(el, list):
             for eli in el.copy():
@@ -375,6 +377,7 @@ class Group(BaseClass):
         return any(eli is el for eli in self._elements)
 
     def clear(self) -> None:
+        touch()
         for lst in (self.lenses, self.apertures, self.filters, self.detectors, self.ray_sources,
                     self.markers, self.volumes):
             lst[:] = []

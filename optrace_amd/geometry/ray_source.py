@@ -242,6 +242,10 @@ class RaySource(Element):
                 raise RuntimeError("For performance reasons only images with less than 2 megapixels are allowed.")
             if val._data.sum() <= 0:
                 raise ValueError("Image can not be completely black")
+            # the pixel probabilities are derived once from the image (ray_source.py:96-107): keep the pixels they
+            # were derived from, frozen, so that the device tables always describe this copy
+            val = val.copy()
+            val._data.flags.writeable = False
         elif key == "front":
             ok = isinstance(val, (Point, Line)) or (isinstance(val, Surface) and val.is_flat())
             if not ok or isinstance(val, SlitSurface):

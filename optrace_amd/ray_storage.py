@@ -58,6 +58,8 @@ class SourceTable:
 
 class RayStorage(BaseClass):
 
+    _tracked = False  # a result container: filling it must not look like a scene change
+
     def __init__(self, **kwargs) -> None:
         self._lock = False
         self.N_list = np.array([], dtype=int)
@@ -69,44 +71,72 @@ class RayStorage(BaseClass):
         self._dev = {}    # name -> torch tensor (flat, component-major)
         self._host = {}   # name -> cached read-only numpy view
         self._powers = []
+        self._ranges = None   # ot_source_range array of the current split
+        self._split_key = None
+        self._rays_c = None   # ot_rays of the current buffers
         super().__init__(**kwargs)
 
     # ---- allocation (ray_storage.py:35-90) ---------------------------------------------------------
     def init(self, ray_source_list: list, N: int, nt: int, no_pol: bool, _single_power: float = None,
-             _N_list=None, _rng=None) -> None:
-        self._lock = False
-        self.no_pol = no_pol
+             _N_list=None, _rng=None, _power_scale: float = 1.0, _split=None, _keep_ranges: bool = False) -> None:
+        """`_power_scale`: the share of the sources' power this storage carries (one rank's shard of a sharded trace);
+        `_split`: (N_list, dN, p) precomputed by `split_rays` for exactly these sources and N; `_keep_ranges`: the
+        caller knows the sources did not change since the previous init (the range records are reused if the split is
+        the same deterministic one)."""
+        d = self.__dict__  # plain dict writes: this runs once per trace
+        d["_lock"] = False
+        d["no_pol"] = no_pol
         assert N >= 0 and nt >= 0 and len(ray_source_list)
         dev = require_device()
 
         # rays per source proportional to power, remainder drawn with the powers as probabilities
-        P_list = np.array([RS.power for RS in ray_source_list])
-        P_all = np.sum(P_list)
-        self.N_list = (N * P_list / P_all).astype(int)
-        dN = N - np.sum(self.N_list)
-        # (a seeded tracer passes its own generator, so that the split repeats with the seed)
-        index_add = (np.random if _rng is None else _rng).choice(self.N_list.shape[0], size=dN, p=P_list / P_all)
-        np.add.at(self.N_list, index_add, np.ones(index_add.shape))
+        N_list, dN, prob = self.split_rays(ray_source_list, N) if _split is None else _split
+        if dN:
+            # (a seeded tracer passes its own generator, so that the split repeats with the seed)
+            index_add = (np.random if _rng is None else _rng).choice(N_list.shape[0], size=dN, p=prob)
+            N_list = N_list.copy()
+            np.add.at(N_list, index_add, np.ones(index_add.shape))
         if _N_list is not None:  # parity runs: the split the recorded rays were created with
-            self.N_list = np.asarray(_N_list).astype(int)
-            assert self.N_list.shape[0] == len(ray_source_list) and self.N_list.sum() == N
-        if np.any(self.N_list == 0):
+            N_list = np.asarray(_N_list).astype(int)
+            assert N_list.shape[0] == len(ray_source_list) and N_list.sum() == N
+        if not N_list.all():
             warning("There are RaySources that have no rays assigned. "
                     "Change the power ratio or raise the overall ray number")
-        self.B_list = np.concatenate(([0], np.cumsum(self.N_list))).astype(int)
-        self.ray_source_list = ray_source_list
-        self._powers = [float(_single_power or RS.power) for RS in ray_source_list]
+        d["N_list"] = N_list
+        d["B_list"] = np.concatenate(([0], np.cumsum(N_list))).astype(int)
+        d["ray_source_list"] = ray_source_list
+        d["_powers"] = [float(_single_power or RS.power) * _power_scale for RS in ray_source_list]
+        split_key = (int(N), float(_power_scale), dN == 0 and _N_list is None and _single_power is None)
+        if not (_keep_ranges and split_key[2] and split_key == self._split_key):
+            d["_ranges"] = None
+        d["_split_key"] = split_key
 
-        self._N, self._nt = int(N), int(nt)
-        self._host = {}
-        self._dev = {
-            "p": torch.empty(3 * nt * N, dtype=torch.float64, device=dev),
-            "s": torch.empty(3 * N, dtype=torch.float64, device=dev),
-            "w": torch.empty(nt * N, dtype=torch.float32, device=dev),
-            "n": torch.empty(nt * N, dtype=torch.float64, device=dev),
-            "wl": torch.empty(N, dtype=torch.float32, device=dev),
-            "pol": None if no_pol else torch.empty(3 * nt * N, dtype=torch.float32, device=dev),
-        }
+        N, nt = int(N), int(nt)
+        old = self._dev
+        if not (old and self._N == N and self._nt == nt and (old["pol"] is None) == bool(no_pol)
+                and old["p"].device == dev):
+            # (a trace with the shape of the previous one writes into the same buffers: host views already handed
+            # out are copies, and nothing on the device outlives the trace that produced it)
+            d["_dev"] = {
+                "p": torch.empty(3 * nt * N, dtype=torch.float64, device=dev),
+                "s": torch.empty(3 * N, dtype=torch.float64, device=dev),
+                "w": torch.empty(nt * N, dtype=torch.float32, device=dev),
+                "n": torch.empty(nt * N, dtype=torch.float64, device=dev),
+                "wl": torch.empty(N, dtype=torch.float32, device=dev),
+                "pol": None if no_pol else torch.empty(3 * nt * N, dtype=torch.float32, device=dev),
+            }
+            d["_rays_c"] = None
+        d["_N"], d["_nt"] = N, nt
+        d["_host"] = {}
+
+    @staticmethod
+    def split_rays(ray_source_list: list, N: int):
+        """(N_list, dN, p): floor(N * P_i / sum P) rays per source, dN rays left to be drawn with probabilities p
+        (ray_storage.py:59-68)."""
+        P_list = np.array([RS.power for RS in ray_source_list])
+        P_all = np.sum(P_list)
+        N_list = (N * P_list / P_all).astype(int)
+        return N_list, int(N - np.sum(N_list)), P_list / P_all
 
     @staticmethod
     def storage_size(N: int, nt: int, no_pol: bool) -> int:
@@ -132,12 +162,15 @@ class RayStorage(BaseClass):
 
     # ---- device side --------------------------------------------------------------------------------
     def _rays_struct(self) -> _capi.Rays:
+        if self._rays_c is not None:
+            return self._rays_c
         d = self._dev
         r = _capi.Rays()
         r.N, r.nt = self._N, self._nt
         r.p, r.s, r.w, r.n, r.wl = (d["p"].data_ptr(), d["s"].data_ptr(), d["w"].data_ptr(),
                                     d["n"].data_ptr(), d["wl"].data_ptr())
         r.pol = d["pol"].data_ptr() if d["pol"] is not None else None
+        self.__dict__["_rays_c"] = r
         return r
 
     # blocks below this size are not cut further (their share of the rays, and of the time, is negligible)
@@ -149,6 +182,8 @@ class RayStorage(BaseClass):
         blocks, largest first, plus one ragged rest: a power-of-two block's stratum permutation needs no rejection
         step (ot_generate.hpp::permute_index), and a wave runs as long as its slowest lane.  Every ray of a source
         carries power / N_source, whatever its block."""
+        if self._ranges is not None:
+            return self._ranges
         per_source = max(1, 64 // max(len(self.N_list), 1))  # at most 64 ranges travel as kernel arguments
         recs = []
         for i, n in enumerate(int(v) for v in self.N_list):
@@ -163,6 +198,7 @@ class RayStorage(BaseClass):
         rng = (_capi.SourceRange * len(recs))()
         for r, (i, first, count, ray_power) in zip(rng, recs):
             r.source, r.first, r.count, r.ray_power = i, first, count, ray_power
+        self.__dict__["_ranges"] = rng
         return rng
 
     @property
@@ -256,8 +292,9 @@ class RayStorage(BaseClass):
     pol_list = property(lambda self: self._view("pol"))
 
     def lock(self) -> None:
-        self._lock = True
-        self._new_lock = True
+        d = self.__dict__
+        d["_lock"] = True
+        d["_new_lock"] = True
 
     def source_sections(self, index: int = None):
         """(p, s, pol, w, wl) of the first section of one source's rays, or of all (ray_storage.py:212-233); only these

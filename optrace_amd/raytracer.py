@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
+from . import base as _base
 from .base import check_type
 from .geometry.elements import Group, Aperture, Detector
 from .geometry.surfaces import Surface, Point, Line, SphericalSurface, RingSurface, SlitSurface
@@ -74,10 +75,20 @@ class Raytracer(Group):
         self._checked_key = None
         self._rays_known_current = False
         self._source_cache = None  # (key, SourceTable): device copy of the source records, reused while unchanged
+        self._fast = None  # what the last full trace established, valid while base.mutation_epoch() stands still
+        self._msgs_host = None
         super().__init__(None, n0, **kwargs)
         self._new_lock = True
 
+    # bookkeeping of the tracer itself: writing these is not a scene change (base.mutation_epoch)
+    _INTERNAL = frozenset(("_msgs", "_last_trace_snapshot", "_scene", "_scene_handle", "_scene_key", "_checked_key",
+                           "_rays_known_current", "_source_cache", "geometry_error", "fault_pos", "_fast",
+                           "_msgs_host", "_lock", "_new_lock"))
+
     def __setattr__(self, key: str, val: Any) -> None:
+        if key in self._INTERNAL:
+            self.__dict__[key] = val
+            return
         if key == "outline":
             check_type(key, val, (list, np.ndarray))
             o = np.asarray_chkfinite(val, dtype=np.float64)
@@ -138,6 +149,8 @@ class Raytracer(Group):
         return ["RaySource"] + sorted(names, key=lambda k: names[k]) + ["Outline"]
 
     def _show_messages(self, N) -> None:
+        if not global_options.show_warnings or not self._msgs.any():
+            return
         names = self._surface_names()
         texts = {
             self.INFOS.TIR: "with total inner reflection at surface {s} ({n}), treating as absorbed.",
@@ -148,12 +161,11 @@ class Raytracer(Group):
             self.INFOS.HURB_NEG_DIR: "have negative z-direction after ray bending at surface {s} ({n}), "
                                      "set to absorbed.",
         }
-        for type_ in range(self._msgs.shape[0]):
-            for surf in range(self._msgs.shape[1]):
-                if count := self._msgs[type_, surf]:
-                    name = names[surf] if surf < len(names) else "?"
-                    warning(f"{count} rays ({100*count/N:.3g}% of all rays) "
-                            + texts[self.INFOS(type_)].format(s=surf, n=name))
+        for type_, surf in zip(*np.nonzero(self._msgs)):
+            count = self._msgs[type_, surf]
+            name = names[surf] if surf < len(names) else "?"
+            warning(f"{count} rays ({100*count/N:.3g}% of all rays) "
+                    + texts[self.INFOS(type_)].format(s=surf, n=name))
 
     # ---- geometry checks (raytracer.py:510-664) ---------------------------------------------------------
     def _pretrace_check(self, N: int, snap: dict = None) -> bool:
@@ -314,57 +326,95 @@ class Raytracer(Group):
             pass
 
     # ---- tracing (raytracer.py:262-415) -----------------------------------------------------------------
+    def _structure(self) -> tuple:
+        """Identity of everything in the tracing lists (list edits do not pass through __setattr__)."""
+        return (tuple(map(id, self.lenses)), tuple(map(id, self.apertures)), tuple(map(id, self.filters)),
+                tuple(map(id, self.ray_sources)))
+
     def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None, _N_list=None,
-              _chunk: int = 0) -> None:
+              _chunk: int = 0, _power_scale: float = 1.0) -> None:
         """Trace N rays through the current geometry.
 
         Geometry errors are reported as warnings and set `geometry_error` instead of raising, like the
         reference.  `_initial_rays` = (p, s, pols, w, wl), `_N_list` (rays per source) and `_hurb_normals`
         (2*n_hurb, N) inject recorded inputs for parity tests; normally rays are generated inside the
         tracing kernel and the remainder of the per-source split is drawn at random like the reference does.
+        `_power_scale`: share of the source powers these rays carry (a rank's shard, distributed.py).
+
+        The reference re-reads the whole object graph on every call (raytracer.py:246-278).  Here everything
+        derived from it -- geometry checks, the compiled scene, the source table, the snapshot -- is kept while
+        nothing changed: every tracked object reports assignments to a global counter (base.mutation_epoch), so
+        an unchanged scene is recognised by one integer comparison plus the identities of the list members.
         """
-        snap = self.tracing_snapshot()  # taken once: geometry-check key, scene key and the post-trace record
-        if self._pretrace_check(N, snap):
-            return
+        fast = self._fast
+        if (fast is not None and fast[0] == _base.mutation_epoch() and fast[1] == self._structure()
+                and not self.geometry_error):
+            check_type("N", N, int)
+            if N < 1:
+                raise ValueError(f"Ray number N needs to be at least 1, but is {N}.")
+            _, _, snap, scene, splits = fast
+            snap = dict(snap)
+            writeable = False
+        else:
+            self._fast = fast = None
+            _base._SAW_WRITEABLE[0] = False
+            snap = self.tracing_snapshot()  # taken once: geometry-check key, scene key and the post-trace record
+            writeable = _base._SAW_WRITEABLE[0]  # large arrays that can still change in place: no shortcut next time
+            if self._pretrace_check(N, snap):
+                return
+            scene = self._compile(snap)
+            splits = {}
         lib = _capi.load_library()
         dev = require_device()
 
-        nt = len(self.tracing_surfaces) + 2
+        nt = scene.nt
         if self.rays.storage_size(N, nt, self.no_pol) > self.MAX_RAY_STORAGE_RAM:
             raise RuntimeError(f"More than {self.MAX_RAY_STORAGE_RAM*1e-9:.1f} GB RAM requested. Either decrease"
                                " the number of rays, surfaces or do an iterative render. If your system can handle"
                                " more RAM usage, increase the Raytracer.MAX_RAY_STORAGE_RAM parameter.")
 
-        scene = self._compile(snap)
-        assert scene.nt == nt
-        rng = None if self.seed is None else np.random.RandomState((int(self.seed) + 1000003 * int(_chunk)) % 2 ** 32)
-        self.rays.init(self.ray_sources, N, nt, self.no_pol, _N_list=_N_list, _rng=rng)
-        rays = self.rays._rays_struct()
-        msgs = torch.zeros(len(self.INFOS) * nt + 1, dtype=torch.int64, device=dev)
+        split = splits.get(N)
+        if split is None:
+            split = splits[N] = RayStorage.split_rays(self.ray_sources, N)
+        rng = None  # draws the remainder of the split: a seeded tracer repeats it with the seed
+        if self.seed is not None and split[1]:
+            rng = np.random.RandomState((int(self.seed) + 1000003 * int(_chunk)) % 2 ** 32)
+        rays_obj = self.rays
+        # unchanged sources and the same deterministic split as last time: the same range records
+        rays_obj.init(self.ray_sources, N, nt, self.no_pol, _N_list=_N_list, _rng=rng, _power_scale=_power_scale,
+                      _split=split, _keep_ranges=fast is not None)
+        rays = rays_obj._rays_struct()
         # a seeded tracer repeats itself call for call; the chunks of one iterative render must differ
         seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed) + 1000003 * int(_chunk)
 
+        n_msgs = len(self.INFOS) * nt + 1
+        if self._msgs_host is None or self._msgs_host.shape[0] != n_msgs:
+            self._msgs_host = np.zeros(n_msgs, dtype=np.int64)
+        msgs_h = self._msgs_host
         if _initial_rays is None:
-            if self.rays._has_function_orientation:  # per-trace orientation arrays: nothing to reuse
-                tab = self.rays._source_table(seed)
+            if rays_obj._has_function_orientation:  # per-trace orientation arrays: nothing to reuse
+                tab = rays_obj._source_table(seed)
             else:
-                skey = repr(snap["RaySources"]) + repr(self.rays._powers)
-                if self._source_cache is None or self._source_cache[0] != skey:
-                    self._source_cache = (skey, self.rays._source_table())
-                tab = self._source_cache[1]
-            rng = self.rays._source_ranges()
-            _capi.check(lib.ot_generate_and_trace(self._scene_handle, tab.handle, rng, len(rng), seed,
-                                                  C.byref(rays), ptr(msgs), stream_ptr()))
+                cache = self._source_cache
+                if fast is None or cache is None or cache[2] != _power_scale:
+                    skey = (repr(snap["RaySources"]), tuple(rays_obj._powers))
+                    if cache is None or cache[0] != skey:
+                        self._source_cache = cache = (skey, rays_obj._source_table(), _power_scale)
+                tab = cache[1]
+            rng_c = rays_obj._source_ranges()
+            # one synchronous call: launch, wait, counters in host memory (no device-to-host copy)
+            _capi.check(lib.ot_generate_and_trace_host(self._scene_handle, tab.handle, rng_c, len(rng_c), seed,
+                                                       C.byref(rays), msgs_h.ctypes.data, stream_ptr()))
         else:
-            self.rays.set_initial_rays(*_initial_rays)
+            rays_obj.set_initial_rays(*_initial_rays)
             hn = None
             if _hurb_normals is not None:
                 hn = torch.from_numpy(np.ascontiguousarray(_hurb_normals, dtype=np.float64).reshape(-1)).to(dev)
+            msgs = torch.zeros(n_msgs, dtype=torch.int64, device=dev)
             _capi.check(lib.ot_trace(self._scene_handle, C.byref(rays), ptr(hn), seed, ptr(msgs), stream_ptr()))
+            msgs_h = msgs.cpu().numpy()  # (synchronises the stream)
 
-        torch.cuda.current_stream().synchronize()
-        self.rays.lock()
-        msgs_h = msgs.cpu().numpy()
+        rays_obj.lock()
         if msgs_h[-1]:
             raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
         self._msgs = msgs_h[:-1].reshape(len(self.INFOS), nt).astype(int)
@@ -372,8 +422,11 @@ class Raytracer(Group):
             self._msgs[self.INFOS.HURB_NEG_DIR, 0] = 0
             raise RuntimeError("All ray divergences s need to be in positive z-divergence")
         self._show_messages(N)
-        snap["Rays"] = [self.rays.N, self.rays.Nt, self.rays.no_pol]
+        snap["Rays"] = [rays_obj.N, rays_obj.Nt, rays_obj.no_pol]
         self._last_trace_snapshot = snap
+        if fast is None and not writeable and _initial_rays is None and not rays_obj._has_function_orientation:
+            # read the counter last: objects this call created itself (the end aperture of the element list) count too
+            self._fast = (_base.mutation_epoch(), self._structure(), snap, scene, splits)
 
     # ---- detector (raytracer.py:881-1098) ----------------------------------------------------------------
     def _hit_detectors(self, info: str, specs: list) -> list:

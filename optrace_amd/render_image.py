@@ -20,6 +20,8 @@ from ._device import require_device, stream_ptr, ptr, to_dev
 
 class RenderImage(BaseClass):
 
+    _tracked = False  # a result container (see base.mutation_epoch)
+
     EPS: float = 1e-9
     K: float = 683.0  # luminous efficacy [lm/W] (scipy.constants "luminous efficacy", render_image.py:35)
     SIZES = [1, 3, 5, 7, 9, 15, 21, 27, 35, 45, 63, 105, 135, 189, 315, 945]

@@ -115,7 +115,7 @@ class Spectrum(BaseClass):
             check_in(key, val, self.spectrum_types)
         elif key in ("lines", "line_vals") and val is not None:
             check_type(key, val, (list, np.ndarray))
-            val2 = np.asarray_chkfinite(val, dtype=np.float32)  # float32 like the reference (spectrum.py:168)
+            val2 = np.array(np.asarray_chkfinite(val, dtype=np.float32))  # float32 like the reference (spectrum.py:168)
             if val2.shape[0] == 0:
                 raise ValueError(f"'{key}' can't be empty.")
             if key == "lines" and (val2.min() < go.wavelength_range[0] or val2.max() > go.wavelength_range[1]):
@@ -125,6 +125,7 @@ class Spectrum(BaseClass):
             if key == "lines" and len(np.unique(val)) != len(val):
                 raise ValueError("All elements inside of 'lines' must be unique.")
             val = val2
+            val.flags.writeable = False  # a private copy that changes only by assignment (change detection)
         elif key == "func_args":
             check_type(key, val, dict)
             val = copy.deepcopy(val)
@@ -139,7 +140,7 @@ class Spectrum(BaseClass):
                     raise RuntimeError("Function func needs to return positive values over the visible range.")
         elif key in ("_wls", "_vals") and val is not None:
             check_type(key, val, (list, np.ndarray))
-            val2 = np.asarray_chkfinite(val, dtype=np.float64)
+            val2 = np.array(np.asarray_chkfinite(val, dtype=np.float64))
             if key == "_wls":
                 if val2[0] < go.wavelength_range[0] or val2[-1] > go.wavelength_range[1]:
                     raise ValueError("wls needs to be inside the visible range")
@@ -148,6 +149,7 @@ class Spectrum(BaseClass):
             elif val2.min() < 0:
                 raise ValueError("vals must be all positive")
             val = val2
+            val.flags.writeable = False  # private copy, see `lines`
         elif key in ("wl", "wl0", "wl1", "mu"):
             check_type(key, val, (int, float))
             val = float(val)
@@ -230,8 +232,7 @@ class LightSpectrum(Spectrum):
         hist = torch.zeros(N, dtype=torch.float64, device=dev)
         _capi.check(lib.ot_spectrum_histogram(n, ptr(wl), ptr(w), ptr(d_edges), N, ptr(hist), stream_ptr()))
         spec._wls = edges
-        spec._vals = hist.cpu().numpy()
-        spec._vals *= 1 / (spec._wls[1] - spec._wls[0])  # W -> W/nm
+        spec._vals = hist.cpu().numpy() * (1 / (spec._wls[1] - spec._wls[0]))  # W -> W/nm
         return spec
 
     def _source_fields(self) -> dict:
