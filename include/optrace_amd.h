@@ -403,6 +403,31 @@ typedef struct ot_detector_req {
 int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_req* reqs,
                            int32_t n_reqs, void* stream);
 
+/* Raytracer.detector_image with a known extent (raytracer.py:1053-1098: _hit_detector + RenderImage.render), and
+ * the per-chunk, per-position body of iterative_render after its first chunk (raytracer.py:1244-1267), in one pass
+ * over the ray sections for up to 8 detectors (or positions of one detector): hit search, projection, user extent,
+ * misc.binning_indices_2d and the XYZW histogram update without the hit positions ever being written to memory.
+ * Per request: hist (Ny, Nx, 4) f64 device, ADDED to; extent = image extent after RenderImage.__fix_extent;
+ * crop4 = the user extent hits are restricted to (HOST f64[4]) or NULL; ill_count as in ot_detector_hits.
+ * Same sums as ot_detector_hits_multi + ot_render_accumulate, in another order. */
+typedef struct ot_detector_image_req {
+    const ot_surface* detector;
+    int32_t projection;   /* OT_PROJ_*                                              */
+    int32_t Nx, Ny;       /* pixel counts (render_image.py:383-387)                 */
+    int32_t _pad;
+    const double* crop4;  /* HOST f64[4] or NULL                                    */
+    double extent[4];     /* image extent [x0, x1, y0, y1]                          */
+    double* hist;         /* device (Ny, Nx, 4) f64                                 */
+    int64_t* ill_count;   /* device int64[2], added to                              */
+} ot_detector_image_req;
+int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_image_req* reqs,
+                       int32_t n_reqs, void* stream);
+
+/* The binning paths take their scratch (up to ~25 B per ray and image) from the device's stream-ordered memory pool,
+ * which keeps at most 16 GB of it between calls.  ot_scratch_trim waits for the device and returns all of it to
+ * the driver (for a caller whose own allocator needs the room). */
+int ot_scratch_trim(void);
+
 /* SphericalSurface.sphere_projection (spherical_surface.py:36-97): p (n,3) F-order -> out (n,3) F-order */
 int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, const double* p, double* out,
                          void* stream);

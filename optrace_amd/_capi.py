@@ -98,6 +98,12 @@ class DetectorReq(C.Structure):
                 ("ill_count", C.c_void_p)]
 
 
+class DetectorImageReq(C.Structure):
+    _fields_ = [("detector", C.c_void_p), ("projection", C.c_int32), ("Nx", C.c_int32), ("Ny", C.c_int32),
+                ("_pad", C.c_int32), ("crop4", C.c_void_p), ("extent", C.c_double * 4), ("hist", C.c_void_p),
+                ("ill_count", C.c_void_p)]
+
+
 class SourceRange(C.Structure):
     _fields_ = [("source", C.c_int32), ("_pad", C.c_int32), ("first", C.c_int64), ("count", C.c_int64),
                 ("ray_power", C.c_double)]
@@ -138,6 +144,8 @@ SIGNATURES = {
     "ot_refraction_index": (C.c_int, [C.POINTER(Medium), vp, i64, i64, vp, vp, vp]),
     "ot_detector_hits": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(Surface), i32, C.POINTER(C.c_double), vp, vp, vp, vp, vp]),
     "ot_detector_hits_multi": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(DetectorReq), i32, vp]),
+    "ot_detector_images": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(DetectorImageReq), i32, vp]),
+    "ot_scratch_trim": (C.c_int, []),
     "ot_sphere_projection": (C.c_int, [C.POINTER(Surface), i32, i64, vp, vp, vp]),
     "ot_image_convert": (C.c_int, [vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]),
     "ot_image_convolve": (C.c_int, [vp, i32, i32, vp, i32, vp, vp]),

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "ot_detector.hpp"
+#include "ot_detector_fused.hpp"
 #include "ot_device.hpp"
 #include "ot_focus.hpp"
 #include "ot_generate.hpp"
@@ -1446,17 +1447,31 @@ extern "C" int ot_sphere_projection(const ot_surface* surf, int32_t projection, 
 }
 
 // Stream-ordered scratch (hipMallocAsync) goes back to the driver at every synchronisation unless the pool is told to
-// keep it; the tile path asks for gigabytes per image, so the pool keeps what it has (once per device).
+// keep it; the tile paths ask for gigabytes per image and would pay for fresh pages every time.  The pool therefore
+// keeps up to OT_SCRATCH_KEEP bytes (about 5 % of the HBM of an MI355X) between calls -- torch's allocator, which
+// owns the ray storage, cannot see this memory -- and ot_scratch_trim() hands everything back on request.
+#define OT_SCRATCH_KEEP (16ull << 30)
 static hipError_t keep_async_pool(int dev) {
     static thread_local bool done[64] = {false};
     if (dev < 0 || dev >= 64 || done[dev]) return hipSuccess;
     hipMemPool_t pool;
     hipError_t e = hipDeviceGetDefaultMemPool(&pool, dev);
     if (e != hipSuccess) return e;
-    unsigned long long keep = ~0ull;
+    unsigned long long keep = OT_SCRATCH_KEEP;
     e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     done[dev] = (e == hipSuccess);
     return e;
+}
+
+extern "C" int ot_scratch_trim(void) {
+    if (int rc = require_device()) return rc;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipMemPool_t pool;
+    HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
+    HIP_TRY(hipDeviceSynchronize());  // frees are stream-ordered: let them happen
+    HIP_TRY(hipMemPoolTrimTo(pool, 0));
+    return OT_OK;
 }
 
 #define OT_TILE_MIN_HITS (1ll << 21)  // shorter lists: the direct kernel alone
@@ -1563,6 +1578,235 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     hipError_t e = hipGetLastError();
     (void)hipFreeAsync(ws, st);
     HIP_TRY(e);
+    return OT_OK;
+}
+
+// ---- detector image in one pass (ot_detector_fused.hpp) ------------------------------------------------------
+static int cu_count();
+
+extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_image_req* reqs,
+                                  int32_t n_reqs, void* stream) {
+    if (!rays || !reqs || n_reqs < 1) return fail(OT_ERR_INVALID, "ot_detector_images: null argument");
+    if (n_reqs > OT_DET_MAX) return fail(OT_ERR_INVALID, "ot_detector_images: at most 8 detectors per call");
+    if (!rays->p || !rays->w || !rays->wl) return fail(OT_ERR_INVALID, "ot_detector_images: ray storage has null buffers");
+    if (first < 0 || count < 0 || first + count > rays->N) return fail(OT_ERR_INVALID, "ot_detector_images: range outside the storage");
+    for (int k = 0; k < n_reqs; k++) {
+        const ot_detector_image_req& q = reqs[k];
+        if (!q.detector || !q.hist || !q.ill_count || q.Nx < 1 || q.Ny < 1) return fail(OT_ERR_INVALID, "ot_detector_images: bad request");
+        if (!(q.extent[1] > q.extent[0]) || !(q.extent[3] > q.extent[2])) return fail(OT_ERR_INVALID, "ot_detector_images: empty image extent");
+        if ((int64_t)q.Nx * q.Ny > (1ll << 27)) return fail(OT_ERR_INVALID, "ot_detector_images: image too large");
+        if (q.projection < OT_PROJ_NONE || q.projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
+    }
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<LeafSurface> ls(n_reqs);
+    for (int k = 0; k < n_reqs; k++)
+        if (int rc = ls[k].init(reqs[k].detector, st)) return rc;
+    if (count == 0) return OT_OK;
+    // Detectors that need the numeric hit search (aspheric, tilted, spline surfaces) or a sphere projection with
+    // transcendentals take the two-step chain: with the Illinois loop and the projection polynomials inside, the fused
+    // kernels need every vector register there is and lose to hit search + binning (C3, 5e7 rays: 3.1 against 2.1 ms).
+    for (int k = 0; k < n_reqs; k++) {
+        const ot_detector_image_req& q = reqs[k];
+        const bool closed = q.detector->kind <= OT_SURF_CONIC || q.detector->z_min == q.detector->z_max;
+        const bool plain = q.projection == OT_PROJ_NONE || q.projection == OT_PROJ_ORTHOGRAPHIC;
+        if (closed && plain) continue;
+        // this request alone through ot_detector_hits + ot_render_accumulate, the others through the fused kernels
+        char* tmp = nullptr;
+        const size_t o_hw = align_up(sizeof(double) * 2 * (size_t)count);
+        HIP_TRY(hipMallocAsync((void**)&tmp, o_hw + sizeof(float) * (size_t)count, st));
+        ot_detector_req dq;
+        dq.detector = q.detector;
+        dq.projection = q.projection;
+        dq.xy_only = 1;
+        dq.crop4 = q.crop4;
+        dq.ph = (double*)tmp;
+        dq.hw = (float*)(tmp + o_hw);
+        dq.extent4 = nullptr;
+        dq.ill_count = q.ill_count;
+        int rc = ot_detector_hits_multi(rays, first, count, &dq, 1, stream);
+        if (!rc) rc = ot_render_accumulate(count, dq.ph, dq.ph + count, dq.hw, rays->wl + first, q.extent, q.Nx, q.Ny, q.hist, stream);
+        (void)hipFreeAsync(tmp, st);
+        if (rc) return rc;
+        std::vector<ot_detector_image_req> rest;
+        for (int j = 0; j < n_reqs; j++)
+            if (j != k) rest.push_back(reqs[j]);
+        return rest.empty() ? OT_OK : ot_detector_images(rays, first, count, rest.data(), (int32_t)rest.size(), stream);
+    }
+    const double* table = observer_table_device();
+    if (!table) return fail(OT_ERR_HIP, "could not upload the CIE observer table");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int cus = cu_count();
+    // a tile-kernel workgroup keeps 20 B of LDS per (detector, tile): more tiles than fit -> two calls
+    int KT_all = 0;
+    for (int k = 0; k < n_reqs; k++)
+        KT_all += ((reqs[k].Nx + OT_TILE_W - 1) / OT_TILE_W) * ((reqs[k].Ny + OT_TILE_W - 1) / OT_TILE_W);
+    if (n_reqs > 1 && KT_all > OT_FUSE_LDS_ENTRIES) {
+        const int h = n_reqs / 2;
+        if (int rc = ot_detector_images(rays, first, count, reqs, h, stream)) return rc;
+        return ot_detector_images(rays, first, count, reqs + h, n_reqs - h, stream);
+    }
+    // OT_RENDER_PATH = direct | tiles pins the binning path (tests, profiling); default: by ray count and probe
+    const char* pin = std::getenv("OT_RENDER_PATH");
+    const bool pin_direct = pin && !std::strcmp(pin, "direct"), pin_tiles = pin && !std::strcmp(pin, "tiles");
+    const bool want_tiles = !pin_direct && (pin_tiles || count >= OT_TILE_MIN_HITS);
+    if (count >= (1ll << 31)) return fail(OT_ERR_UNSUPPORTED, "ot_detector_images: at most 2^31 - 1 rays per call");
+    // tile kernel: two rays per thread and sub-block where the images have at most 1024 tiles (10-bit tile numbers)
+    bool small_k = n_reqs == 1;
+    for (int k = 0; k < n_reqs; k++)
+        small_k = small_k && ((reqs[k].Nx + OT_TILE_W - 1) / OT_TILE_W) * ((reqs[k].Ny + OT_TILE_W - 1) / OT_TILE_W) <= 1024;
+    const int64_t brt = OT_FUSE_BR * (small_k ? 2 : 1);
+    const unsigned n_wg = (unsigned)std::min<int64_t>(2 * (int64_t)cus, (count + brt - 1) / brt);
+    const int64_t piece = ((count + n_wg - 1) / n_wg + brt - 1) / brt * brt;
+
+    std::vector<FuseOne> host(n_reqs);
+    bool numeric = false, general = false;  // general: numeric hit search or a sphere projection somewhere
+    int KT = 0, Kmax = 1;
+    uint32_t capmax = 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_dets = carve(sizeof(FuseOne) * n_reqs);
+    const size_t o_flags = carve(sizeof(int) * 4 * n_reqs);  // per detector: spread, -, overflow, pad
+    std::vector<size_t> o_ctile(n_reqs), o_cfill(n_reqs), o_rec(n_reqs);
+    for (int k = 0; k < n_reqs; k++) {
+        FuseOne& f = host[k];
+        std::memset(&f, 0, sizeof(f));
+        const ot_detector_image_req& q = reqs[k];
+        f.det = ls[k].d;
+        f.Rcurv = q.detector->R;
+        if (q.crop4) f.crop = {q.crop4[0], q.crop4[1], q.crop4[2], q.crop4[3], 1};
+        f.projection = q.projection;
+        f.a.x0 = q.extent[0];
+        f.a.x1 = q.extent[1];
+        f.a.y0 = q.extent[2];
+        f.a.y1 = q.extent[3];
+        f.a.fx = (double)q.Nx / (q.extent[1] - q.extent[0]);  // Nx / s[0]  misc.py:75
+        f.a.fy = (double)q.Ny / (q.extent[3] - q.extent[2]);
+        f.a.Nx = q.Nx;
+        f.a.Ny = q.Ny;
+        f.tx = (q.Nx + OT_TILE_W - 1) / OT_TILE_W;
+        f.K = f.tx * ((q.Ny + OT_TILE_W - 1) / OT_TILE_W);
+        f.ill = (unsigned long long*)q.ill_count;
+        f.hist = q.hist;
+        f.tiles_ok = want_tiles && f.K <= OT_TILE_MAX && f.K <= OT_FUSE_LDS_ENTRIES;
+        f.koff = KT;
+        if (f.tiles_ok) {
+            KT += f.K;
+            // a workgroup hands out chunks of its own part of the pool; every (workgroup, tile) pair leaves at most one
+            // chunk partly filled
+            f.per_wg = (uint32_t)((piece + OT_FUSE_CH - 1) / OT_FUSE_CH + f.K + 2);
+            f.cap = (uint32_t)std::min<int64_t>((int64_t)f.per_wg * n_wg, 0x7fffffffll);
+            o_ctile[k] = carve(sizeof(uint32_t) * f.cap);
+            o_cfill[k] = carve(sizeof(uint32_t) * f.cap);
+            o_rec[k] = carve(sizeof(TileRec) * (size_t)f.cap * OT_FUSE_CH);
+            Kmax = std::max(Kmax, f.K);
+            capmax = std::max(capmax, f.cap);
+        }
+        numeric = numeric || !(f.det.kind == OT_SURF_CONIC || f.det.flat);
+        general = general || !(f.det.kind == OT_SURF_CONIC || f.det.flat) || (q.projection != OT_PROJ_NONE && q.projection != OT_PROJ_ORTHOGRAPHIC);
+    }
+    const size_t o_tn = carve(sizeof(unsigned int) * Kmax);
+    const size_t o_ts = carve(sizeof(unsigned int) * (Kmax + 1));
+    const size_t o_list = carve(sizeof(unsigned int) * capmax);
+    const size_t o_slabs = carve(KT ? sizeof(double) * OT_TILE_PX * 4 * (size_t)Kmax * OT_FUSE_SPLIT : 0);
+    char* ws = nullptr;
+    if (KT) HIP_TRY(keep_async_pool(dev));
+    if (hipMallocAsync((void**)&ws, off, st) != hipSuccess || !ws) {
+        if (!KT) return fail(OT_ERR_HIP, "ot_detector_images: no scratch memory");
+        // no room for the records: bin directly (needs the flags and the detector table only)
+        (void)hipGetLastError();
+        KT = 0;
+        for (auto& f : host) f.tiles_ok = 0;
+        off = o_flags + sizeof(int) * 4 * n_reqs + 256;
+        HIP_TRY(hipMallocAsync((void**)&ws, off, st));
+    }
+    int* flags = (int*)(ws + o_flags);
+    for (int k = 0; k < n_reqs; k++) {
+        FuseOne& f = host[k];
+        f.spread = flags + 4 * k;
+        f.overflow = flags + 4 * k + 2;
+        if (f.tiles_ok) {
+            f.chunk_tile = (uint32_t*)(ws + o_ctile[k]);
+            f.chunk_fill = (uint32_t*)(ws + o_cfill[k]);
+            f.rec = (TileRec*)(ws + o_rec[k]);
+        }
+    }
+    hipError_t err = hipMemsetAsync(flags, 0, sizeof(int) * 4 * n_reqs, st);
+    if (err == hipSuccess) err = hipMemcpyAsync(ws + o_dets, host.data(), sizeof(FuseOne) * n_reqs, hipMemcpyHostToDevice, st);
+    const FuseOne* dd = (const FuseOne*)(ws + o_dets);
+    static thread_local bool lds_set[64] = {false};
+    const int lds_probe = OT_TILE_PROBE_SET * (int)sizeof(int);
+    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
+    if (err == hipSuccess && dev >= 0 && dev < 64 && !lds_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)fuse_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
+        lds_set[dev] = true;
+    }
+    if (err == hipSuccess) {
+        if (KT) {
+            if (pin_tiles) {  // spread = 1 for every detector with a pool
+                std::vector<int> hf(4 * n_reqs, 0);
+                for (int k = 0; k < n_reqs; k++) hf[4 * k] = host[k].tiles_ok;
+                err = hipMemcpyAsync(flags, hf.data(), sizeof(int) * 4 * n_reqs, hipMemcpyHostToDevice, st);
+                (void)hipStreamSynchronize(st);  // hf goes out of scope
+            } else if (numeric) {
+                hipLaunchKernelGGL(fuse_probe_kernel<true>, dim3(n_reqs), dim3(1024), lds_probe, st, *rays, first, count, dd);
+            } else {
+                hipLaunchKernelGGL(fuse_probe_kernel<false>, dim3(n_reqs), dim3(1024), lds_probe, st, *rays, first, count, dd);
+            }
+        }
+        const unsigned blocks = (unsigned)std::min<int64_t>(cus, (count + 1023) / 1024);
+        const size_t lds_tiles = sizeof(unsigned int) * (5 * (size_t)std::max(KT, 1) + OT_DET_MAX);
+        ot_rays part = *rays;  // the tile kernel addresses its rays with 32 bits from the start of the range
+        part.p += first;
+        part.w += first;
+        part.wl += first;
+#define OT_LAUNCH_FUSE(NUM, ND, RP)                                                                                       \
+    do {                                                                                                                  \
+        hipLaunchKernelGGL((fuse_direct_kernel<NUM, ND>), dim3(blocks), dim3(1024), 0, st, *rays, first, count, dd, n_reqs, table); \
+        if (KT)                                                                                                           \
+            hipLaunchKernelGGL((fuse_tiles_kernel<NUM, ND, RP>), dim3(n_wg), dim3(OT_FUSE_BR), lds_tiles, st, part,        \
+                               (uint32_t)count, dd, n_reqs, KT, (uint32_t)piece);                                          \
+    } while (0)
+        if (general) {
+            OT_LAUNCH_FUSE(true, 8, 1);
+        } else if (n_reqs == 1) {
+            if (small_k) OT_LAUNCH_FUSE(false, 1, 2); else OT_LAUNCH_FUSE(false, 1, 1);
+        } else if (n_reqs <= 2) {
+            OT_LAUNCH_FUSE(false, 2, 1);
+        } else if (n_reqs <= 4) {
+            OT_LAUNCH_FUSE(false, 4, 1);
+        } else {
+            OT_LAUNCH_FUSE(false, 8, 1);
+        }
+#undef OT_LAUNCH_FUSE
+        err = hipGetLastError();
+        // tile path, detector by detector: chunks grouped by tile, LDS accumulation, slabs summed into the image
+        for (int k = 0; k < n_reqs && err == hipSuccess && KT; k++) {
+            const FuseOne& f = host[k];
+            if (!f.tiles_ok) continue;
+            FuseIndex ix;
+            ix.tile_n = (unsigned int*)(ws + o_tn);
+            ix.tstart = (unsigned int*)(ws + o_ts);
+            ix.list = (unsigned int*)(ws + o_list);
+            ix.slabs = (double*)(ws + o_slabs);
+            err = hipMemsetAsync(ix.tile_n, 0, sizeof(unsigned int) * f.K, st);
+            if (err != hipSuccess) break;
+            const unsigned gc = (f.cap + 1024 * OT_FUSE_IDX_PER - 1) / (1024 * OT_FUSE_IDX_PER);
+            hipLaunchKernelGGL(fuse_chunk_hist_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
+            hipLaunchKernelGGL(fuse_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, f, ix);
+            hipLaunchKernelGGL(fuse_chunk_place_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
+            hipLaunchKernelGGL(fuse_accum_kernel, dim3(OT_FUSE_SPLIT, (unsigned)f.K), dim3(1024), lds_accum, st, f, ix, table);
+            hipLaunchKernelGGL(fuse_reduce_kernel, dim3(OT_TILE_PX / 256, (unsigned)f.K), dim3(256), 0, st, f, ix);
+            err = hipGetLastError();
+        }
+    }
+    (void)hipFreeAsync(ws, st);
+    HIP_TRY(err);
     return OT_OK;
 }
 

@@ -152,24 +152,33 @@ struct SectionPair {  // the last two sections of a ray and the weight of the la
     float wq;
 };
 
-template <bool NUMERIC, class DET>
-OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, int64_t count, DET& D, const SectionPair& sp,
-                         double (*sext)[4]) {
+// direction of the last but one section, re-derived from the stored positions (ray_storage.py:274-279)
+OT_DEV V3 pair_direction(const SectionPair& sp) {
+    V3 d = {sp.xl - sp.xq, sp.yl - sp.yq, sp.zl - sp.zq};
+    return normalize3(d);
+}
+
+// The hit of one ray on one detector: section search, intersection, projection, user extent.
+// -> valid, ph (projected), w; any_ill / timeout report the numeric hit search.
+// PROJ = false leaves the sphere projections out (their atan / tan polynomials cost ~64 VGPRs of hoisted constants once
+// the hit search sits inside a loop).
+template <bool NUMERIC, bool PROJ = true, class DET>
+OT_DEV void detector_hit(const ot_rays& R, int64_t r, bool active, DET& D, const SectionPair& sp, const V3& sdir, V3& ph,
+                         float& w, bool& valid, bool& any_ill, bool& timeout) {
     const int64_t N = R.N;
     const int nt = R.nt;
-    const int lane = __lane_id();
     const double* __restrict__ zp = R.p + r + N * (2 * (int64_t)nt);
     const double* __restrict__ xp = R.p + r;
     const double* __restrict__ yp = R.p + r + N * (int64_t)nt;
     const int kq = nt >= 2 ? nt - 2 : 0;
     const double zl = sp.zl, zq = sp.zq, xl = sp.xl, xq = sp.xq, yl = sp.yl, yq = sp.yq;
     const float wq = sp.wq;
-    {
-
     const auto& det = D.det;
-    V3 ph = {0.0, 0.0, 0.0};
-    float w = 0.f;
-    bool ish = false, any_ill = false, timeout = false;
+    ph = {0.0, 0.0, 0.0};
+    w = 0.f;
+    bool ish = false;
+    any_ill = false;
+    timeout = false;
 
     if (active) {
         // section search (raytracer.py:929-938): first section whose start lies at/behind the detector's z_min.
@@ -211,8 +220,7 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
             V3 p, s;
             if (k == kq && nt >= 2) {  // the prefetched pair of sections
                 p = {xq, yq, zq};
-                V3 d = {xl - xq, yl - yq, zl - zq};
-                s = normalize3(d);
+                s = sdir;  // = pair_direction(sp): the same for every detector of a launch, formed once per ray
                 w = wq;
             } else {
                 p = {xp[N * (int64_t)k], yp[N * (int64_t)k], zp[N * (int64_t)k]};
@@ -238,10 +246,21 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
             }
         }
     }
-    bool valid = active && ish && (w > 0);
-    if (valid) sphere_project(det.px, det.py, det.pz, D.Rcurv, D.projection, ph);
+    valid = active && ish && (w > 0);
+    if (PROJ && valid) sphere_project(det.px, det.py, det.pz, D.Rcurv, D.projection, ph);
     // user extent: hits outside are dropped (raytracer.py:1036-1040)
     if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
+}
+
+template <bool NUMERIC, class DET>
+OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, int64_t count, DET& D, const SectionPair& sp,
+                         const V3& sdir, double (*sext)[4]) {
+    const int lane = __lane_id();
+    {
+    V3 ph;
+    float w;
+    bool valid, any_ill, timeout;
+    detector_hit<NUMERIC>(R, r, active, D, sp, sdir, ph, w, valid, any_ill, timeout);
     if (active) {
         D.ph[q] = valid ? ph.x : 0.0;
         D.ph[q + count] = valid ? ph.y : 0.0;
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first,
     const int64_t r = first + (active ? q : 0);
     __shared__ double sext[4][4];
     const SectionPair sp = load_section_pair(R, r, active);
-    detector_one<NUMERIC>(R, q, r, active, count, D, sp, sext);
+    detector_one<NUMERIC>(R, q, r, active, count, D, sp, pair_direction(sp), sext);
 }
 
 // several detectors, records in device memory.  The detector loop is unrolled at compile time (NDET = 2, 4, 8; unused
@@ -319,12 +338,13 @@ __global__ __launch_bounds__(256) void detector_multi_kernel(ot_rays R, int64_t 
     const int64_t r = first + (active ? q : 0);
     __shared__ double sext[4][4];
     const SectionPair sp = load_section_pair(R, r, active);
+    const V3 sdir = pair_direction(sp);
     if constexpr (NUMERIC) {  // the Illinois loop and the spline code do not unroll; rare as detectors (run-time loop)
-        for (int di = 0; di < n_det; di++) detector_one<NUMERIC>(R, q, r, active, count, as_const(dets)[di], sp, sext);
+        for (int di = 0; di < n_det; di++) detector_one<NUMERIC>(R, q, r, active, count, as_const(dets)[di], sp, sdir, sext);
     } else {
 #pragma unroll
         for (int di = 0; di < NDET; di++)
-            if (di < n_det) detector_one<NUMERIC>(R, q, r, active, count, as_const(dets)[di], sp, sext);
+            if (di < n_det) detector_one<NUMERIC>(R, q, r, active, count, as_const(dets)[di], sp, sdir, sext);
     }
 }
 

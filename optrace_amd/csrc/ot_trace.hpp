@@ -246,11 +246,18 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
 // Stores with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: `global_store ... v_off, v_data,
 // s[base]`.  Written as inline assembly because the compiler otherwise keeps one 64-bit VGPR address per stored plane
 // and advances each of them every section (9 v_lshl_add_u64 per section: 3.5 % of the loop's vector instructions).
+// The base is copied to a scratch SGPR pair inside the statement: a base the register allocator reloads from a spill
+// slot comes out of v_readlane_b32, and a vector-memory instruction that reads an SGPR written by the vector ALU less
+// than five wait states earlier uses the OLD value (gfx9 hazard).  The compiler pads that hazard for its own
+// instructions but cannot see into an asm statement; a scalar move in between is interlocked by the hardware on both
+// sides.  (Found as stray final directions in 1 of ~3 runs of the kernel variants that spill SGPRs.)
 OT_DEV void store_f64(const void* base, uint32_t off, double v) {
-    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
+    const void* b;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0" : "=&s"(b) : "v"(off), "v"(v), "s"(base));
 }
 OT_DEV void store_f32(const void* base, uint32_t off, float v) {
-    asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
+    const void* b;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" : "=&s"(b) : "v"(off), "v"(v), "s"(base));
 }
 
 // One section of one ray.  The plane base addresses (array + N * plane) are wave-uniform and stay in SGPRs; the
@@ -260,11 +267,11 @@ OT_DEV void store_f32(const void* base, uint32_t off, float v) {
 template <bool POL>
 OT_DEV void store_section(const ot_rays& R, uint32_t o8, uint32_t o4, int sec, const V3& p, float w, double n, float px,
                           float py, float pz) {
-    // Measured alternatives on the bench scene: a workgroup-relative form (SGPR base + threadIdx offset with 64-bit
-    // vector adds) was 4 % slower (1.93 vs 1.86 ms); a wave-tiled layout ([tile of 64 rays][section][component][lane]
-    // inside each array) made no difference (1.750 vs 1.755 ms) although it wins in the store-only experiment
-    // (tools/experiments/store_pattern.hip) -- so the reference's planar Fortran layout stays, and host views need
-    // no re-ordering.
+    // Measured on the bench scene, same box (profiles/r2/store_variants.txt): this form 1.676 ms, per-plane 64-bit
+    // VGPR addresses 1.700 ms, a wave-tiled layout ([tile of 64 rays][section][component][lane] inside each array)
+    // 1.682 ms -- so the reference's planar Fortran layout stays and host views need no re-ordering.  Without the
+    // section stores the same kernel runs 1.238 ms at 2.39 GHz; with them the chip holds 1.97 GHz: compute and stores
+    // do overlap, but together they run into the package power limit.
     const int64_t N = R.N;
     const int64_t nt = R.nt;
     store_f64(R.p + N * sec, o8, p.x);

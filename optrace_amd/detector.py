@@ -59,6 +59,40 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
     return res
 
 
+def detector_images(rays, first: int, count: int, requests: list) -> list:
+    """Hit search and binning fused (`ot_detector_images`) for detector images whose extent is known beforehand.
+
+    requests: dicts with surf_desc (_capi.Surface), projection (int), crop ([x0, x1, y0, y1]: the user extent hits are
+    restricted to, or None), extent (image extent after RenderImage._fix_extent), Nx, Ny, hist (flat f64 device tensor
+    of Ny * Nx * 4 entries that the hits are ADDED to).  At most 8 per call.  -> ill-conditioned count per request."""
+    lib = _capi.load_library()
+    dev = require_device()
+    n = len(requests)
+    reqs = (_capi.DetectorImageReq * n)()
+    keep = []
+    ill = torch.zeros(2 * n, dtype=torch.int64, device=dev)
+    any_numeric = False
+    for k, rq in enumerate(requests):
+        sd = rq["surf_desc"]
+        crop4 = None if rq.get("crop") is None else (C.c_double * 4)(*(float(v) for v in rq["crop"]))
+        keep.append((sd, crop4))
+        r = reqs[k]
+        r.detector = C.addressof(sd)
+        r.projection = int(rq["projection"])
+        r.Nx, r.Ny = int(rq["Nx"]), int(rq["Ny"])
+        r.crop4 = None if crop4 is None else C.addressof(crop4)
+        r.extent[:] = [float(v) for v in rq["extent"]]
+        r.hist = rq["hist"].data_ptr()
+        r.ill_count = ill.data_ptr() + 16 * k
+        any_numeric = any_numeric or (sd.kind >= _capi.SURF_ASPHERE and sd.z_min != sd.z_max)
+    rs = rays._rays_struct()
+    _capi.check(lib.ot_detector_images(C.byref(rs), int(first), int(count), reqs, n, stream_ptr()))
+    ill_h = ill.cpu().numpy() if any_numeric else np.zeros(2 * n, dtype=np.int64)  # no read-back, no sync otherwise
+    if ill_h[1::2].any():
+        raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
+    return [int(v) for v in ill_h[0::2]]
+
+
 def detector_hits(rays, first: int, count: int, surf_desc: _capi.Surface, projection: int, want_extent: bool,
                   crop=None):
     """-> (ph flat (3*count) f64 device tensor, hw (count) f32 device tensor, extent4 or None, ill_count).

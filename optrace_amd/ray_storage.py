@@ -113,18 +113,30 @@ class RayStorage(BaseClass):
 
         N, nt = int(N), int(nt)
         old = self._dev
-        if not (old and self._N == N and self._nt == nt and (old["pol"] is None) == bool(no_pol)
-                and old["p"].device == dev):
+        reuse = bool(old and self._N == N and self._nt == nt and (old["pol"] is None) == bool(no_pol)
+                     and old["p"].device == dev)
+        del old
+        if not reuse:
             # (a trace with the shape of the previous one writes into the same buffers: host views already handed
             # out are copies, and nothing on the device outlives the trace that produced it)
-            d["_dev"] = {
-                "p": torch.empty(3 * nt * N, dtype=torch.float64, device=dev),
-                "s": torch.empty(3 * N, dtype=torch.float64, device=dev),
-                "w": torch.empty(nt * N, dtype=torch.float32, device=dev),
-                "n": torch.empty(nt * N, dtype=torch.float64, device=dev),
-                "wl": torch.empty(N, dtype=torch.float32, device=dev),
-                "pol": None if no_pol else torch.empty(3 * nt * N, dtype=torch.float32, device=dev),
-            }
+            d["_dev"] = {}  # the previous storage goes back to the allocator before the new one is requested
+
+            def alloc() -> dict:
+                return {
+                    "p": torch.empty(3 * nt * N, dtype=torch.float64, device=dev),
+                    "s": torch.empty(3 * N, dtype=torch.float64, device=dev),
+                    "w": torch.empty(nt * N, dtype=torch.float32, device=dev),
+                    "n": torch.empty(nt * N, dtype=torch.float64, device=dev),
+                    "wl": torch.empty(N, dtype=torch.float32, device=dev),
+                    "pol": None if no_pol else torch.empty(3 * nt * N, dtype=torch.float32, device=dev),
+                }
+            try:
+                d["_dev"] = alloc()
+            except torch.OutOfMemoryError:
+                # the library's binning scratch lives in HIP's stream-ordered pool, which torch's allocator cannot see
+                _capi.check(_capi.load_library().ot_scratch_trim())
+                torch.cuda.empty_cache()
+                d["_dev"] = alloc()
             d["_rays_c"] = None
         d["_N"], d["_nt"] = N, nt
         d["_host"] = {}

@@ -429,15 +429,9 @@ class Raytracer(Group):
             self._fast = (_base.mutation_epoch(), self._structure(), snap, scene, splits)
 
     # ---- detector (raytracer.py:881-1098) ----------------------------------------------------------------
-    def _hit_detectors(self, info: str, specs: list) -> list:
-        """Device hit search for several (detector, position) pairs in one pass over the ray sections.
-
-        specs: dicts with detector_index, source_index, extent, projection_method and optionally pos (the detector is
-        moved there first, as `iterative_render` does position by position, raytracer.py:1244).
-        -> per spec (ph, hw, wl, extent_out, projection, ill_count, desc): device tensors of the selected ray range; ph
-        holds the x and y planes, the z plane as well with want_z
-        (dense: rays without a valid hit carry weight 0), the extent actually used, the projection name, the
-        ill-conditioned count and the image description at that position."""
+    def _detector_requests(self, specs: list) -> list:
+        """Checks of `_hit_detector` (raytracer.py:897-920) and, per spec, everything the device calls need:
+        dicts with Ns, Ne (ray range), surf_desc, projection (name), crop (user extent or None), desc, centre."""
         if not self.detectors:
             raise RuntimeError("Detector Missing")
         if not self.rays.N:
@@ -451,51 +445,108 @@ class Raytracer(Group):
         if not self._rays_known_current and not self.check_if_rays_are_current():
             raise RuntimeError("Tracing geometry/properties changed. Please retrace first.")
 
-        groups: dict = {}  # ray range -> requests (one launch per range and at most 8 detectors)
-        meta = []
-        for n, sp in enumerate(specs):
+        out = []
+        for sp in specs:
             source_index, detector_index = sp.get("source_index"), sp.get("detector_index", 0)
             extent, projection_method = sp.get("extent"), sp.get("projection_method", "Equidistant")
             Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
-            Ns, Ne = int(Ns), int(Ne)
             det = self.detectors[detector_index]
             if sp.get("pos") is not None:
                 det.move_to(sp["pos"])
             dsurf = det.surface
 
+            projection = None
             if isinstance(dsurf, SphericalSurface) and projection_method is not None:
                 if projection_method not in SphericalSurface.sphere_projection_methods:
                     raise ValueError(f"Invalid projection_method {projection_method}, "
                                      f"must be one of {SphericalSurface.sphere_projection_methods}.")
                 projection = projection_method
-            else:
-                projection = None
 
             if not (extent is None or isinstance(extent, (list, np.ndarray))):
                 raise ValueError(f"Invalid extent '{extent}'.")
-            extent_out = None
+            crop = None
             if extent is not None:
-                extent_out = np.asarray_chkfinite(np.array(extent, dtype=np.float64).copy(), dtype=np.float64)
+                crop = np.asarray_chkfinite(np.array(extent, dtype=np.float64).copy(), dtype=np.float64)
 
             pname = f": {det.desc}" if det.desc != "" else ""
-            desc = f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm"
+            out.append(dict(Ns=int(Ns), Ne=int(Ne), surf_desc=dsurf._desc(), projection=projection, crop=crop,
+                            desc=f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm",
+                            centre=det.pos[:2].repeat(2), want_z=bool(sp.get("want_z", False))))
+        return out
+
+    def _hit_detectors(self, info: str, specs: list) -> list:
+        """Device hit search for several (detector, position) pairs in one pass over the ray sections.
+
+        specs: dicts with detector_index, source_index, extent, projection_method and optionally pos (the detector is
+        moved there first, as `iterative_render` does position by position, raytracer.py:1244).
+        -> per spec (ph, hw, wl, extent_out, projection, ill_count, desc): device tensors of the selected ray range; ph
+        holds the x and y planes, the z plane as well with want_z
+        (dense: rays without a valid hit carry weight 0), the extent actually used, the projection name, the
+        ill-conditioned count and the image description at that position."""
+        reqs = self._detector_requests(specs)
+        groups: dict = {}  # ray range -> requests (one launch per range and at most 8 detectors)
+        for n, rq in enumerate(reqs):
             # rays outside a user extent are dropped (raytracer.py:1036-1040): the hit kernel gives them weight 0
-            groups.setdefault((Ns, Ne), []).append((n, dict(surf_desc=dsurf._desc(), want_extent=extent is None,
-                                                            projection=_capi.PROJECTIONS[projection], crop=extent_out,
-                                                            want_z=bool(sp.get("want_z", False)))))
-            meta.append((Ns, Ne, extent_out, projection, desc, det.pos[:2].repeat(2)))
+            groups.setdefault((rq["Ns"], rq["Ne"]), []).append(
+                (n, dict(surf_desc=rq["surf_desc"], want_extent=rq["crop"] is None,
+                         projection=_capi.PROJECTIONS[rq["projection"]], crop=rq["crop"], want_z=rq["want_z"])))
 
         out = [None] * len(specs)
-        for (Ns, Ne), reqs in groups.items():
-            for b in range(0, len(reqs), 8):
-                part = reqs[b:b + 8]
+        for (Ns, Ne), part_all in groups.items():
+            for b in range(0, len(part_all), 8):
+                part = part_all[b:b + 8]
                 res = _detector.detector_hits_multi(self.rays, Ns, Ne - Ns, [r for _, r in part])
                 for (n, _), (ph, hw, ext4, ill_count) in zip(part, res):
-                    _, _, extent_out, projection, desc, centre = meta[n]
+                    rq = reqs[n]
+                    extent_out = rq["crop"]
                     if extent_out is None:
-                        extent_out = ext4.copy() if np.all(np.isfinite(ext4)) else centre
-                    out[n] = (ph, hw, self.rays._dev["wl"][Ns:Ne], extent_out, projection, ill_count, desc)
+                        extent_out = ext4.copy() if np.all(np.isfinite(ext4)) else rq["centre"]
+                    out[n] = (ph, hw, self.rays._dev["wl"][Ns:Ne], extent_out, rq["projection"], ill_count, rq["desc"])
         return out
+
+    def _render_detectors(self, specs: list, limits: list, into: list = None, **kwargs) -> list:
+        """Detector images whose extents are known beforehand (every spec carries a user extent): hit search and
+        binning in ONE pass over the ray sections (`ot_detector_images`), up to 8 images per pass; the hit positions
+        are never written to memory.  into: per spec a (Ny, Nx, 4) device histogram to add to, or None.
+        -> RenderImages (raytracer.py:1053-1098 for each spec)."""
+        reqs = self._detector_requests(specs)
+        images, calls = [], {}
+        dev = require_device()
+        for n, (sp, rq, limit) in enumerate(zip(specs, reqs, limits)):
+            desc = rq["desc"]
+            if sp.get("source_index") is not None:
+                desc = f"Rays from RS{sp['source_index']} at " + desc
+            img = RenderImage(long_desc=desc, extent=rq["crop"], projection=rq["projection"])
+            img._limit = limit
+            img._fix_extent()
+            Nx, Ny = img._pixel_counts()
+            tgt = None if into is None else into[n]
+            if tgt is not None:
+                if tuple(tgt.shape) != (Ny, Nx, 4):
+                    raise ValueError("histogram to accumulate into has the wrong shape")
+                hist = tgt.view(-1)
+            else:
+                hist = torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=dev)
+            img._dev = hist.view(Ny, Nx, 4)
+            img._host = None
+            images.append(img)
+            calls.setdefault((rq["Ns"], rq["Ne"]), []).append(
+                (n, dict(surf_desc=rq["surf_desc"], projection=_capi.PROJECTIONS[rq["projection"]], crop=rq["crop"],
+                         extent=img.extent, Nx=Nx, Ny=Ny, hist=hist)))
+        for (Ns, Ne), part_all in calls.items():
+            for b in range(0, len(part_all), 8):
+                part = part_all[b:b + 8]
+                ills = _detector.detector_images(self.rays, Ns, Ne - Ns, [r for _, r in part])
+                for (n, _), ill_count in zip(part, ills):
+                    if ill_count:
+                        warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned "
+                                f"for numerical hit finding at detector {specs[n].get('detector_index', 0)}. "
+                                "Where and whether they intersect might be wrong.")
+        if not kwargs.get("_dont_filter", False):
+            for img in images:
+                if img._limit is not None:
+                    img._apply_rayleigh_filter()
+        return images
 
     def _hit_detector(self, info: str, detector_index: int = 0, source_index: int = None, extent=None,
                       projection_method: str = "Equidistant"):
@@ -522,8 +573,12 @@ class Raytracer(Group):
             warning("Using the limit parameter in combination with a user defined extent"
                     " will produce an incorrect detector image, as the rays outside the extent"
                     " are not included in the convolution calculation.")
-        hits = self._hit_detectors("Detector Image", [dict(detector_index=detector_index, source_index=source_index,
-                                                           extent=extent, projection_method=projection_method)])[0]
+        spec = dict(detector_index=detector_index, source_index=source_index, extent=extent,
+                    projection_method=projection_method)
+        if extent is not None and not kwargs.get("_unfused", False):  # extent known: one pass, no hit positions in memory
+            return self._render_detectors([spec], [limit], **kwargs)[0]
+        kwargs.pop("_unfused", None)
+        hits = self._hit_detectors("Detector Image", [spec])[0]
         return self._image_from_hits(hits, detector_index, source_index, limit, **kwargs)
 
     def detector_spectrum(self, detector_index: int = 0, source_index: int = None, extent=None,
@@ -774,21 +829,30 @@ class Raytracer(Group):
                 msgs_cum += self._msgs
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
-                # up to 8 positions are intersected in one pass over the sections (`ot_detector_hits_multi`); their
-                # hit lists (20 B per ray and position) are binned and released before the next group is searched
+                # up to 8 positions are intersected in one pass over the sections.  Once the extents are known (given by
+                # the caller, or fixed by the first chunk, raytracer.py:1262) hit search and binning are one pass as
+                # well (`ot_detector_images`); otherwise the hit lists (20 B per ray and position, `ot_detector_hits_multi`)
+                # are binned and released before the next group is searched
                 for j0 in range(0, len(pos), 8):
-                    group = range(j0, min(j0 + 8, len(pos)))
-                    hits = self._hit_detectors("Detector Image", [
-                        dict(detector_index=detector_index[j], extent=extentc[j], projection_method=projection_method[j],
-                             pos=pos[j]) for j in group])
+                    group = list(range(j0, min(j0 + 8, len(pos))))
+                    specs = [dict(detector_index=detector_index[j], extent=extentc[j],
+                                  projection_method=projection_method[j], pos=pos[j]) for j in group]
+                    # chunks of equal size are binned straight into the image of the first chunk (their common
+                    # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
+                    # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
+                    direct = 0 < i and rays_step == step0
+                    into = [images[j]._dev if direct else None for j in group]
+                    if all(extentc[j] is not None for j in group):
+                        imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, _dont_filter=True)
+                    else:
+                        hits = self._hit_detectors("Detector Image", specs)
+                        imgs = []
+                        for g, j in enumerate(group):
+                            imgs.append(self._image_from_hits(hits[g], detector_index[j], None, limit[j],
+                                                              _dont_filter=True, _into=into[g]))
+                            hits[g] = None
                     for g, j in enumerate(group):
-                        # chunks of equal size are binned straight into the image of the first chunk (their common
-                        # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
-                        # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
-                        direct = 0 < i and rays_step == step0
-                        img = self._image_from_hits(hits[g], detector_index[j], None, limit[j], _dont_filter=True,
-                                                    _into=images[j]._dev if direct else None)
-                        hits[g] = None
+                        img = imgs[g]
                         if i == 0:
                             images.append(img)
                             extentc[j] = img._extent0

@@ -45,7 +45,7 @@ def test_abi_version(lib):
 def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / "sz.c"
     names = ["ot_surface", "ot_medium", "ot_filter", "ot_element", "ot_scene_desc", "ot_source",
-             "ot_source_range", "ot_rays", "ot_detector_req"]
+             "ot_source_range", "ot_rays", "ot_detector_req", "ot_detector_image_req"]
     body = "\n".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names)
     extra = 'printf("off_coeff %zu\\n", offsetof(ot_surface, coeff)); printf("off_spec %zu\\n", offsetof(ot_source, spec_tab));'
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(){{{body}{extra}return 0;}}')
@@ -54,7 +54,8 @@ def test_struct_layout_matches_header(tmp_path):
     out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
     py = {"ot_surface": _capi.Surface, "ot_medium": _capi.Medium, "ot_filter": _capi.Filter,
           "ot_element": _capi.Element, "ot_scene_desc": _capi.SceneDesc, "ot_source": _capi.Source,
-          "ot_source_range": _capi.SourceRange, "ot_rays": _capi.Rays, "ot_detector_req": _capi.DetectorReq}
+          "ot_source_range": _capi.SourceRange, "ot_rays": _capi.Rays, "ot_detector_req": _capi.DetectorReq,
+          "ot_detector_image_req": _capi.DetectorImageReq}
     for n, cls in py.items():
         assert C.sizeof(cls) == int(out[n]), n
     assert _capi.Surface.coeff.offset == int(out["off_coeff"])

@@ -1,0 +1,148 @@
+"""Detector images with a known extent: hit search and binning in one pass (`ot_detector_images`,
+csrc/ot_detector_fused.hpp) against the two-step chain `ot_detector_hits_multi` + `ot_render_accumulate`, which the
+reference fixtures pin (tests/test_gpu_parity.py).  Same hits, same pixels; f64 sums in another order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import optrace_amd as ot
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+class pinned:
+    """OT_RENDER_PATH = direct | tiles for the calls inside (None: the probe decides)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        self.old = os.environ.pop("OT_RENDER_PATH", None)
+        if self.path:
+            os.environ["OT_RENDER_PATH"] = self.path
+
+    def __exit__(self, *a):
+        os.environ.pop("OT_RENDER_PATH", None)
+        if self.old is not None:
+            os.environ["OT_RENDER_PATH"] = self.old
+
+
+def same_image(a, b, tol=1e-11):
+    A, B = a._data, b._data
+    assert A.shape == B.shape
+    np.testing.assert_allclose(a.extent, b.extent, rtol=0, atol=0)
+    assert A[..., 3].sum() > 0
+    assert np.array_equal(A[..., 3] != 0, B[..., 3] != 0), "same pixels lit"
+    assert np.abs(A - B).max() <= tol * np.abs(A).max()
+
+
+def image_scene(N=400_000, seed=3, no_pol=True):
+    """Extended RGB image source through a lens onto a square detector (geometry of examples/image_render_many_rays.py)."""
+    RT = ot.Raytracer(outline=[-8, 8, -8, 8, 0, 40], no_pol=no_pol, seed=seed)
+    RT.add(ot.RaySource(ot.RGBImage(scenes.synthetic_rgb_image(), [4, 3]), divergence="Isotropic",
+                        div_angle=np.rad2deg(np.arctan(3 / 12) * 1.2), s=[0, 0, 1], pos=[0, 0, 0],
+                        orientation="Converging", conv_pos=[0, 0, 12]))
+    RT.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1, pos=[0, 0, 12],
+                   n=ot.RefractionIndex("Abbe", n=1.5, V=40)))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[16, 16]), pos=[0, 0, 36]))
+    with ot.global_options.no_warnings():
+        RT.trace(N)
+    return RT
+
+
+@pytest.mark.parametrize("path", ["direct", "tiles", None])
+def test_fused_equals_two_step_extended_image(path):
+    RT = image_scene()
+    for extent in ([-8., 8., -8., 8.], [-2., 1., -1.5, 0.5], [-9., 9., -3., 3.]):  # whole, crop, ratio 3 image
+        with pinned(path):
+            fused = RT.detector_image(extent=extent)
+            two = RT.detector_image(extent=extent, _unfused=True)
+        same_image(fused, two)
+    # power inside the crop is what the hits inside carry
+    full = RT.detector_image(extent=[-8., 8., -8., 8.])
+    part = RT.detector_image(extent=[-2., 1., -1.5, 0.5])
+    assert 0 < part.power() < full.power()
+
+
+@pytest.mark.parametrize("path", ["direct", "tiles"])
+def test_fused_point_images_and_source_selection(path):
+    """Five PSF-like spots (double Gauss): everything lands in a few pixels; one source alone selects its ray range."""
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, seed=5)
+        RT.trace(300_000)
+        e4 = [float(v) for v in RT.detector_image(source_index=4)._extent0]  # where the spot of the last source lies
+        e0 = [float(v) for v in RT.detector_image(source_index=0)._extent0]
+        for kw in (dict(extent=[-45., 45., -45., 45.]), dict(extent=e4, source_index=4),
+                   dict(extent=e0, source_index=0, limit=5.)):
+            with pinned(path):
+                fused = RT.detector_image(**kw)
+                two = RT.detector_image(**kw, _unfused=True)
+            same_image(fused, two, tol=1e-9 if "limit" in kw else 1e-11)
+            assert fused.long_desc == two.long_desc
+
+
+@pytest.mark.parametrize("projection", ["Equidistant", "Orthographic", "Equal-Area", "Stereographic"])
+def test_fused_spherical_detector_projections(projection):
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -10, 40], seed=9)
+        RT.add(ot.RaySource(ot.CircularSurface(r=1.5), divergence="Lambertian", div_angle=25, pos=[0, 0, 0]))
+        RT.add(ot.Detector(ot.SphericalSurface(r=7.9, R=-8), pos=[0, 0, 12]))
+        RT.trace(200_000)
+        auto = RT.detector_image(projection_method=projection)
+        ext = [float(v) for v in auto._extent0]
+        for path in ("direct", "tiles"):
+            with pinned(path):
+                fused = RT.detector_image(extent=ext, projection_method=projection)
+                two = RT.detector_image(extent=ext, projection_method=projection, _unfused=True)
+            same_image(fused, two)
+            assert fused.projection == projection
+
+
+def test_fused_numeric_detector_and_no_hits():
+    """A tilted (numerically intersected) detector goes through the NUMERIC kernels; an extent without hits gives an
+    empty image instead of an error."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -10, 40], seed=11)
+        RT.add(ot.RaySource(ot.RectangularSurface(dim=[2, 1]), divergence="Isotropic", div_angle=8, pos=[0, 0, 0]))
+        RT.add(ot.Detector(ot.TiltedSurface(r=6, normal=[0.2, 0.1, 1]), pos=[0, 0, 20]))
+        RT.trace(150_000)
+        for path in ("direct", "tiles"):
+            with pinned(path):
+                fused = RT.detector_image(extent=[-6., 6., -6., 6.])
+                two = RT.detector_image(extent=[-6., 6., -6., 6.], _unfused=True)
+            same_image(fused, two)
+        empty = RT.detector_image(extent=[5.5, 5.9, 5.5, 5.9])
+        assert empty.power() == 0.0 and empty._data.shape == (945, 945, 4)
+
+
+@pytest.mark.parametrize("path", ["direct", "tiles", None])
+def test_iterative_render_positions_equal_single_images(path):
+    """Chunks after the first are binned by the fused kernels, up to 8 detector positions per pass: the result equals
+    images rendered position by position from the same chunks."""
+    N, step = 600_000, 200_000
+    pos = [[0, 0, 30.], [0, 0, 33.], [0, 0, 36.], [0.5, 0, 38.]]
+    ext = [[-8., 8., -8., 8.]] * 3 + [None]
+    with ot.global_options.no_warnings(), pinned(path):
+        RT = image_scene(N=1000, seed=21)
+        RT.ITER_RAYS_STEP = step
+        imgs = RT.iterative_render(N, pos=pos, extent=ext)
+        # the same chunks by hand: trace(chunk i), one detector_image per position, scaled sums (raytracer.py:1247-1267)
+        ref = [None] * len(pos)
+        extents = list(ext)
+        for i in range(N // step):
+            RT.trace(step, _chunk=i)
+            for j, p in enumerate(pos):
+                RT.detectors[0].move_to(p)
+                im = RT.detector_image(extent=extents[j], _unfused=True)
+                if i == 0:
+                    extents[j] = [float(v) for v in im._extent0]
+                    ref[j] = im._data * (step / N)
+                else:
+                    ref[j] = ref[j] + im._data * (step / N)
+    for j in range(len(pos)):
+        assert imgs[j]._data.shape == ref[j].shape
+        assert np.abs(imgs[j]._data - ref[j]).max() <= 1e-11 * np.abs(ref[j]).max()
+        assert abs(imgs[j].power() - ref[j][..., 3].sum()) <= 1e-11 * ref[j][..., 3].sum()

@@ -289,4 +289,7 @@ def test_discrete_spectrum_tables_equal_formula_path(name, no_pol):
     assert np.array_equal(msgs.cpu().numpy()[:-1].reshape(5, -1), msgs_fused)
     for k, t in fused.items():
         a, b = t.cpu().numpy(), RT.rays._dev[k].cpu().numpy()
-        assert np.array_equal(a, b, equal_nan=True), f"{k} differs between the LINES and the formula kernel"
+        if not np.array_equal(a, b, equal_nan=True):
+            bad = np.nonzero(~((a == b) | (np.isnan(a) & np.isnan(b))))[0]
+            raise AssertionError(f"{k} differs between the LINES and the formula kernel: {bad.shape[0]} of {a.shape[0]} "
+                                 f"entries, first at {bad[:8]}, values {a[bad[:4]]} vs {b[bad[:4]]}")

@@ -38,26 +38,36 @@ with ot.global_options.no_warnings():
     RT.trace(N)
     for ext in ([-8, 8, -8, 8], None):
         line(f"C4 detector_image extent={'user' if ext else 'auto'}", N, timeit(lambda: RT.detector_image(extent=ext, _keep_on_device=True)))
+    line("C4 detector_image extent=user, two-step chain (hits, then binning)", N,
+         timeit(lambda: RT.detector_image(extent=[-8, 8, -8, 8], _unfused=True)))
     line("C4 detector_spectrum", N, timeit(lambda: RT.detector_spectrum()))
     pos = [[0, 0, z] for z in (30, 32, 34, 36, 38, 39.5)]
-    RT.iterative_render(2_000_000, pos=pos[:1])
     for ext in ([[-8, 8, -8, 8]] * 6, None):
-        t0 = time.perf_counter()
-        RT.iterative_render(N, pos=pos, extent=ext)
+        RT.iterative_render(N, pos=pos, extent=ext)  # warm-up at full size: allocator pools, clocks
         torch.cuda.synchronize()
-        line(f"C4 iterative_render, 6 detector positions, extent={'user' if ext else 'auto'}", N, (time.perf_counter() - t0) * 1e3)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            RT.iterative_render(N, pos=pos, extent=ext)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        line(f"C4 iterative_render, 6 detector positions, extent={'user' if ext else 'auto'}", N, min(ts))
     del RT
     torch.cuda.empty_cache()
 
     RT, N = bc.c3(ot), 50_000_000
     RT.trace(N)
     line("C3 detector_image (spherical detector, Equidistant)", N, timeit(lambda: RT.detector_image(_keep_on_device=True)))
+    e3 = [float(v) for v in RT.detector_image()._extent0]
+    line("C3 detector_image, that extent given", N, timeit(lambda: RT.detector_image(extent=e3)))
     del RT
     torch.cuda.empty_cache()
 
     RT, N = scenes.hurb_slit_lens(ot, seed=51), 100_000_000
     RT.trace(N)
     line("C5 detector_image extent=auto", N, timeit(lambda: RT.detector_image(_keep_on_device=True)))
+    e5 = [float(v) for v in RT.detector_image()._extent0]
+    line("C5 detector_image, that extent given", N, timeit(lambda: RT.detector_image(extent=e5)))
     del RT
     torch.cuda.empty_cache()
 
