@@ -454,6 +454,10 @@ int ot_render_accumulate(int64_t n, const double* px, const double* py, const fl
 #define OT_IMG_CHROMA 7           /* :211  luv_chroma                                                   */
 #define OT_IMG_SATURATION 8       /* :216  luv_saturation                                               */
 
+/* added to an sRGB mode: color.xyz_to_srgb(normalize=False) / (clip=False), srgb.py:379-407 (used by convolve()) */
+#define OT_IMG_FLAG_NO_NORMALIZE 0x100
+#define OT_IMG_FLAG_NO_CLIP 0x200
+
 /* RenderImage.get (render_image.py:131-222): converts the (Ny, Nx, 4) float64 XYZW histogram into a display
  * quantity.  fact joins fact x fact bins first (the reference's cv2.resize INTER_AREA, :174; must divide Nx and
  * Ny).  apx = area of one ORIGINAL pixel, K = luminous efficacy.  chroma_scale = NaN selects the automatic value.

@@ -19,6 +19,7 @@ from .image import RGBImage, GrayscaleImage, ScalarImage
 from .render_image import RenderImage
 from .ray_storage import RayStorage
 from .raytracer import Raytracer
+from .convolve import convolve
 from . import presets, misc
 
 __version__ = "0.1.0"

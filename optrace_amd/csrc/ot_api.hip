@@ -1815,6 +1815,8 @@ extern "C" int ot_image_convert(const double* hist, int32_t Nx, int32_t Ny, int3
                                 double K, double L_th, double chroma_scale, double* out, double* workspace, void* stream) {
     if (!hist || !out || !workspace || Nx < 1 || Ny < 1 || fact < 1 || Nx % fact || Ny % fact)
         return fail(OT_ERR_INVALID, "ot_image_convert: bad argument");
+    const int flags = mode & (OT_IMG_FLAG_NO_NORMALIZE | OT_IMG_FLAG_NO_CLIP);
+    mode &= ~(OT_IMG_FLAG_NO_NORMALIZE | OT_IMG_FLAG_NO_CLIP);
     if (mode < OT_IMG_IRRADIANCE || mode > OT_IMG_SATURATION) return fail(OT_ERR_INVALID, "ot_image_convert: unknown mode");
     if (int rc = require_device()) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1854,7 +1856,7 @@ extern "C" int ot_image_convert(const double* hist, int32_t Nx, int32_t Ny, int3
         }
         hipLaunchKernelGGL(img_correct_kernel, grid, block, 0, st, img, npx, intent, cs, use_ones, red);
     }
-    hipLaunchKernelGGL(img_final_kernel, grid, block, 0, st, img, npx, mode, apx, K, red, out);
+    hipLaunchKernelGGL(img_final_kernel, grid, block, 0, st, img, npx, mode | flags, apx, K, red, out);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

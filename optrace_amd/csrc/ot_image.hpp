@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256) void img_final_kernel(const double* __restrict
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npx) return;
     const double X = img[i * 4], Y = img[i * 4 + 1], Z = img[i * 4 + 2], W = img[i * 4 + 3];
+    const bool normalize = !(mode & OT_IMG_FLAG_NO_NORMALIZE), clip = !(mode & OT_IMG_FLAG_NO_CLIP);
+    mode &= ~(OT_IMG_FLAG_NO_NORMALIZE | OT_IMG_FLAG_NO_CLIP);
     switch (mode) {
         case OT_IMG_IRRADIANCE: out[i] = 1 / apx * W; return;
         case OT_IMG_ILLUMINANCE: out[i] = K / apx * Y; return;
@@ -247,15 +249,17 @@ __global__ __launch_bounds__(256) void img_final_kernel(const double* __restrict
             double r, g, b;
             to_rgbl(X, Y, Z, r, g, b);
             double nmax = red[OT_RED_RGBMAX2];
-            if (nmax != 0 && !isnan(nmax) && isfinite(nmax)) {  // `if normalize and (nmax := np.nanmax(RGBL_))`
+            if (normalize && nmax != 0 && !isnan(nmax) && isfinite(nmax)) {  // `if normalize and (nmax := np.nanmax(RGBL_))`
                 double s = 1 / nmax;
                 r *= s;
                 g *= s;
                 b *= s;
             }
-            r = fmin(fmax(r, 0.0), 1.0);
-            g = fmin(fmax(g, 0.0), 1.0);
-            b = fmin(fmax(b, 0.0), 1.0);
+            if (clip) {  // color.xyz_to_srgb srgb.py:403-404
+                r = fmin(fmax(r, 0.0), 1.0);
+                g = fmin(fmax(g, 0.0), 1.0);
+                b = fmin(fmax(b, 0.0), 1.0);
+            }
             out[i * 3 + 0] = srgb_gamma(r);
             out[i * 3 + 1] = srgb_gamma(g);
             out[i * 3 + 2] = srgb_gamma(b);

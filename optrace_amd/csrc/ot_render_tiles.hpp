@@ -217,11 +217,13 @@ __global__ __launch_bounds__(1024) void tile_accum_kernel(TileArgs t, const doub
         const double wm = (double)rec.w;
         double xo, yo, zo;
         observer_xyz_at(obs, (double)rec.wl, xo, yo, zo);
-        double* hv = tile + 4 * (int)rec.px;
-        unsafeAtomicAdd(hv + 0, xo * wm);
-        unsafeAtomicAdd(hv + 1, yo * wm);
-        unsafeAtomicAdd(hv + 2, zo * wm);
-        unsafeAtomicAdd(hv + 3, 1.0 * wm);
+        // plane-major tile [channel][pixel]: the lanes of one add spread over 16 bank pairs (with 4 doubles per pixel
+        // they share 4, a 16-way bank conflict on every add)
+        double* hv = tile + (int)rec.px;
+        unsafeAtomicAdd(hv + 0 * OT_TILE_PX, xo * wm);
+        unsafeAtomicAdd(hv + 1 * OT_TILE_PX, yo * wm);
+        unsafeAtomicAdd(hv + 2 * OT_TILE_PX, zo * wm);
+        unsafeAtomicAdd(hv + 3 * OT_TILE_PX, 1.0 * wm);
     }
     __syncthreads();
     double* slab = wk.slabs + (size_t)c * (OT_TILE_PX * 4);
@@ -240,11 +242,11 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(TileArgs t, TileWork w
     if (ix >= t.a.Nx || iy >= t.a.Ny) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int c = c0; c < c1; c++) {
-        const double4 v = *(const double4*)(wk.slabs + (size_t)c * (OT_TILE_PX * 4) + 4 * local);
-        s0 += v.x;
-        s1 += v.y;
-        s2 += v.z;
-        s3 += v.w;
+        const double* sl = wk.slabs + (size_t)c * (OT_TILE_PX * 4) + local;  // plane-major slab
+        s0 += sl[0 * OT_TILE_PX];
+        s1 += sl[1 * OT_TILE_PX];
+        s2 += sl[2 * OT_TILE_PX];
+        s3 += sl[3 * OT_TILE_PX];
     }
     double* hg = hist + ((int64_t)iy * t.a.Nx + ix) * 4;
     hg[0] += s0;

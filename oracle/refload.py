@@ -48,6 +48,16 @@ def load(seed: int | None = None):
     if "cv2" not in sys.modules:
         cv2 = types.ModuleType("cv2")
         cv2.INTER_AREA = 3
+
+        def resize(src, dsize, interpolation=None):
+            """The one call on a numeric path (convolve.py:335, PSF -> image pixel pitch): the fixtures use PSFs
+            that already have the image's pitch, where OpenCV returns a copy.  Anything else is not reproduced
+            here -- no stand-in arithmetic enters a golden vector."""
+            if tuple(int(v) for v in dsize) != (src.shape[1], src.shape[0]):
+                raise NotImplementedError("cv2.resize stand-in: equal sizes only")
+            return src.copy()
+
+        cv2.resize = resize
         sys.modules["cv2"] = cv2
     if "chardet" not in sys.modules:
         sys.modules["chardet"] = types.ModuleType("chardet")

@@ -28,6 +28,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 import refload  # noqa: E402
 import scenes  # noqa: E402
+from convolve_cases import convolve_cases, build_convolve_inputs  # noqa: E402
 
 ot = refload.load(0)
 
@@ -446,8 +447,27 @@ def gen_render_image_file():
     print("render_image_ref.npz", img._data.shape, img.power())
 
 
+def gen_convolve():
+    """convolve() (convolve.py:49-454) on synthetic images and PSFs: every 4th result pixel, sums and extents."""
+    out = {}
+    for name, case in convolve_cases().items():
+        img, psf = build_convolve_inputs(ot, case)
+        res = ot.convolve(img, psf, m=case["m"], **case["kwargs"])
+        d = res.data
+        out[f"{name}/img"], out[f"{name}/psf"] = case["img"], case["psf"]
+        out[f"{name}/shape"] = np.array(d.shape)
+        out[f"{name}/extent"] = np.array(res.extent)
+        out[f"{name}/grid4"] = d[1::4, 2::4].astype(np.float64)
+        out[f"{name}/sum"] = d.sum(axis=(0, 1))
+        out[f"{name}/max"] = d.max(axis=(0, 1))
+    np.savez_compressed(HERE / "convolve.npz", **out)
+    print("convolve.npz", len(out))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["leaf", "leaf2", "media", "trace", "trace2", "sources", "images", "spectra", "focus", "file"]
+    if "convolve" in which:
+        gen_convolve()
     if "leaf" in which:
         gen_leaf_surfaces()
     if "leaf2" in which:
