@@ -1190,9 +1190,14 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
     // kernel variant: polarisation x on-device generation x spectrum handling x feature set
     const bool tab = sc->needs_tables || hurb_normals != nullptr;
     const int feat = sc->needs_numeric ? 2 : (sc->needs_full ? 1 : 0);
-    const bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr;  // generated rays only
-    const size_t lds = sizeof(unsigned int) * (size_t)n_cnt +
-                       (lines ? sizeof(double) * (size_t)(3 * sc->h.n_steps + 2) * OT_MAX_LINES : 0) + 8;
+    bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr;  // generated rays only
+    // dynamic LDS: the counter table, and with discrete spectra the per-line tables (3 rows per step).  Very long
+    // stacks do not fit the 64 KB a kernel gets without asking: the formula kernels (SPEC 0 / 1) trace those.
+    const size_t lds_cnt = sizeof(unsigned int) * (size_t)n_cnt + 8;
+    const size_t lds_lines = sizeof(double) * (size_t)(3 * sc->h.n_steps + 2) * OT_MAX_LINES;
+    if (lds_cnt > 60000) return fail(OT_ERR_UNSUPPORTED, "ot_trace: more than ~3000 tracing surfaces in one scene");
+    if (lines && lds_cnt + lds_lines > 60000) lines = false;
+    const size_t lds = lds_cnt + (lines ? lds_lines : 0);
     unsigned int* slots = sc->cnt_slots;
     if (sc->timing) HIP_TRY(hipEventRecord(sc->ev0, st));
     // lanes address their ray with 32-bit byte offsets: launches of at most 2^28 rays, base pointers advanced

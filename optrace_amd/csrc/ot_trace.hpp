@@ -118,6 +118,11 @@ OT_DEV void refraction_polarization(const V3& n, const V3& s, const V3& s_, doub
     V3 m = cross3(n, s);
     V3 pol = {(double)r.polx, (double)r.poly, (double)r.polz};
     double mm = dot3(m, m), mp = dot3(m, pol), sp = dot3(s, pol), np_ = dot3(n, pol);
+    // n and s exactly parallel (a collimated beam along a face normal) while s' still differs from s by rounding:
+    // the plane of incidence is undefined (m = 0, 1 / mm not finite).  The reference builds its basis from the
+    // rounding noise s' x s and gets A_ts^2 + A_tp^2 = |pol|^2 with ts = tp, i.e. the normal-incidence transmission
+    // and an unchanged pol -- which is the unchanged-direction branch.
+    if (!(mm > 0)) mask = false;
     double inv = fast_rcp(mm);
     double tp = ns * sp - np_;   // A_tp |m|
     double ct = N - q * ns;      // s . s'

@@ -1,11 +1,16 @@
 """Scene elements: Element, Lens, IdealLens, Aperture, Filter, Detector and Group.
 
-Host-side mirror of optrace/tracer/geometry/{element,lens,ideal_lens,aperture,filter,detector,group}.py.
-These objects only hold and validate geometry; `optrace_amd.scene.compile_scene` flattens them into
-the plain descriptor tables the device kernels read.
+Host-side counterpart of optrace/tracer/geometry/{element,lens,ideal_lens,aperture,filter,detector,group}.py: the
+same constructors, attributes and error texts, written around what this package needs from them --
+elements validate geometry and hand `optrace_amd.scene.CompiledScene` the surfaces to flatten into descriptor tables.
+
+An element owns private copies of its surfaces and keeps them consistent: the reference position of a two-surface
+element lies d1 behind the front vertex and d2 before the back vertex, so every move, flip or surface exchange goes
+through the element (direct assignment of front / back / d1 / d2 / pos is refused once it is built).
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Any
 
 import numpy as np
@@ -16,6 +21,19 @@ from ..spectrum import TransmissionSpectrum
 from .._warn import warning
 from .surfaces import Surface, Point, Line, CircularSurface, AsphericSurface
 
+_GUARDED = {"d1": "surface", "d2": "surface", "front": "surface", "surface": "surface", "back": "surface", "pos": "pos"}
+_GUARD_TEXT = {"surface": "Use Functions set_surface to reassign a new Surface or its thickness.",
+               "pos": "Use move_to(pos) to move the object"}
+
+
+def _position(pos, text: str) -> np.ndarray:
+    """A finite [x, y, z] as float64 array, or the errors the reference raises for it."""
+    check_type("pos", pos, (list, np.ndarray))
+    arr = np.asarray_chkfinite(pos, dtype=np.float64)
+    if arr.shape[0] != 3:
+        raise ValueError(text)
+    return arr
+
 
 class Element(BaseClass):
     """Object with a front and an optional back surface (element.py:38-237)."""
@@ -24,42 +42,46 @@ class Element(BaseClass):
     _allow_non_2D = True
 
     def __init__(self, front, pos, back=None, d1: float = None, d2: float = None, **kwargs) -> None:
-        self._geometry_lock = False
-        self.front = front
-        self.back = back
-        self.d1 = d1
-        self.d2 = d2
-        if self.has_back():
-            if d1 is None or d2 is None:
+        self._sealed = False  # True: geometry attributes change through methods only
+        self.front, self.back = front, back
+        self.d1, self.d2 = d1, d2
+        if back is not None:
+            if None in (d1, d2):
                 raise ValueError("d1 and d2 need to be specified for a Element with a back surface")
-            if d1 < 0 or d2 < 0:
+            if min(d1, d2) < 0:
                 raise ValueError(f"Thicknesses d1, d2 need to be non-negative but are {d1=} and {d2=}.")
         self.move_to(pos)
-        super().__init__(**kwargs)
-        self._geometry_lock = True
+        BaseClass.__init__(self, **kwargs)
+        self._sealed = True
+
+    @contextlib.contextmanager
+    def _open(self):
+        """Geometry attributes may be assigned inside this block."""
+        self._sealed = False
+        try:
+            yield
+        finally:
+            self._sealed = True
 
     def has_back(self) -> bool:
         return self.back is not None
 
     def set_surface(self, surf: Surface) -> None:
-        if self.has_back():
+        if self.back is not None:
             raise RuntimeError("Replacing of Surfaces only supported for objects with one surface")
-        self._geometry_lock = False
-        pos = self.front.pos
-        self.front = surf.copy()
-        self.front.move_to(pos)
-        self._geometry_lock = True
+        where = self.front.pos
+        with self._open():
+            self.front = surf  # (copied on assignment)
+            self.front.move_to(where)
 
     def move_to(self, pos) -> None:
-        check_type("pos", pos, (list, np.ndarray))
-        pos = np.asarray_chkfinite(pos, dtype=np.float64)
-        if pos.shape[0] != 3:
-            raise ValueError("pos needs to have 3 elements.")
-        if not self.has_back():
-            self.front.move_to(pos)
-        else:
-            self.front.move_to(pos - [0, 0, self.d1])
-            self.back.move_to(pos + [0, 0, self.d2])
+        target = _position(pos, "pos needs to have 3 elements.")
+        if self.back is None:
+            self.front.move_to(target)
+            return
+        dz = np.array([0., 0., 1.])
+        self.front.move_to(target - self.d1 * dz)
+        self.back.move_to(target + self.d2 * dz)
 
     @property
     def surface(self):
@@ -67,58 +89,76 @@ class Element(BaseClass):
 
     @property
     def pos(self) -> np.ndarray:
-        return self.front.pos + [0, 0, 0 if not self.has_back() else self.d1]
+        p = np.array(self.front.pos, dtype=np.float64)
+        if self.back is not None:
+            p[2] += self.d1
+        return p
 
     @property
     def extent(self) -> tuple:
-        if not self.has_back():
+        if self.back is None:
             return self.front.extent
-        ext = np.zeros(6, dtype=np.float64)
-        exts = np.column_stack((self.front.extent, self.back.extent))
-        ext[[0, 2, 4]] = np.min(exts, axis=1)[[0, 2, 4]]
-        ext[[1, 3, 5]] = np.max(exts, axis=1)[[1, 3, 5]]
-        return tuple(ext)
+        f, b = np.asarray(self.front.extent), np.asarray(self.back.extent)
+        lo, hi = np.minimum(f, b), np.maximum(f, b)
+        return tuple(np.where([True, False] * 3, lo, hi))
 
     def get_desc(self, fallback: str = None) -> str:
-        s1 = type(self.front).__name__
-        if self.has_back():
-            fallback = f"{s1} + {type(self.back).__name__}, z = {self.pos[2]:.04g}"
-        else:
-            fallback = f"{s1}, z = {self.pos[2]:.04g}"
-        return super().get_desc(fallback)
+        kinds = type(self.front).__name__ + (f" + {type(self.back).__name__}" if self.back is not None else "")
+        return BaseClass.get_desc(self, f"{kinds}, z = {self.pos[2]:.04g}")
 
     def flip(self) -> None:
-        if self.has_back():
-            self._geometry_lock = False
-            self.back.flip()
+        """Turn the element around an axis parallel to x through its position."""
+        if self.back is None:
             self.front.flip()
-            zp = self.pos[2]
-            self.front.move_to([*self.front.pos[:2], zp + self.d1])
-            self.back.move_to([*self.back.pos[:2], zp - self.d2])
-            self.front, self.back = self.back, self.front
-            self.d1, self.d2 = self.d2, self.d1
-            self._geometry_lock = True
-        else:
-            self.front.flip()
+            return
+        z = self.pos[2]
+        with self._open():
+            for s in (self.front, self.back):
+                s.flip()
+            # the old back surface becomes the front and vice versa, vertex distances swap with them
+            self.front.move_to([self.front.pos[0], self.front.pos[1], z + self.d1])
+            self.back.move_to([self.back.pos[0], self.back.pos[1], z - self.d2])
+            old_front, old_d1 = self.front, self.d1
+            BaseClass.__setattr__(self, "front", self.back)  # (both are this element's own copies already)
+            BaseClass.__setattr__(self, "back", old_front)
+            self.d1, self.d2 = self.d2, old_d1
 
     def rotate(self, angle: float) -> None:
-        self.front.rotate(angle)
-        if self.has_back():
-            self.back.rotate(angle)
+        for s in (self.front, self.back):
+            if s is not None:
+                s.rotate(angle)
 
     def __setattr__(self, key: str, val: Any) -> None:
-        if self.__dict__.get("_geometry_lock", False):
-            if key in ("d1", "d2", "front", "surface", "back"):
-                raise RuntimeError("Use Functions set_surface to reassign a new Surface or its thickness.")
-            if key == "pos":
-                raise RuntimeError("Use move_to(pos) to move the object")
-        if key == "front" or (key == "back" and val is not None):
+        if key in _GUARDED and self.__dict__.get("_sealed", False):
+            raise RuntimeError(_GUARD_TEXT[_GUARDED[key]])
+        if key in ("front", "back") and val is not None:
             check_type(key, val, (Surface, Point, Line) if self._allow_non_2D else Surface)
             val = val.copy()  # elements own private copies of their surfaces (element.py:223-231)
         elif key in ("d1", "d2") and val is not None:
             check_type(key, val, (int, float))
             val = float(val)
-        super().__setattr__(key, val)
+        BaseClass.__setattr__(self, key, val)
+
+
+def _lens_thicknesses(front, back, de, d, d1, d2):
+    """(d1, d2) of a lens from whichever thickness the caller gave (lens.py:58-86): the centre thickness d, the gap
+    de between the z ranges of the surfaces (default 0), or d1 and d2 themselves.  A centre thickness (or a negative
+    gap) that makes the z ranges overlap is split evenly."""
+    d1 = None if d1 is None else float(d1)
+    d2 = None if d2 is None else float(d2)
+    if not (isinstance(front, Surface) and isinstance(back, Surface)):
+        return d1, d2  # the type error comes from the assignment in Element
+    if d is not None:
+        de = d - front.dp - back.dn
+        if de < 0:
+            return d / 2, d / 2
+    if de is not None and d1 is None and d2 is None:
+        if de < 0:
+            return -de / 2, -de / 2
+        return front.dp + de / 2., back.dn + de / 2.
+    if None in (d1, d2):
+        raise ValueError("Both thicknesses d1, d2 need to be specified")
+    return d1, d2
 
 
 class Lens(Element):
@@ -131,44 +171,27 @@ class Lens(Element):
     def __init__(self, front: Surface, back: Surface, n: RefractionIndex, pos, de: float = 0,
                  d: float = None, d1: float = None, d2: float = None, n2: RefractionIndex = None,
                  **kwargs) -> None:
-        self.n = n
-        self.n2 = n2
-        d1 = float(d1) if d1 is not None else d1
-        d2 = float(d2) if d2 is not None else d2
-
-        if isinstance(front, Surface) and isinstance(back, Surface):
-            if d is not None:
-                de = d - front.dp - back.dn
-                if de < 0:  # overlapping z extents: split the centre thickness evenly
-                    d1 = d / 2
-                    d2 = d / 2
-            if de is not None and d1 is None and d2 is None:
-                if de < 0:
-                    d1 = -de / 2
-                    d2 = -de / 2
-                else:
-                    d1 = de / 2. + front.dp
-                    d2 = de / 2. + back.dn
-            elif d1 is None or d2 is None:
-                raise ValueError("Both thicknesses d1, d2 need to be specified")
-
-        super().__init__(front, pos, back, d1, d2, **kwargs)
+        self.n, self.n2 = n, n2
+        d1, d2 = _lens_thicknesses(front, back, de, d, d1, d2)
+        Element.__init__(self, front, pos, back, d1, d2, **kwargs)
         self._new_lock = True
 
     @property
     def d(self) -> float:
+        """Thickness at the optical axis."""
         return self.d1 + self.d2
 
     @property
     def de(self) -> float:
-        return float(self.back.z_min - self.front.z_max)
+        """Gap between the z ranges of the two surfaces (negative if they overlap)."""
+        return float(self.back.z_min) - float(self.front.z_max)
 
     def __setattr__(self, key, val):
-        if key == "n2":
-            check_type(key, val, (RefractionIndex, type(None)))
         if key == "n":
             check_type(key, val, RefractionIndex)
-        super().__setattr__(key, val)
+        elif key == "n2":
+            check_type(key, val, (RefractionIndex, type(None)))
+        Element.__setattr__(self, key, val)
 
 
 class IdealLens(Lens):
@@ -179,87 +202,81 @@ class IdealLens(Lens):
     def __init__(self, r: float, D: float, pos, n2: RefractionIndex = None, **kwargs) -> None:
         check_type("D", D, (int, float))
         np.asarray_chkfinite(D)
-        self.D = float(D)
-        if not D:
+        if D == 0:
             raise ValueError("Optical Power needs to be non-zero")
-        super().__init__(front=CircularSurface(r=r), back=CircularSurface(r=r),
-                         n=RefractionIndex("Constant", n=1), pos=pos, d=0, n2=n2, **kwargs)
+        self.D = float(D)
+        disc = CircularSurface(r=r)
+        Lens.__init__(self, disc, disc, RefractionIndex("Constant", n=1), pos, d=0, n2=n2, **kwargs)
 
 
-class Aperture(Element):
-    """Absorbing surface (aperture.py:8-26)."""
+class _SingleSurface(Element):
+    """Elements made of one 2-D surface."""
 
-    abbr = "AP"
     _allow_non_2D = False
 
     def __init__(self, surface: Surface, pos, **kwargs) -> None:
-        super().__init__(surface, pos, **kwargs)
+        Element.__init__(self, surface, pos, **kwargs)
         self._new_lock = True
 
 
-class Filter(Element):
+class Aperture(_SingleSurface):
+    """Absorbing surface (aperture.py:8-26)."""
+
+    abbr = "AP"
+
+
+class Filter(_SingleSurface):
     """Surface with a transmission spectrum (filter.py:11-63)."""
 
     abbr = "F"
-    _allow_non_2D = False
 
     def __init__(self, surface: Surface, pos, spectrum: TransmissionSpectrum, **kwargs) -> None:
-        super().__init__(surface, pos, **kwargs)
         self.spectrum = spectrum
-        self._new_lock = True
+        _SingleSurface.__init__(self, surface, pos, **kwargs)
 
     def __call__(self, wl: np.ndarray) -> np.ndarray:
+        """Transmission at the wavelengths wl."""
         return self.spectrum(wl)
 
     def __setattr__(self, key, val):
         if key == "spectrum":
             check_type(key, val, TransmissionSpectrum)
-        super().__setattr__(key, val)
+        Element.__setattr__(self, key, val)
 
 
-class Detector(Element):
+class Detector(_SingleSurface):
     """Surface on which images are rendered (detector.py:11-43)."""
 
     abbr = "DET"
-    _allow_non_2D = False
-
-    def __init__(self, surface: Surface, pos, **kwargs) -> None:
-        super().__init__(surface, pos, **kwargs)
-        self._new_lock = True
 
     def __setattr__(self, key, val):
         if key == "front" and isinstance(val, AsphericSurface):
             raise RuntimeError("Function-defined surfaces are not supported as Detector surfaces.")
-        super().__setattr__(key, val)
+        Element.__setattr__(self, key, val)
 
 
 class Group(BaseClass):
     """Container of elements with an ambient index n0 (group.py:18-308)."""
 
+    _LISTS = ("lenses", "apertures", "filters", "ray_sources", "detectors", "markers", "volumes")
+
     def __init__(self, elements: list = None, n0: RefractionIndex = None, **kwargs) -> None:
-        self.lenses: list = []
-        self.apertures: list = []
-        self.filters: list = []
-        self.detectors: list = []
-        self.ray_sources: list = []
-        self.markers: list = []
-        self.volumes: list = []
+        for name in self._LISTS:
+            BaseClass.__setattr__(self, name, [])
         self.n0 = n0
-        super().__init__(**kwargs)
+        BaseClass.__init__(self, **kwargs)
         if elements is not None:
             self.add(elements)
 
     def __setattr__(self, key, val):
         if key == "n0":
-            if val is None:
-                val = RefractionIndex("Constant", n=1)
+            val = RefractionIndex("Constant", n=1) if val is None else val
             check_type(key, val, RefractionIndex)
-        super().__setattr__(key, val)
+        BaseClass.__setattr__(self, key, val)
 
     @property
     def _elements(self) -> list:
-        return [*self.lenses, *self.apertures, *self.filters, *self.ray_sources, *self.detectors,
-                *self.markers, *self.volumes]
+        return [el for name in self._LISTS for el in getattr(self, name)]
 
     @property
     def elements(self) -> list:
@@ -268,116 +285,111 @@ class Group(BaseClass):
 
     @property
     def pos(self):
-        return self.elements[0].pos if len(self._elements) else [0, 0, 0]
+        """Position of the first element along z; the origin for an empty group."""
+        els = self.elements
+        return els[0].pos if els else [0, 0, 0]
 
     @property
     def tracing_surfaces(self) -> list:
-        """Front/back surfaces of lenses, filters and apertures in z order (group.py:84-98)."""
-        surfs = []
+        """Front/back surfaces of lenses, filters and apertures in z order (group.py:84-98); an ideal lens counts
+        once."""
+        out = []
         for el in self.elements:
-            if isinstance(el, (Lens, Filter, Aperture)):
-                surfs.append(el.front)
-                if el.has_back() and not isinstance(el, IdealLens):
-                    surfs.append(el.back)
-        return surfs
+            if not isinstance(el, (Lens, Filter, Aperture)):
+                continue
+            out.append(el.front)
+            if el.back is not None and not getattr(el, "is_ideal", False):
+                out.append(el.back)
+        return out
 
     @property
     def extent(self) -> tuple:
-        els = self._elements
-        if not len(els):
+        boxes = np.array([el.extent for el in self._elements], dtype=np.float64).reshape(-1, 6)
+        if not boxes.shape[0]:
             return 0, 0, 0, 0, 0, 0
-        ext = np.array([np.array(el.extent) for el in els])
-        mx, mn = np.max(ext, axis=0), np.min(ext, axis=0)
-        return mn[0], mx[1], mn[2], mx[3], mn[4], mx[5]
+        lo, hi = boxes.min(axis=0), boxes.max(axis=0)
+        return lo[0], hi[1], lo[2], hi[3], lo[4], hi[5]
 
     def move_to(self, pos) -> None:
-        check_type("pos", pos, (list, np.ndarray))
-        pos = np.asarray_chkfinite(pos, dtype=np.float64)
-        if pos.shape[0] != 3:
-            raise ValueError("pos needs to have exactly 3 elements.")
-        pos0 = self.pos
+        """Shift all elements so that the group's position becomes `pos`."""
+        shift = _position(pos, "pos needs to have exactly 3 elements.") - self.pos
         for el in self._elements:
-            el.move_to(el.pos - (pos0 - pos))
+            el.move_to(el.pos + shift)
 
     def rotate(self, angle: float, x0: float = 0, y0: float = 0) -> None:
-        if not len(self._elements):
-            return
-        ang = np.deg2rad(angle)
+        """Rotate the group by `angle` degrees around the axis through (x0, y0) parallel to z."""
+        c, s = np.cos(np.deg2rad(angle)), np.sin(np.deg2rad(angle))
         for el in self.elements:
-            xr, yr = el.pos[0] - x0, el.pos[1] - y0
-            posr = [x0 + xr * np.cos(ang) - yr * np.sin(ang), y0 + xr * np.sin(ang) + yr * np.cos(ang), el.pos[2]]
+            x, y, z = el.pos
             el.rotate(angle)
-            el.move_to(posr)
+            el.move_to([x0 + c * (x - x0) - s * (y - y0), y0 + s * (x - x0) + c * (y - y0), z])
 
     def flip(self, y0: float = 0, z0: float = None) -> None:
-        if not len(self._elements):
+        """Turn the group around the axis through (y0, z0) parallel to x (z0: middle of the z extent).  The media
+        between the lenses reverse their order with the elements."""
+        order = self.elements
+        if not order:
             return
-        els = self.elements
-        ns = [self.n0] + [L.n2 for L in els if isinstance(L, Lens)]
-        z0 = np.mean(self.extent[4:]) if z0 is None else z0
+        media = [self.n0] + [el.n2 for el in order if isinstance(el, Lens)]
+        zc = 0.5 * (self.extent[4] + self.extent[5]) if z0 is None else z0
         self.clear()
-        els.reverse()
-        self.add(els)
-        for el in els:
+        self.add(order[::-1])
+        for el in order:
+            x, y, z = el.pos
             el.flip()
-            el.move_to([el.pos[0], y0 - (el.pos[1] - y0), z0 - (el.pos[2] - z0)])
-        ns.reverse()
-        ns = [n if n is not None else self.n0 for n in ns]
-        self.n0 = ns[0]
-        for n2, L in zip(ns[1:], self.lenses):
-            L.n2 = n2
+            el.move_to([x, 2 * y0 - y, 2 * zc - z])
+        media = [self.n0 if n is None else n for n in media[::-1]]
+        self.n0 = media[0]
+        for lens, n2 in zip(self.lenses, media[1:]):
+            lens.n2 = n2
+
+    def _list_for(self, el):
+        from .ray_source import RaySource
+        for cls, name in ((Aperture, "apertures"), (Filter, "filters"), (RaySource, "ray_sources"),
+                          (Detector, "detectors"), (Lens, "lenses")):
+            if isinstance(el, cls):
+                return getattr(self, name)
+        return None
 
     def add(self, el) -> None:
-        from .ray_source import RaySource
+        """Add an element, a list of elements or the elements of another Group (whose ambient index is taken over)."""
         touch()
-        if not isinstance(el, list) and self.has(el):
+        if isinstance(el, list):
+            for item in el:
+                self.add(item)
+            return
+        if self.has(el):
             warning("Element already included in geometry. Make a copy to include it another time.")
             return
-        if isinstance(el, Aperture):
-            self.apertures.append(el)
-        elif isinstance(el, Filter):
-            self.filters.append(el)
-        elif isinstance(el, RaySource):
-            self.ray_sources.append(el)
-        elif isinstance(el, Detector):
-            self.detectors.append(el)
-        elif isinstance(el, Lens):
-            self.lenses.append(el)
-        elif isinstance(el, Group):
-            if self.n0 != el.n0:
+        if isinstance(el, Group):
+            if el.n0 != self.n0:
                 warning("Overwriting ambient index with index from new Group.")
                 self.n0 = el.n0
-            for eli in el.elements:
-                self.add(eli)
-        elif isinstance(el, list):
-            for eli in el:
-                self.add(eli)
-        else:
+            self.add(el.elements)
+            return
+        target = self._list_for(el)
+        if target is None:
             raise TypeError(f"Unsupported element type {type(el).__name__}.")
+        target.append(el)
 
     def remove(self, el) -> bool:
+        """Remove an element (by identity), a list of elements or a Group's elements; True if anything was removed."""
         touch()
-        success = False
-        if isinstance(el, list):
-            for eli in el.copy():
-                success = self.remove(eli) or success
-        elif isinstance(el, Group):
-            for eli in el._elements.copy():
-                success = self.remove(eli) or success
-        else:
-            for lst in (self.lenses, self.apertures, self.detectors, self.volumes, self.filters,
-                        self.ray_sources, self.markers):
-                for lel in lst.copy():
-                    if lel is el:
-                        lst.remove(lel)
-                        success = True
-        return success
+        if isinstance(el, (list, Group)):
+            items = list(el) if isinstance(el, list) else el._elements
+            return any([self.remove(item) for item in items])
+        found = False
+        for name in self._LISTS:
+            lst = getattr(self, name)
+            kept = [x for x in lst if x is not el]
+            found = found or len(kept) != len(lst)
+            lst[:] = kept
+        return found
 
     def has(self, el) -> bool:
-        return any(eli is el for eli in self._elements)
+        return any(x is el for x in self._elements)
 
     def clear(self) -> None:
         touch()
-        for lst in (self.lenses, self.apertures, self.filters, self.detectors, self.ray_sources,
-                    self.markers, self.volumes):
-            lst[:] = []
+        for name in self._LISTS:
+            getattr(self, name)[:] = []

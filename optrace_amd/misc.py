@@ -1,65 +1,76 @@
-"""Small host-side vector helpers with the reference's names (optrace/tracer/misc.py).
+"""Small host-side vector helpers under the reference's names (optrace/tracer/misc.py:9-168).
 
-They serve post-processing on host copies (RayStorage.rays_by_mask etc.); the device kernels carry
-their own inlined versions.
+Only post-processing on host copies uses them (RayStorage.rays_by_mask, user scripts); the device kernels carry
+their own versions (csrc/ot_device.hpp: dot3, cross3, normalize3).
 """
-from __future__ import annotations
-
 import os
 
 import numpy as np
 
 
 def cpu_count() -> int:
-    """Logical CPU count, overridable with PYTHON_CPU_COUNT in 1..64 (misc.py:9-32)."""
-    count = os.process_cpu_count() if hasattr(os, "process_cpu_count") else os.cpu_count()
-    count = count or 1
-    if "PYTHON_CPU_COUNT" in os.environ:
-        count = int(os.environ["PYTHON_CPU_COUNT"])
-    if not (1 <= count <= 64):
-        raise RuntimeError(f"Invalid core count {count}, must be between 1 and 64.")
-    return count
+    """Cores the process may use; PYTHON_CPU_COUNT (1..64) overrides the detected number."""
+    detected = getattr(os, "process_cpu_count", os.cpu_count)() or 1
+    n = int(os.environ.get("PYTHON_CPU_COUNT", detected))
+    if n < 1 or n > 64:
+        raise RuntimeError(f"Invalid core count {n}, must be between 1 and 64.")
+    return n
+
+
+def _rows(a: np.ndarray, cols: tuple) -> np.ndarray:
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] not in cols:
+        raise RuntimeError("Invalid number of dimensions.")
+    return a
 
 
 def rdot(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """Row-wise scalar product for (N, 2) or (N, 3) arrays (misc.py:94-118).
+    """Scalar product of each row of a with the same row of b; rows have two or three components.
 
-    >>> rdot(np.array([[1., 2., 3.], [4., 5., 6.]]), np.array([[-1., 2., -3.], [7., 8., 9.]]))
-    array([ -6., 122.])
+    >>> rdot(np.array([[1., 2., 3.], [4., 5., 6.]]), np.array([[0., 1., 0.], [1., 1., 1.]]))
+    array([ 2., 15.])
     """
-    if a.shape[1] == 3:
-        return a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1] + a[:, 2] * b[:, 2]
-    if a.shape[1] == 2:
-        return a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]
-    raise RuntimeError("Invalid number of dimensions.")
+    a, b = _rows(a, (2, 3)), np.asarray(b)
+    acc = a[:, 0] * b[:, 0]
+    for c in range(1, a.shape[1]):  # left to right, like the spelled-out sum of the reference
+        acc = acc + a[:, c] * b[:, c]
+    return acc
 
 
 def masked_assign(cond1: np.ndarray, cond2: np.ndarray) -> np.ndarray:
-    """Write cond2 into the True positions of cond1 (misc.py:120-133).
+    """cond1 with its True entries replaced, in order, by the entries of cond2.
 
-    >>> masked_assign(np.array([True, False, False, True]), np.array([True, False]))
-    array([ True, False, False, False])
+    >>> masked_assign(np.array([False, True, True, False, True]), np.array([True, False, True]))
+    array([False,  True, False, False,  True])
     """
-    out = np.zeros_like(cond1)
-    out[cond1] = cond2
-    return out
+    res = np.zeros(cond1.shape, dtype=bool)
+    res[np.flatnonzero(cond1)] = cond2
+    return res
 
 
 def normalize(a: np.ndarray) -> np.ndarray:
-    """Unit vectors along axis 1; zero vectors give NaN (misc.py:136-150)."""
-    with np.errstate(invalid="ignore"):
-        return a / np.sqrt(a[:, 0] ** 2 + a[:, 1] ** 2 + a[:, 2] ** 2)[:, np.newaxis]
+    """Rows of an (N, 3) array scaled to unit length; a zero row becomes NaN (no warning).
+
+    >>> normalize(np.array([[3., 0., 4.], [0., 0., 0.]]))
+    array([[0.6, 0. , 0.8],
+           [nan, nan, nan]])
+    """
+    a = _rows(a, (3,))
+    length = np.sqrt(a[:, 0] ** 2 + a[:, 1] ** 2 + a[:, 2] ** 2)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return a / length[:, None]
 
 
 def cross(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """Row-wise cross product of (N, 3) arrays (misc.py:152-168).
+    """Cross product of each row of a with the same row of b, as a Fortran-ordered (N, 3) float64 array.
 
-    >>> cross(np.array([[1., 2., 3.], [4., 5., 6.]]), np.array([[-1., 2., -3.], [7., 8., 9.]]))
-    array([[-12.,   0.,   4.],
-           [ -3.,   6.,  -3.]])
+    >>> cross(np.array([[1., 0., 0.], [0., 2., 0.]]), np.array([[0., 1., 0.], [0., 0., 3.]]))
+    array([[0., 0., 1.],
+           [6., 0., 0.]])
     """
-    n = np.zeros_like(a, dtype=np.float64, order='F')
-    n[:, 0] = a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1]
-    n[:, 1] = a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2]
-    n[:, 2] = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
-    return n
+    a, b = _rows(a, (3,)), np.asarray(b)
+    out = np.empty(a.shape, dtype=np.float64, order="F")
+    for c in range(3):
+        i, j = (c + 1) % 3, (c + 2) % 3
+        out[:, c] = a[:, i] * b[:, j] - a[:, j] * b[:, i]
+    return out

@@ -34,6 +34,7 @@ from .scene import CompiledScene, tracing_elements
 from ._device import require_device, stream_ptr, ptr
 from ._warn import warning
 from . import detector as _detector
+from . import checks as _checks
 
 
 class Raytracer(Group):
@@ -91,81 +92,94 @@ class Raytracer(Group):
             return
         if key == "outline":
             check_type(key, val, (list, np.ndarray))
-            o = np.asarray_chkfinite(val, dtype=np.float64)
-            if o.shape[0] != 6 or o[0] >= o[1] or o[2] >= o[3] or o[4] >= o[5]:
+            box = np.asarray_chkfinite(val, dtype=np.float64)
+            if box.shape[0] != 6 or np.any(box[0::2] >= box[1::2]):
                 raise ValueError("Outline needs to be specified as [x1, x2, y1, y2, z1, z2] "
                                  "with x2 > x1, y2 > y1, z2 > z1.")
-            val = o
+            val = box
         elif key in ("no_pol", "use_hurb"):
             check_type(key, val, bool)
         super().__setattr__(key, val)
 
     @property
     def extent(self):
-        return tuple(self.outline)
+        """The outline box as a tuple."""
+        return tuple(self.outline.tolist())
 
     @property
     def pos(self):
-        return np.mean(self.outline[:2]), np.mean(self.outline[2:4]), self.outline[4]
+        """Centre of the outline's front face."""
+        x0, x1, y0, y1, z0, _ = self.outline
+        return 0.5 * (x0 + x1), 0.5 * (y0 + y1), z0
 
     def clear(self) -> None:
         super().clear()
         self.rays.__init__()
 
     # ---- change detection (raytracer.py:129-179) ------------------------------------------------------
+    _SNAP_LISTS = (("Lenses", "lenses"), ("Filters", "filters"), ("Apertures", "apertures"), ("RaySources", "ray_sources"))
+
     def tracing_snapshot(self) -> dict:
-        return dict(Rays=[self.rays.N, self.rays.Nt, self.rays.no_pol],
-                    Ambient=[tuple(self.outline), self.n0.crepr()],
-                    TraceSettings=[self.no_pol, self.use_hurb, self.HURB_FACTOR],
-                    Lenses=[D.crepr() for D in self.lenses],
-                    Filters=[D.crepr() for D in self.filters],
-                    Apertures=[D.crepr() for D in self.apertures],
-                    RaySources=[D.crepr() for D in self.ray_sources])
+        """State of everything a trace depends on, as nested lists / tuples of plain values (compared, not hashed)."""
+        rays = self.rays
+        snap = {"Rays": [rays.N, rays.Nt, rays.no_pol],
+                "Ambient": [tuple(self.outline), self.n0.crepr()],
+                "TraceSettings": [self.no_pol, self.use_hurb, self.HURB_FACTOR]}
+        for key, attr in self._SNAP_LISTS:
+            snap[key] = [el.crepr() for el in getattr(self, attr)]
+        return snap
 
     def property_snapshot(self) -> dict:
-        return self.tracing_snapshot() | dict(Detectors=[D.crepr() for D in self.detectors])
+        """The tracing snapshot plus the detectors (they matter to images, not to the rays)."""
+        snap = self.tracing_snapshot()
+        snap["Detectors"] = [det.crepr() for det in self.detectors]
+        return snap
 
     def compare_property_snapshot(self, h1: dict, h2: dict) -> dict:
-        diff = {key: h1[key] != h2[key] for key in h1.keys()}
-        diff["Ambient"] = diff["Ambient"] or diff["Lenses"]
-        diff["Any"] = any(diff.values())
-        return diff
+        """Which groups differ between two snapshots; "Any" sums up, and new lenses also count as a change of the
+        ambient (their n2 takes part in it)."""
+        changed = {key: h1[key] != h2[key] for key in h1}
+        changed["Ambient"] |= changed["Lenses"]
+        changed["Any"] = any(changed.values())
+        return changed
 
     def check_if_rays_are_current(self) -> bool:
-        if self._last_trace_snapshot is None:
-            return False
-        return not self.compare_property_snapshot(self._last_trace_snapshot, self.tracing_snapshot())["Any"]
+        last = self._last_trace_snapshot
+        return last is not None and not self.compare_property_snapshot(last, self.tracing_snapshot())["Any"]
 
     # ---- messages (raytracer.py:181-244) ----------------------------------------------------------------
+    _EVENT_TEXT = {
+        "TIR": "with total inner reflection at surface {s} ({n}), treating as absorbed.",
+        "ABSORB_MISSING": "missing lens surface {s} ({n}), set to absorbed",
+        "ILL_COND": "are ill-conditioned for numerical hit finding at surface {s} ({n}). "
+                    "Where and whether they intersect might be wrong.",
+        "OUTLINE_INTERSECTION": "hitting outline after surface {s} ({n}), set to absorbed.",
+        "HURB_NEG_DIR": "have negative z-direction after ray bending at surface {s} ({n}), set to absorbed.",
+    }
+
     def _surface_names(self) -> list:
-        names = dict()
-        for type_, els in zip(["Lens", "Aperture", "Filter"], [self.lenses, self.apertures, self.filters]):
-            for i, el in enumerate(els):
-                if not el.has_back():
-                    names[f"surface of {type_} {el.abbr}{i}"] = el.pos[2]
+        """Names of the ray sections in tracing order: the source, every tracing surface by z, the outline."""
+        labelled = []
+        for kind, group in (("Lens", self.lenses), ("Aperture", self.apertures), ("Filter", self.filters)):
+            for k, el in enumerate(group):
+                tag = f"{kind} {el.abbr}{k}"
+                if el.has_back():
+                    labelled += [(el.front.pos[2], f"front surface of {tag}"), (el.back.pos[2], f"back surface of {tag}")]
                 else:
-                    names[f"front surface of {type_} {el.abbr}{i}"] = el.front.pos[2]
-                    names[f"back surface of {type_} {el.abbr}{i}"] = el.back.pos[2]
-        return ["RaySource"] + sorted(names, key=lambda k: names[k]) + ["Outline"]
+                    labelled.append((el.pos[2], f"surface of {tag}"))
+        labelled.sort(key=lambda item: item[0])
+        return ["RaySource"] + [name for _, name in labelled] + ["Outline"]
 
     def _show_messages(self, N) -> None:
+        """One warning per non-zero event counter (raytracer.py:207-244)."""
         if not global_options.show_warnings or not self._msgs.any():
             return
         names = self._surface_names()
-        texts = {
-            self.INFOS.TIR: "with total inner reflection at surface {s} ({n}), treating as absorbed.",
-            self.INFOS.ABSORB_MISSING: "missing lens surface {s} ({n}), set to absorbed",
-            self.INFOS.ILL_COND: "are ill-conditioned for numerical hit finding at surface {s} ({n}). "
-                                 "Where and whether they intersect might be wrong.",
-            self.INFOS.OUTLINE_INTERSECTION: "hitting outline after surface {s} ({n}), set to absorbed.",
-            self.INFOS.HURB_NEG_DIR: "have negative z-direction after ray bending at surface {s} ({n}), "
-                                     "set to absorbed.",
-        }
-        for type_, surf in zip(*np.nonzero(self._msgs)):
-            count = self._msgs[type_, surf]
-            name = names[surf] if surf < len(names) else "?"
+        for kind, sec in zip(*np.nonzero(self._msgs)):
+            count = self._msgs[kind, sec]
+            where = names[sec] if sec < len(names) else "?"
             warning(f"{count} rays ({100*count/N:.3g}% of all rays) "
-                    + texts[self.INFOS(type_)].format(s=surf, n=name))
+                    + self._EVENT_TEXT[self.INFOS(kind).name].format(s=sec, n=where))
 
     # ---- geometry checks (raytracer.py:510-664) ---------------------------------------------------------
     def _pretrace_check(self, N: int, snap: dict = None) -> bool:
@@ -189,100 +203,20 @@ class Raytracer(Group):
         return repr(snap)
 
     def _geometry_checks(self) -> None:
-        elements = tracing_elements(self)
-
-        def is_inside(e) -> bool:
-            o = self.outline + self.N_EPS * np.array([-1, 1, -1, 1, -1, 1])
-            return o[0] <= e[0] and e[1] <= o[1] and o[2] <= e[2] and e[3] <= o[3] and o[4] <= e[4] and e[5] <= o[5]
-
-        if not self.ray_sources:
-            warning("RaySource Missing.")
-            self.geometry_error = True
-            return
-
-        coll = False
-        xc = yc = zc = np.array([])
-        for i, el in enumerate(elements):
-            if not is_inside(el.extent):
-                warning(f"Element{i} {el} with extent {el.extent} outside outline {self.outline}.")
-                self.geometry_error = True
-                return
-            if i + 1 < len(elements):
-                coll, xc, yc, zc = self.check_collision(el.front, elements[i + 1].front)
-            if not coll and el.has_back():
-                coll, xc, yc, zc = self.check_collision(el.front, el.back)
-            if not coll and el.has_back():
-                coll, xc, yc, zc = self.check_collision(el.back, elements[i + 1].front)
-            if self.use_hurb and i < len(elements) - 1 and isinstance(el, Aperture):
-                if not isinstance(el.front, (RingSurface, SlitSurface)):
-                    warning(f"Ray bending for surface type {type(el.front).__name__} not implemented.")
-                    self.geometry_error = True
-                    return
-            if coll:
-                break
-
-        if not coll:
-            for rs in self.ray_sources:
-                if not is_inside(rs.extent):
-                    warning(f"RaySource {rs} with extent {rs.extent} outside outline {self.outline}.")
-                    self.geometry_error = True
-                    return
-                if rs.pos[2] >= elements[0].extent[4]:
-                    coll, xc, yc, zc = self.check_collision(rs.surface, elements[0].front)
-                if coll:
-                    break
-
-        if coll:
-            warning(f"Detected collision between two Surfaces at {xc[0], yc[0], zc[0]}"
-                    f" and at least {xc.shape[0]} other positions.")
-            self.geometry_error = True
-            self.fault_pos = np.column_stack((xc, yc, zc))
-            return
-        self.geometry_error = False
+        """Scene validation (checks.py): sets `geometry_error` / `fault_pos` and warns about the first finding."""
+        finding = _checks.find_geometry_error(self, tracing_elements(self))
+        self.geometry_error = finding is not None
+        if finding is not None:
+            text, where = finding
+            warning(text)
+            if where is not None:
+                self.fault_pos = where
 
     @staticmethod
     def check_collision(front, back, res: int = 100):
-        """Is `front` anywhere behind `back` where both are defined?  Sampled on a res x res grid
-        (raytracer.py:580-664).  Host NumPy: one-off validation, not part of the per-ray path."""
-        empty = np.array([])
-        if not (isinstance(front, Surface) or isinstance(back, Surface)):
-            raise TypeError("At least one object needs to be a Surface for collision detection")
-
-        if isinstance(front, Point) or isinstance(back, Point):
-            rev, pt, surf = (False, front, back) if isinstance(front, Point) else (True, back, front)
-            x, y = np.array([pt.pos[0]]), np.array([pt.pos[1]])
-            z = surf._values_host(x, y)
-            hit = ((z < pt.pos[2]) if not rev else (z > pt.pos[2])) & surf._mask_host(x, y)
-            where = np.where(hit)[0]
-            return bool(np.any(hit)), x[where], y[where], z[where]
-
-        if isinstance(front, Line) or isinstance(back, Line):
-            rev, line, surf = (False, front, back) if isinstance(front, Line) else (True, back, front)
-            t = np.linspace(-line.r, line.r, 10 * res)
-            ang = np.deg2rad(line.angle)
-            x = line.pos[0] + np.cos(ang) * t
-            y = line.pos[1] + np.sin(ang) * t
-            z = surf._values_host(x, y)
-            hit = ((z < line.pos[2]) if not rev else (z > line.pos[2])) & surf._mask_host(x, y)
-            where = np.where(hit)[0]
-            return bool(np.any(hit)), x[where], y[where], z[where]
-
-        xsf, xef, ysf, yef, zsf, zef = front.extent
-        xsb, xeb, ysb, yeb, zsb, zeb = back.extent
-        if zef < zsb:
-            return False, empty, empty, empty
-        xs, xe, ys, ye = max(xsf, xsb), min(xef, xeb), max(ysf, ysb), min(yef, yeb)
-        if xs > xe or ys > ye:
-            return False, empty, empty, empty
-        Y, X = np.mgrid[ys:ye:res * 1j, xs:xe:res * 1j]
-        x2, y2 = X.flatten(), Y.flatten()
-        valid = front._mask_host(x2, y2) & back._mask_host(x2, y2)
-        x2v, y2v = x2[valid], y2[valid]
-        zfv = front._values_host(x2v, y2v)
-        zbv = back._values_host(x2v, y2v)
-        coll = zfv > zbv
-        where = np.where(coll)[0]
-        return bool(np.any(coll)), x2v[where], y2v[where], zfv[where]
+        """Is `front` anywhere behind `back` where both are defined?  -> (collision, x, y, z) of the offending sample
+        positions on a res x res grid (raytracer.py:580-664); see checks.collision_points."""
+        return _checks.collision_points(front, back, res)
 
     # ---- scene upload --------------------------------------------------------------------------------------
     def _compile(self, snap: dict = None) -> CompiledScene:
@@ -429,49 +363,72 @@ class Raytracer(Group):
             self._fast = (_base.mutation_epoch(), self._structure(), snap, scene, splits)
 
     # ---- detector (raytracer.py:881-1098) ----------------------------------------------------------------
+    # ---- shared argument checks of the post-processing entry points ------------------------------------------
+    def _need_rays(self) -> None:
+        if not self.rays.N:
+            raise RuntimeError("No rays traced.")
+
+    def _need_current(self, hint: str = "") -> None:
+        """The stored rays must belong to the present geometry (raytracer.py:903-913)."""
+        if self._rays_known_current or self.check_if_rays_are_current():
+            return
+        raise RuntimeError(f"Tracing geometry/properties changed{hint}. Please retrace first.")
+
+    def _ray_range(self, source_index) -> tuple:
+        """[first, end) of the rays of one source, or of all rays for None."""
+        if source_index is None:
+            return 0, int(self.rays.N)
+        if not 0 <= source_index < len(self.ray_sources):
+            raise IndexError("Invalid source_index.")
+        return int(self.rays.B_list[source_index]), int(self.rays.B_list[source_index + 1])
+
+    def _detector_label(self, detector_index: int) -> str:
+        det = self.detectors[detector_index]
+        title = f": {det.desc}" if det.desc else ""
+        return f"{Detector.abbr}{detector_index}{title} at z = {det.pos[2]:.5g} mm"
+
+    def _warn_ill(self, ill_count: int, detector_index: int) -> None:
+        if ill_count:
+            warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
+                    f"numerical hit finding at detector {detector_index}. "
+                    "Where and whether they intersect might be wrong.")
+
     def _detector_requests(self, specs: list) -> list:
         """Checks of `_hit_detector` (raytracer.py:897-920) and, per spec, everything the device calls need:
         dicts with Ns, Ne (ray range), surf_desc, projection (name), crop (user extent or None), desc, centre."""
         if not self.detectors:
             raise RuntimeError("Detector Missing")
-        if not self.rays.N:
-            raise RuntimeError("No rays traced.")
-        for sp in specs:
-            source_index, detector_index = sp.get("source_index"), sp.get("detector_index", 0)
-            if source_index is not None and (source_index > len(self.ray_sources) - 1 or source_index < 0):
-                raise IndexError("Invalid source_index.")
-            if detector_index > len(self.detectors) - 1 or detector_index < 0:
+        self._need_rays()
+        ranges = []
+        for sp in specs:  # all indices first: nothing is moved or launched for a bad request
+            ranges.append(self._ray_range(sp.get("source_index")))
+            if not 0 <= sp.get("detector_index", 0) < len(self.detectors):
                 raise IndexError("Invalid detector_index.")
-        if not self._rays_known_current and not self.check_if_rays_are_current():
-            raise RuntimeError("Tracing geometry/properties changed. Please retrace first.")
+        self._need_current()
 
         out = []
-        for sp in specs:
-            source_index, detector_index = sp.get("source_index"), sp.get("detector_index", 0)
-            extent, projection_method = sp.get("extent"), sp.get("projection_method", "Equidistant")
-            Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
-            det = self.detectors[detector_index]
+        for sp, (Ns, Ne) in zip(specs, ranges):
+            k = sp.get("detector_index", 0)
+            det = self.detectors[k]
             if sp.get("pos") is not None:
                 det.move_to(sp["pos"])
             dsurf = det.surface
 
+            method = sp.get("projection_method", "Equidistant")
             projection = None
-            if isinstance(dsurf, SphericalSurface) and projection_method is not None:
-                if projection_method not in SphericalSurface.sphere_projection_methods:
-                    raise ValueError(f"Invalid projection_method {projection_method}, "
+            if isinstance(dsurf, SphericalSurface) and method is not None:
+                if method not in SphericalSurface.sphere_projection_methods:
+                    raise ValueError(f"Invalid projection_method {method}, "
                                      f"must be one of {SphericalSurface.sphere_projection_methods}.")
-                projection = projection_method
+                projection = method
 
+            extent = sp.get("extent")
             if not (extent is None or isinstance(extent, (list, np.ndarray))):
                 raise ValueError(f"Invalid extent '{extent}'.")
-            crop = None
-            if extent is not None:
-                crop = np.asarray_chkfinite(np.array(extent, dtype=np.float64).copy(), dtype=np.float64)
-
-            pname = f": {det.desc}" if det.desc != "" else ""
-            out.append(dict(Ns=int(Ns), Ne=int(Ne), surf_desc=dsurf._desc(), projection=projection, crop=crop,
-                            desc=f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm",
-                            centre=det.pos[:2].repeat(2), want_z=bool(sp.get("want_z", False))))
+            crop = None if extent is None else np.asarray_chkfinite(np.array(extent, dtype=np.float64), dtype=np.float64)
+            out.append(dict(Ns=Ns, Ne=Ne, surf_desc=dsurf._desc(), projection=projection, crop=crop,
+                            desc=self._detector_label(k), centre=det.pos[:2].repeat(2),
+                            want_z=bool(sp.get("want_z", False))))
         return out
 
     def _hit_detectors(self, info: str, specs: list) -> list:
@@ -513,10 +470,10 @@ class Raytracer(Group):
         images, calls = [], {}
         dev = require_device()
         for n, (sp, rq, limit) in enumerate(zip(specs, reqs, limits)):
-            desc = rq["desc"]
+            label = rq["desc"]
             if sp.get("source_index") is not None:
-                desc = f"Rays from RS{sp['source_index']} at " + desc
-            img = RenderImage(long_desc=desc, extent=rq["crop"], projection=rq["projection"])
+                label = f"Rays from RS{sp['source_index']} at {label}"
+            img = RenderImage(extent=rq["crop"], projection=rq["projection"], long_desc=label)
             img._limit = limit
             img._fix_extent()
             Nx, Ny = img._pixel_counts()
@@ -538,10 +495,7 @@ class Raytracer(Group):
                 part = part_all[b:b + 8]
                 ills = _detector.detector_images(self.rays, Ns, Ne - Ns, [r for _, r in part])
                 for (n, _), ill_count in zip(part, ills):
-                    if ill_count:
-                        warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned "
-                                f"for numerical hit finding at detector {specs[n].get('detector_index', 0)}. "
-                                "Where and whether they intersect might be wrong.")
+                    self._warn_ill(ill_count, specs[n].get("detector_index", 0))
         if not kwargs.get("_dont_filter", False):
             for img in images:
                 if img._limit is not None:
@@ -555,16 +509,14 @@ class Raytracer(Group):
                                                projection_method=projection_method, want_z=True)])[0][:6]
 
     def _image_from_hits(self, hits: tuple, detector_index: int, source_index, limit, **kwargs) -> RenderImage:
-        p, w, wl, extent_out, projection, ill_count, desc = hits
+        """Bin one hit list of `_hit_detectors` into a RenderImage."""
+        xy, weights, wavelengths, extent_out, projection, ill_count, label = hits
         if source_index is not None:
-            desc = f"Rays from RS{source_index} at " + desc
-        img = RenderImage(long_desc=desc, extent=extent_out, projection=projection)
-        img.render(p, w, wl, limit=limit, **kwargs)
-        if ill_count:
-            warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
-                    f"numerical hit finding at detector {detector_index}. "
-                    "Where and whether they intersect might be wrong.")
-        return img
+            label = f"Rays from RS{source_index} at {label}"
+        image = RenderImage(extent=extent_out, projection=projection, long_desc=label)
+        image.render(xy, weights, wavelengths, limit=limit, **kwargs)
+        self._warn_ill(ill_count, detector_index)
+        return image
 
     def detector_image(self, detector_index: int = 0, source_index: int = None, extent=None,
                        limit: float = None, projection_method: str = "Equidistant", **kwargs) -> RenderImage:
@@ -586,16 +538,9 @@ class Raytracer(Group):
         """Spectrum of the light hitting a detector (raytracer.py:1100-1132); hit search and histogram on the GPU."""
         _, w, wl, _, _, ill_count = self._hit_detector("Detector Spectrum", detector_index, source_index, extent)
 
-        det = self.detectors[detector_index]
-        pname = f": {det.desc}" if det.desc != "" else ""
-        desc = f"{Detector.abbr}{detector_index}{pname} at z = {det.pos[2]:.5g} mm"
-        desc = (f"Spectrum of RS{source_index} at " if source_index is not None else "Spectrum at ") + desc
-
-        spec = LightSpectrum.render(wl, w, long_desc=desc, **kwargs)
-        if ill_count:
-            warning(f"{ill_count} rays ({100*ill_count/self.rays.N:.3g}% of all rays) were ill-conditioned for "
-                    f"numerical hit finding at detector {detector_index}. "
-                    "Where and whether they intersect might be wrong.")
+        prefix = "Spectrum at " if source_index is None else f"Spectrum of RS{source_index} at "
+        spec = LightSpectrum.render(wl, w, long_desc=prefix + self._detector_label(detector_index), **kwargs)
+        self._warn_ill(ill_count, detector_index)
         return spec
 
     # ---- source side (raytracer.py:1281-1352) ---------------------------------------------------------------
@@ -603,38 +548,30 @@ class Raytracer(Group):
         """Section-0 device views of one source's rays: ((x, y), w, wl, extent)  (raytracer.py:1281-1309)."""
         if not self.ray_sources:
             raise RuntimeError("Ray Sources Missing.")
-        if not self.rays.N:
-            raise RuntimeError("No rays traced.")
-        if source_index > len(self.ray_sources) - 1 or source_index < 0:
-            raise IndexError("Invalid source_index.")
-        if not self.check_if_rays_are_current():
-            raise RuntimeError("Tracing geometry/properties changed. Please retrace first.")
-
-        extent = self.ray_sources[source_index].extent[:4]
-        Ns, Ne = (int(v) for v in self.rays.B_list[source_index:source_index + 2])
-        N, nt = self.rays.N, self.rays.Nt
-        d = self.rays._dev
+        self._need_rays()
+        Ns, Ne = self._ray_range(int(source_index))
+        self._need_current()
+        N, nt, d = self.rays.N, self.rays.Nt, self.rays._dev
         # element (ray r, section i, component c) of p lives at r + N * (i + nt * c); section 0 here
-        px, py = d["p"][Ns:Ne], d["p"][N * nt + Ns:N * nt + Ne]
-        return (px, py), d["w"][Ns:Ne], d["wl"][Ns:Ne], extent
+        xy = d["p"][Ns:Ne], d["p"][N * nt + Ns:N * nt + Ne]
+        return xy, d["w"][Ns:Ne], d["wl"][Ns:Ne], self.ray_sources[source_index].extent[:4]
+
+    def _source_label(self, source_index: int) -> str:
+        rs = self.ray_sources[source_index]
+        title = f": {rs.desc}" if rs.desc else ""
+        return f"{RaySource.abbr}{source_index}{title} at z = {rs.pos[2]:.5g} mm"
 
     def source_spectrum(self, source_index: int = 0, **kwargs) -> LightSpectrum:
         """Spectrum emitted by a source, from its traced rays (raytracer.py:1311-1329)."""
         _, w, wl, _ = self._hit_source("Source Spectrum", source_index)
-        rs = self.ray_sources[source_index]
-        pname = f": {rs.desc}" if rs.desc != "" else ""
-        desc = f"Spectrum of {RaySource.abbr}{source_index}{pname} at z = {rs.pos[2]:.5g} mm"
-        return LightSpectrum.render(wl, w, long_desc=desc, **kwargs)
+        return LightSpectrum.render(wl, w, long_desc="Spectrum of " + self._source_label(source_index), **kwargs)
 
     def source_image(self, source_index: int = 0, limit: float = None, **kwargs) -> RenderImage:
         """Image of a source's emitting area, from its traced rays (raytracer.py:1331-1352)."""
-        p, w, wl, extent = self._hit_source("Source Image", source_index)
-        rs = self.ray_sources[source_index]
-        pname = f": {rs.desc}" if rs.desc != "" else ""
-        desc = f"{RaySource.abbr}{source_index}{pname} at z = {rs.pos[2]:.5g} mm"
-        img = RenderImage(long_desc=desc, extent=extent, projection=None)
-        img.render(p, w, wl, limit=limit, **kwargs)
-        return img
+        xy, w, wl, extent = self._hit_source("Source Image", source_index)
+        image = RenderImage(long_desc=self._source_label(source_index), extent=extent, projection=None)
+        image.render(xy, w, wl, limit=limit, **kwargs)
+        return image
 
     # ---- focus search (raytracer.py:1354-1640) ----------------------------------------------------------------
     focus_search_methods = ['RMS Spot Size', 'Irradiance Variance', 'Image Sharpness', 'Image Center Sharpness']
@@ -652,35 +589,34 @@ class Raytracer(Group):
         Returns (scipy OptimizeResult, dict(pos, bounds, z, cost, N))."""
         import scipy.optimize
 
-        if not (self.outline[4] <= z_start <= self.outline[5]):
+        z_lo, z_hi = self.outline[4:]
+        if z_start < z_lo or z_start > z_hi:
             raise ValueError(f"Starting position z_start={z_start} outside raytracer"
                              f" z-outline range {self.outline[4:]}.")
         if method not in self.focus_search_methods:
             raise ValueError(f"Invalid method '{method}', should be one of {self.focus_search_methods}.")
-        if not self.rays.N:
-            raise RuntimeError("No rays traced.")
+        self._need_rays()
+        n_src = len(self.rays.N_list)
         if source_index is not None and source_index < 0:
             raise IndexError(f"source_index needs to be >= 0, but is {source_index}")
-        if (source_index is not None and source_index > len(self.rays.N_list) - 1) or len(self.rays.N_list) == 0:
+        if n_src == 0 or (source_index is not None and source_index >= n_src):
             raise IndexError(f"source_index={source_index} larger than number of simulated sources "
                              f"({len(self.rays.N_list)}. "
                              "Either the source was not added or the new geometry was not traced.")
-        if not self.check_if_rays_are_current():
-            raise RuntimeError("Tracing geometry/properties changed or last trace had errors. Please retrace first.")
+        self._need_current(" or last trace had errors")
 
-        # search bounds: from the end of all sources (or the surface before z_start) to the next surface / outline
-        b0 = self.N_EPS + np.max([rs.extent[5] for rs in self.ray_sources])
-        b1 = self.outline[5] - self.N_EPS
+        # the search runs in the free gap around z_start: from the last surface (or source end) before it to the
+        # first surface (or the outline's far face) behind it
+        gap = [self.N_EPS + max(rs.extent[5] for rs in self.ray_sources), self.outline[5] - self.N_EPS]
         for surf in self.tracing_surfaces:
             if surf.z_max > z_start:
-                b1 = surf.z_min
+                gap[1] = surf.z_min
                 break
-            b0 = surf.z_max
-        bounds = [float(b0), float(b1)]
+            gap[0] = surf.z_max
+        bounds = [float(gap[0]), float(gap[1])]
 
         Nt = 320  # cost function sampling points
-        Ns, Ne = self.rays.B_list[source_index:source_index + 2] if source_index is not None else (0, self.rays.N)
-        Ns, Ne = int(Ns), int(Ne)
+        Ns, Ne = self._ray_range(source_index)
         n = Ne - Ns
 
         lib = _capi.load_library()
@@ -694,10 +630,10 @@ class Raytracer(Group):
         N_use = int(n_use_d.item())
         if N_use < 1000:
             warning(f"WARNING: Less than 1000 rays for focus_search ({N_use}).")
-        if N_use <= 1:
-            return scipy.optimize.OptimizeResult(), \
-                dict(pos=[np.nan, np.nan, np.nan], bounds=bounds, z=np.full(Nt, np.nan),
-                     cost=np.full(Nt, np.nan), N=N_use)
+        if N_use <= 1:  # nothing to focus: an empty result with the reference's keys
+            nan_curve = np.full(Nt, np.nan)
+            return scipy.optimize.OptimizeResult(), dict(pos=[np.nan] * 3, bounds=bounds, z=nan_curve,
+                                                         cost=nan_curve.copy(), N=N_use)
 
         mode = self.focus_search_methods.index(method)
         # image side grows with sqrt(N) (raytracer.py:1381-1385), odd
@@ -726,7 +662,8 @@ class Raytracer(Group):
             return out.cpu().numpy()
 
         r = vals = None
-        if return_cost or method in ["Image Sharpness", "Image Center Sharpness"]:
+        needs_curve = mode >= 2  # the sharpness methods start their optimiser at the best sample of the curve
+        if return_cost or needs_curve:
             if _z_samples is not None:
                 r = np.asarray(_z_samples, dtype=np.float64)
             else:  # random.stratified_interval_sampling(b0, b1, Nt, shuffle=False), random.py:48-67
@@ -734,25 +671,23 @@ class Raytracer(Group):
                 r = np.linspace(bounds[0], bounds[1] - dba, Nt) + np.random.uniform(0., dba, Nt)
             vals = cost_at(r)
 
-        if method == "RMS Spot Size":
-            # direct solution, extended by ray weights (raytracer.py:1420-1460)
-            dnorm = sm[5]
-            d = -sm[6] / dnorm if dnorm else np.mean(bounds)
-            d = float(np.clip(d, bounds[0], bounds[1]))
-            res = scipy.optimize.OptimizeResult()
-            res.x = d
-            res.fun = float(cost_at(np.array([d]))[0])
+        if mode == 0:
+            # RMS spot size: direct solution, extended by ray weights (raytracer.py:1420-1460)
+            z_best = -sm[6] / sm[5] if sm[5] else 0.5 * (bounds[0] + bounds[1])
+            z_best = float(min(max(z_best, bounds[0]), bounds[1]))
+            res = scipy.optimize.OptimizeResult(x=z_best, fun=float(cost_at(np.array([z_best]))[0]))
         else:
-            def cost_func2(z, *_):
+            def scalar_cost(z, *_):
                 return float(cost_at(np.array([z[0]]))[0])
 
-            if method == "Irradiance Variance":
-                res = scipy.optimize.minimize(cost_func2, np.mean(bounds), tol=None, callback=None,
-                                              options={'maxiter': 100}, bounds=[bounds], method="Nelder-Mead")
+            # same optimisers and limits as the reference: Nelder-Mead from the middle of the gap for the irradiance
+            # variance, COBYLA from the best curve sample for the sharpness methods
+            if mode == 1:
+                start, solver, steps = 0.5 * (bounds[0] + bounds[1]), "Nelder-Mead", 100
             else:
-                pos = int(np.argmin(vals))
-                res = scipy.optimize.minimize(cost_func2, r[pos], tol=None, callback=None,
-                                              options={'maxiter': 30}, bounds=[bounds], method="COBYLA")
+                start, solver, steps = r[int(np.argmin(vals))], "COBYLA", 30
+            res = scipy.optimize.minimize(scalar_cost, start, method=solver, bounds=[bounds], tol=None, callback=None,
+                                          options=dict(maxiter=steps))
             res.x = res.x[0]
 
         rrl = (res.x - bounds[0]) < 10 * (bounds[1] - bounds[0]) / Nt
@@ -779,45 +714,45 @@ class Raytracer(Group):
         if (N := int(N)) <= 0:
             raise ValueError(f"Ray number N_rays needs to be a positive int, but is {N}.")
 
+        # one image per detector position: scalars are repeated, lists must have one entry per position
         if pos is None:
             if isinstance(detector_index, list):
                 raise ValueError("detector_index list needs to have the same length as pos list")
             pos = [self.detectors[detector_index].pos]
-        elif isinstance(pos, list) and not isinstance(pos[0], (list, np.ndarray)):
+        elif not isinstance(pos[0], (list, np.ndarray)):
             pos = [pos]
+        n_img = len(pos)
 
-        def as_list(v, name):
-            if not isinstance(v, list):
-                return [v] * len(pos)
-            if len(v) != len(pos):
+        def per_image(value, name, is_list):
+            if not is_list:
+                return [value] * n_img
+            if len(value) != n_img:
                 raise ValueError(f"{name} list needs to have the same length as pos list")
-            return v
+            return list(value)
 
-        detector_index = as_list(detector_index, "detector_index")
-        limit = as_list(limit, "limit")
-        projection_method = as_list(projection_method, "projection_method")
-        if not isinstance(extent, list) or isinstance(extent[0], (int, float)):
-            extent = [extent] * len(pos)
-        elif len(extent) != len(pos):
-            raise ValueError("extent list needs to have the same length as pos list")
-        extentc = extent.copy()
+        detector_index = per_image(detector_index, "detector_index", isinstance(detector_index, list))
+        limit = per_image(limit, "limit", isinstance(limit, list))
+        projection_method = per_image(projection_method, "projection_method", isinstance(projection_method, list))
+        # (an extent is itself a list of numbers: only a list of extents counts as one)
+        extentc = per_image(extent, "extent", isinstance(extent, list) and not isinstance(extent[0], (int, float)))
 
-        nt = len(self.tracing_surfaces) + 2
+        n_sec = len(self.tracing_surfaces) + 2
         rays_step = self.ITER_RAYS_STEP
         if rays_step is None:
             # chunk = what ITER_STORAGE_BYTES of ray storage hold (the reference's 1 M rays are sized for a few GB of
             # host RAM, raytracer.py:40); chunks of equal size, at least 1 M rays
-            step_max = max(1_000_000, self.rays.max_rays_for_size(self.ITER_STORAGE_BYTES, nt, self.no_pol))
+            step_max = max(1_000_000, self.rays.max_rays_for_size(self.ITER_STORAGE_BYTES, n_sec, self.no_pol))
             iterations = -(-N // step_max)
             rays_step = -(-N // iterations)
         else:
-            iterations = max(1, int(N / rays_step))
+            iterations = max(N // rays_step, 1)
         step0 = rays_step
         images: list = []
 
         if self._pretrace_check(rays_step):
             raise RuntimeError("Geometry checks failed. Tracing aborted. Check the warnings.")
 
+        nt = n_sec
         msgs_cum = np.zeros((len(self.INFOS), nt), dtype=int)
         scale0, scaled = 1.0, False
 

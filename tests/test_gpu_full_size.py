@@ -1,6 +1,7 @@
-"""BASELINE.json configs C3, C4, C5 at their FULL ray counts on one MI355X, checked through size-independent
-properties computed on the device (nothing of the 18-34 GB ray storage is copied to the host).
+"""BASELINE.json configs C2, C3, C4, C5 at their FULL ray counts on one MI355X, checked through size-independent
+properties computed on the device (nothing of the 8-34 GB ray storage is copied to the host).
 
+    C2  double Gauss, 5 point sources, FDC lines, pol on, N = 1e7, M = 15   (8.4 GB; the bench configuration)
     C3  arizona eye, RGB image source, N = 5e7, M = 5            (18.2 GB)
     C4  image_render_many_rays geometry, no_pol, N = 2e8, M = 2  (34.4 GB; more than 2^31 stored doubles)
     C5  slit + lens with HURB, pol on, N = 1e8, M = 3            (26.8 GB)
@@ -63,6 +64,41 @@ def detector_checks(RT, di=0, **kw):
     assert abs(img.power() - power) <= 1e-9 * max(power, 1e-300)
     assert np.all(img._data >= 0) and np.all(np.isfinite(img._data))
     return img, power
+
+
+def test_c2_double_gauss_1e7():
+    """The headline configuration at its quoted size (bench.py times exactly this trace)."""
+    N = 10_000_000
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, seed=11)
+        RT.trace(N)
+        assert not RT.geometry_error and RT.rays.Nt == 17 and not RT.no_pol
+        assert RT.rays.storage_size(N, 17, False) == N * (17 * 48 + 28)
+        lost = device_checks(RT, N, 5.0)
+        # the stop (ring aperture) and the rims of the lenses take rays, the rest ends on the outline's far face
+        assert lost[-1] > 0.1 * N and lost[:-1].sum() > 0.1 * N
+        d = RT.rays._dev
+        # three spectral lines, nothing else
+        lines = torch.unique(d["wl"]).cpu().numpy()
+        np.testing.assert_allclose(np.sort(lines), np.float32([486.1327, 589.2938, 656.272]), rtol=0, atol=0)
+        # unit directions and unit, transverse polarisation vectors on the living rays of a few sections
+        s = d["s"].view(3, N)
+        alive_end = d["w"].view(17, N)[15] > 0
+        nrm = (s * s).sum(dim=0).sqrt()[alive_end]
+        assert float((nrm - 1).abs().max()) < 1e-12
+        pol = d["pol"].view(3, 17, N)
+        for sec in (0, 7, 15):
+            live = d["w"].view(17, N)[sec] > 0
+            pn = (pol[:, sec].double() ** 2).sum(dim=0).sqrt()[live]
+            assert float((pn - 1).abs().max()) < 1e-4
+        # refractive indices along the rays: ambient 1 at both ends, glass in between for rays inside a lens
+        n = d["n"].view(17, N)
+        assert float(n[0].min()) == 1.0 and float(n[0].max()) == 1.0
+        assert float(n.max()) < 2.0 and float(n.min()) >= 1.0
+        img, power = detector_checks(RT, 0, extent=[-45., 45., -45., 45.])
+        assert 0.3 < power < 5.0
+        img2, power2 = detector_checks(RT, 0)  # automatic extent: same power, five spots
+        assert abs(power2 - power) < 1e-9 * power
 
 
 def test_c3_arizona_eye_rgb_source_5e7():
