@@ -539,3 +539,47 @@ def test_optical_and_geometric_path_lengths():
         want[:, 0], want[:, 1], want[:, 2], want[:, 3] = 1, 1.2, 2.8, 4
         assert np.allclose(ln - want, 0, atol=1e-9, rtol=0)
         assert np.all(ln[m1, m2] == r.ray_lengths(m1, m2))
+
+
+def test_long_stack_with_discrete_spectrum_falls_back_to_formula_kernels():
+    """A monochromatic source selects the kernel that keeps per-line tables of every step in LDS; with hundreds of
+    surfaces those tables exceed what a workgroup gets, and the formula kernel traces the scene instead of a launch
+    error (340 surfaces: 3 rows x 8 lines x 8 B per step = 65 KB)."""
+    n = ot.RefractionIndex("Constant", n=1.5)
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -2, 175], seed=3)
+        RT.add(ot.RaySource(ot.CircularSurface(r=0.5), pos=[0, 0, -1], spectrum=ot.LightSpectrum("Monochromatic", wl=550.)))
+        for k in range(170):  # weak, alternating lenses: the bundle stays near the axis
+            R = 400.0 if k % 2 == 0 else -400.0
+            RT.add(ot.Lens(ot.SphericalSurface(r=2, R=R), ot.SphericalSurface(r=2, R=-R), n=n, pos=[0, 0, 1.0 * k], d=0.4))
+        RT.trace(3000)
+        assert not RT.geometry_error and RT.rays.Nt == 342
+        w = RT.rays.w_list
+        assert np.all(w[:, -1] == 0) and np.all(w[:, -2] > 0), "everything arrives at the end aperture"
+        # Fresnel losses of 340 near-normal glass / air passages
+        t = float(w[:, -2].astype(np.float64).sum() / w[:, 0].astype(np.float64).sum())
+        assert abs(t - 0.96 ** 340) < 0.1 * 0.96 ** 340
+        assert RT._msgs.shape == (5, 342) and RT._msgs[:, :-1].sum() == 0
+
+
+def test_beam_along_a_face_normal_keeps_its_power():
+    """A collimated beam whose direction equals the normal of a tilted face bitwise: the plane of incidence is
+    undefined (n x s = 0).  The reference gets the normal-incidence transmission 4 n1 n2 / (n1 + n2)^2 out of its
+    rounding-noise basis; a NaN weight here would silently absorb the rays."""
+    nrm = np.array([0.06, -0.03, 1.0])
+    nrm /= np.linalg.norm(nrm)
+    n = ot.RefractionIndex("Constant", n=1.6)
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-6, 6, -6, 6, -5, 30], seed=9)
+        RT.add(ot.RaySource(ot.CircularSurface(r=0.4), pos=[0, 0, -2], s=list(nrm), polarization="Uniform"))
+        front = ot.TiltedSurface(r=3, normal=list(nrm))
+        RT.add(ot.Lens(front, ot.CircularSurface(r=3), n=n, pos=[0, 0, 5], d=1.5))
+        RT.trace(20000)
+        assert not RT.geometry_error
+        w, pol = RT.rays.w_list.astype(np.float64), RT.rays.pol_list.astype(np.float64)
+        assert np.all(np.isfinite(w)) and np.all(np.isfinite(pol[:, :3]))
+        assert np.all(w[:, 1] > 0), "no ray is lost at the tilted face"
+        T = 4 * 1.6 / (1 + 1.6) ** 2
+        np.testing.assert_allclose(w[:, 1] / w[:, 0], T, rtol=2e-6)
+        # direction unchanged up to rounding, polarisation still transverse and of unit length
+        np.testing.assert_allclose(np.linalg.norm(pol[:, 1], axis=1), 1.0, atol=1e-6)
