@@ -21,24 +21,32 @@ os.replace(newest("stats/*/*_kernel_stats.csv"), os.path.join(out, "bench_kernel
 rows = [r for r in csv.DictReader(open(newest("stats/*/*_kernel_trace.csv"))) if "trace_kernel" in r["Kernel_Name"]]
 main = rows[0]["Kernel_Name"]  # the timed configuration comes first; the secondary no_pol launches follow it
 rows = [r for r in rows if r["Kernel_Name"] == main]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 4) for r in rows]
+# launch order of bench.py: 1 small set-up trace, 30 warm-up traces, 50 timed traces (Raytracer.trace), then 60 raw
+# back-to-back launches and one more trace for the detector image
+timed = ms[31:81]
 line = [l for l in open(os.path.join(out, "bench_stats.log")) if l.startswith("{")]
-json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu   (30 warm-up + 50 timed launches)",
-           "kernel": rows[0]["Kernel_Name"][:40], "launch_ms": ms, "timed_mean_ms": sum(ms[-50:]) / 50,
+json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu   (1 set-up + 30 warm-up + 50 timed Raytracer.trace calls, then 60 raw launches + 1)",
+           "kernel": rows[0]["Kernel_Name"][:40], "launch_ms": ms, "timed_mean_ms": sum(timed) / len(timed),
            "bench_line": json.loads(line[-1]) if line else None}, open(os.path.join(out, "trace_kernel_launches.json"), "w"), indent=1)
 pmc = {"rays": 10000000, "pol": True, "unit": "KB per launch",
        "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --skip-cpu"}
 for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     rows = [r for r in csv.DictReader(open(newest(d + "/*/*_counter_collection.csv"))) if r["Kernel_Name"] == main and r["Counter_Name"] == name]
-    pmc[name] = [float(r["Counter_Value"]) for r in rows]
+    vals = [float(r["Counter_Value"]) for r in rows]
+    pmc[name] = [v for v in vals if v > 0.5 * max(vals)] if name == "WRITE_SIZE" else vals[1:]  # full-size launches only (the first is the 100 k-ray set-up trace)
 json.dump(pmc, open(os.path.join(out, "trace_kernel_pmc.json"), "w"), indent=1)
 sq = {}
 for r in csv.DictReader(open(newest("sq/*/*_counter_collection.csv"))):
     if r["Kernel_Name"] == main:
         sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-json.dump({k: sum(v) / len(v) for k, v in sq.items()}, open(os.path.join(out, "trace_kernel_sq.json"), "w"), indent=1)
+# full-size launches only: the set-up trace of bench.py has 1/100 of the waves
+full = [i for i, w in enumerate(sq["SQ_WAVES"]) if w > 0.5 * max(sq["SQ_WAVES"])]
+json.dump({"rays": 10000000, "pol": True, **{k: sum(v[i] for i in full) / len(full) for k, v in sq.items()}},
+          open(os.path.join(out, "trace_kernel_sq.json"), "w"), indent=1)
 os.replace(newest("detector/*/*_kernel_stats.csv"), os.path.join(out, "detector_kernel_stats.csv"))
 print(open(os.path.join(out, "trace_kernel_sq.json")).read())
-print("timed mean ms", sum(ms[-50:]) / 50)
+print("timed mean ms", sum(timed) / len(timed))
 PY
 grep -v amdgpu.ids "$OUT/detector.log" | grep "rays/s" > "$OUT/detector_full_size_profiled.txt" || true
