@@ -114,7 +114,7 @@ struct GenCtx {
 // stream -> which dither value(s) it uses (consecutive pairs for the 2-D samplers).  The slots are grouped so
 // that a source only pays for the Philox blocks it needs: block A (u0-u3) serves every source -- point sources
 // with direction, wavelength and polarisation need nothing else --, block B (u4-u7) extended emitters and 2-D
-// divergence, block C (u8-u11) image sources.
+// divergence; image sources take eight 16-bit dithers (u0-u3, u8-u11) out of block A alone (fill_dither).
 OT_DEV int dither_slot(uint32_t stream) {
     switch (stream) {
         case ST_DIV: return 0;         // u0, u1
@@ -129,24 +129,35 @@ OT_DEV int dither_slot(uint32_t stream) {
     }
 }
 
-OT_DEV void fill_dither(GenCtx& g, bool need_b, bool need_c) {
+OT_DEV void fill_dither(GenCtx& g, bool need_b, bool image) {
     const uint32_t i0 = (uint32_t)g.gidx, i1 = (uint32_t)(g.gidx >> 32), k0 = (uint32_t)g.seed, k1 = (uint32_t)(g.seed >> 32);
-    Philox a = philox4x32(i0, i1, 0x67656e31u, 0, k0, k1);
+    Philox a = philox4x32<7>(i0, i1, 0x67656e31u, 0, k0, k1);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         g.u[k] = ((double)a.c[k] + 0.5) * 0x1.0p-32;
         g.u[4 + k] = 0.5;
         g.u[8 + k] = 0.5;
     }
+    if (image) {
+        // image sources draw eight dithers (direction x 2, wavelength, polarisation, pixel, in-pixel x 2, primary):
+        // the one block serves them all with 16 bits each -- a dither only places the ray inside its stratum, whose
+        // width is 1 / (rays of the range) of the sampled interval already
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double lo = ((double)(a.c[k] & 0xffffu) + 0.5) * 0x1.0p-16, hi = ((double)(a.c[k] >> 16) + 0.5) * 0x1.0p-16;
+            if (k < 2) {
+                g.u[2 * k] = lo;      // u0, u2
+                g.u[2 * k + 1] = hi;  // u1, u3
+            } else {
+                g.u[8 + 2 * (k - 2)] = lo;      // u8, u10
+                g.u[8 + 2 * (k - 2) + 1] = hi;  // u9, u11
+            }
+        }
+    }
     if (need_b) {
-        Philox b = philox4x32(i0, i1, 0x67656e32u, 1, k0, k1);
+        Philox b = philox4x32<7>(i0, i1, 0x67656e32u, 1, k0, k1);
 #pragma unroll
         for (int k = 0; k < 4; k++) g.u[4 + k] = ((double)b.c[k] + 0.5) * 0x1.0p-32;
-    }
-    if (need_c) {
-        Philox c = philox4x32(i0, i1, 0x67656e33u, 2, k0, k1);
-#pragma unroll
-        for (int k = 0; k < 4; k++) g.u[8 + k] = ((double)c.c[k] + 0.5) * 0x1.0p-32;
     }
 }
 
@@ -208,7 +219,7 @@ OT_DEV void strat_ring(const GenCtx& g, uint32_t stream, double ri, double r, bo
     }
     if (!polar) {
         double sn, cs;
-        sincospi(th, &sn, &cs);
+        sincospi_small(th, &sn, &cs);
         o0 = r_ * cs;
         o1 = r_ * sn;
     } else {  // (|r|, theta / pi) with theta shifted by -pi for negative r
@@ -418,7 +429,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         } else {
             double r, alpha_pi;
             strat_ring(g, ST_DIV, 0.0, src.div_sin, true, r, alpha_pi);
-            sincospi(alpha_pi, &sa, &ca);
+            sincospi_small(alpha_pi, &sa, &ca);
             switch (src.divergence) {
                 case OT_DIV_LAMBERTIAN:  // theta = asin(r)
                     st = r;
@@ -460,7 +471,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 cs = src.pol_cos;
                 sn = src.pol_sin;
                 break;
-            case OT_POL_UNIFORM: sincospi(strat_interval(g, ST_POL, 0.0, 2.0), &sn, &cs); break;  // angle in [0, 2 pi)
+            case OT_POL_UNIFORM: sincospi_small(strat_interval(g, ST_POL, 0.0, 2.0), &sn, &cs); break;  // angle in [0, 2 pi)
             case OT_POL_LIST: {
                 const double* F = src.pol_tab + src.n_pol;
                 double ang = inv_cdf_discrete(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, 0.0, F[src.n_pol - 1]), src.g_pol);

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""A few traces of one BASELINE configuration (for rocprofv3 counter runs).  Usage: trace_cfg.py C3|C4|C5|C2 [reps]"""
+import pathlib
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tests"), str(ROOT / "tools")]
+which = sys.argv[1] if len(sys.argv) > 1 else "C4"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+sys.argv = [sys.argv[0], "NONE"]
+import torch
+
+import optrace_amd as ot
+import bench_configs as bc
+
+name = [k for k in bc.CONFIGS if k.startswith(which)][0]
+build, N = bc.CONFIGS[name]
+with ot.global_options.no_warnings():
+    RT = build(ot)
+    for _ in range(reps):
+        RT.trace(N)
+torch.cuda.synchronize()
+print(name, N)
