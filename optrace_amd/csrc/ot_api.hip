@@ -907,7 +907,9 @@ __global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const Sc
             for (int j = 1; j < sc.n_lines; j++)
                 if ((float)ltab[j] == r.wl) lj = j;
         }
-        bool ok = trace_ray<POL, SPEC, FEAT>(sc, R, local, (uint64_t)ray, r, hurb_normals, seed, cnt, ltab, lj);
+        // feature level 2: 25 doubles per lane behind the counters for the spline patch cache
+        double* patch = (FEAT >= 2) ? lds + n_tab + (n_cnt + 2) / 2 : nullptr;
+        bool ok = trace_ray<POL, SPEC, FEAT>(sc, R, local, (uint64_t)ray, r, hurb_normals, seed, cnt, ltab, lj, patch);
         if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)
     }
     __syncthreads();
@@ -1197,7 +1199,10 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
     const size_t lds_lines = sizeof(double) * (size_t)(3 * sc->h.n_steps + 2) * OT_MAX_LINES;
     if (lds_cnt > 60000) return fail(OT_ERR_UNSUPPORTED, "ot_trace: more than ~3000 tracing surfaces in one scene");
     if (lines && lds_cnt + lds_lines > 60000) lines = false;
-    const size_t lds = lds_cnt + (lines ? lds_lines : 0);
+    // numeric surfaces: a 5 x 5 coefficient patch per lane (spline surfaces, ot_spline.hpp::PatchCache)
+    const size_t lds_patch = (feat == 2) ? 256 * 25 * sizeof(double) + 16 : 0;
+    if (lines && lds_cnt + lds_lines + lds_patch > 65000) lines = false;
+    const size_t lds = ((lds_cnt + (lines ? lds_lines : 0) + 7) / 8) * 8 + lds_patch;
     unsigned int* slots = sc->cnt_slots;
     if (sc->timing) HIP_TRY(hipEventRecord(sc->ev0, st));
     // lanes address their ray with 32-bit byte offsets: launches of at most 2^28 rays, base pointers advanced

@@ -94,7 +94,7 @@ OT_DEV V3 along(const V3& p, const V3& s, double t) {
 // ---- spline surfaces: DataSurface2D._call / ._values / .normals data_surface_2d.py:126-196 -----------------
 // table layout (include/optrace_amd.h): DATA1D t[n] | c[n] | dc[n];  DATA2D t[n] | c[(n-5)^2] | cx[(n-6)(n-5)] | cy
 template <class SF>
-OT_HD double data_values_rel(SF& sf, double x, double y) {
+OT_HD double data_values_rel(SF& sf, double x, double y, PatchCache* pc = nullptr) {
     const double* t = sf.tab;
     const int n = sf.nk;
     double v;
@@ -106,14 +106,14 @@ OT_HD double data_values_rel(SF& sf, double x, double y) {
             xr = x * sf.cna - y * sf.sna;
             yr = x * sf.sna + y * sf.cna;
         }
-        v = spl2_eval<OT_SPL_K, OT_SPL_K>(t, n, t, n, t + n, sf.inv_h, xr, sf.sgn * yr);
+        v = spl2_eval<OT_SPL_K, OT_SPL_K>(t, n, t, n, t + n, sf.inv_h, xr, sf.sgn * yr, pc);
     }
     return sf.sgn * (v - sf.offs);
 }
 
 // -(dz/dx), -(dz/dy), 1 normalised; x, y relative to the centre, inside the mask
 template <class SF>
-OT_HD void data_gradient(SF& sf, double x, double y, double& gx, double& gy) {
+OT_HD void data_gradient(SF& sf, double x, double y, double& gx, double& gy, PatchCache* pc = nullptr) {
     const double* t = sf.tab;
     const int n = sf.nk;
     if (sf.kind == OT_SURF_DATA1D) {
@@ -131,8 +131,13 @@ OT_HD void data_gradient(SF& sf, double x, double y, double& gx, double& gy) {
     }
     const int nc = (n - OT_SPL_K - 1), ncx = (n - OT_SPL_K - 2) * nc;
     const double* c = t + n;
-    double nxn = spl2_eval<OT_SPL_K - 1, OT_SPL_K>(t + 1, n - 2, t, n, c + nc * nc, sf.inv_h, xr, sf.sgn * yr) * sf.sgn;
-    double nyn = spl2_eval<OT_SPL_K, OT_SPL_K - 1>(t, n, t + 1, n - 2, c + nc * nc + ncx, sf.inv_h, xr, sf.sgn * yr);
+    double nxn, nyn;
+    if (spl2_grad_cached(t, n, c, sf.inv_h, xr, sf.sgn * yr, pc, nxn, nyn)) {  // from the patch of the hit search
+        nxn = nxn * sf.sgn;
+    } else {
+        nxn = spl2_eval<OT_SPL_K - 1, OT_SPL_K>(t + 1, n - 2, t, n, c + nc * nc, sf.inv_h, xr, sf.sgn * yr) * sf.sgn;
+        nyn = spl2_eval<OT_SPL_K, OT_SPL_K - 1>(t, n, t + 1, n - 2, c + nc * nc + ncx, sf.inv_h, xr, sf.sgn * yr);
+    }
     if (sf.rot) {  // _rotate_rc(nxn, nyn, +angle)
         gx = nxn * sf.cpa - nyn * sf.spa;
         gy = nxn * sf.spa + nyn * sf.cpa;
@@ -189,9 +194,9 @@ OT_DEV double asph_poly_deriv(SF& sf, double r) {  // polyval(polyder(..)) asphe
 
 // Surface._values relative to the centre: conic_surface.py:57, aspheric_surface.py:51
 template <class SF>
-OT_DEV double surf_values_rel(SF& sf, double x, double y) {
+OT_DEV double surf_values_rel(SF& sf, double x, double y, PatchCache* pc = nullptr) {
     if (sf.kind == OT_SURF_TILTED) return x * sf.mx + y * sf.my;  // tilted_surface.py:60-73
-    if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) return data_values_rel(sf, x, y);
+    if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) return data_values_rel(sf, x, y, pc);
     if (sf.kind == OT_SURF_CONIC) {
         double r2 = x * x + y * y;
         return ot_div(sf.rho * r2, 1 + sqrt(1 - sf.k1rho2 * r2));
@@ -205,16 +210,16 @@ OT_DEV double surf_values_rel(SF& sf, double x, double y) {
 
 // Surface.values surface.py:137-164
 template <class SF>
-OT_DEV double surf_values(SF& sf, double x, double y) {
+OT_DEV double surf_values(SF& sf, double x, double y, PatchCache* pc = nullptr) {
     if (sf.flat) return sf.z_max;
-    if (surf_mask(sf, x, y)) return sf.pz + surf_values_rel(sf, x - sf.px, y - sf.py);
+    if (surf_mask(sf, x, y)) return sf.pz + surf_values_rel(sf, x - sf.px, y - sf.py, pc);
     if (sf.kind == OT_SURF_TILTED || sf.kind == OT_SURF_DATA2D) {
         // no rotational symmetry: edge value along the direction of (x, y), surface.py:156-159;
         // cos / sin of arctan2 formed as dx / rr, dy / rr like in surf_normal
         double dx = x - sf.px, dy = y - sf.py;
         double rr = sqrt(dx * dx + dy * dy);
         double c = (rr > 0.0) ? dx / rr : 1.0, sn = (rr > 0.0) ? dy / rr : 0.0;
-        return sf.pz + surf_values_rel(sf, sf.r_edge * c, sf.r_edge * sn);
+        return sf.pz + surf_values_rel(sf, sf.r_edge * c, sf.r_edge * sn, pc);
     }
     return sf.edge_val;
 }
@@ -224,7 +229,7 @@ OT_DEV double surf_values(SF& sf, double x, double y) {
 // cos(atan2(dy,dx)) and sin(atan2(dy,dx)) are formed as dx/r, dy/r: same value to 1-2 ulp without three
 // transcendental calls per ray (normals never feed a mask directly; tolerance 1e-6).
 template <bool INSIDE = false, bool ALL_KINDS = true, class SF>
-OT_DEV V3 surf_normal(SF& sf, double x, double y) {
+OT_DEV V3 surf_normal(SF& sf, double x, double y, PatchCache* pc = nullptr) {
     V3 n = {0.0, 0.0, 1.0};
     if (sf.kind < OT_SURF_CONIC) return n;
     if (!ALL_KINDS && sf.kind != OT_SURF_CONIC) return n;  // kernel variant for scenes of flat and conic surfaces
@@ -238,7 +243,7 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y) {
     double dx = x - sf.px, dy = y - sf.py;
     if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) {  // data_surface_2d.py:153-196
         double gx, gy;
-        data_gradient(sf, dx, dy, gx, gy);
+        data_gradient(sf, dx, dy, gx, gy, pc);
         V3 m = {-gx, -gy, 1.0};
         return normalize3(m);
     }
@@ -271,8 +276,8 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y) {
 
 // Surface._find_hit_handle_abnormal surface.py:436-479
 template <class SF>
-OT_DEV void handle_abnormal(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) {
-    double zs = surf_values(sf, ph.x, ph.y);
+OT_DEV void handle_abnormal(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, PatchCache* pc = nullptr) {
+    double zs = surf_values(sf, ph.x, ph.y, pc);
     bool dev = fabs(ph.z - zs) > OT_C_EPS;
     bool beh = p.z > sf.z_beh;
     bool neg = ph.z < p.z - OT_C_EPS;
@@ -338,7 +343,7 @@ OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) 
 // and converged lanes idle, so a wave pays max(iterations) of its own 64 rays only.
 // Returns false if a lane hit the 200-iteration timeout (surface.py:403).
 template <bool NUMERIC = true, class SF>
-OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& ill) {
+OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& ill, PatchCache* pc = nullptr) {
     ill = false;
     if (sf.kind == OT_SURF_CONIC) {
         find_hit_conic(sf, p, s, ph, hit);
@@ -374,8 +379,8 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
     V3 p1 = along(p, s, t1), p2 = along(p, s, t2);
     double f1 = 0.0, f2 = 0.0;
     if (!pre) {
-        f1 = p1.z - surf_values(sf, p1.x, p1.y);
-        f2 = p2.z - surf_values(sf, p2.x, p2.y);
+        f1 = p1.z - surf_values(sf, p1.x, p1.y, pc);
+        f2 = p2.z - surf_values(sf, p2.x, p2.y, pc);
     }
     bool w = !pre && isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
     ph.x = ph.y = ph.z = 0.0;
@@ -387,7 +392,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         if (w) {
             double ts = t1 - ot_div(f1, f2 - f1) * (t2 - t1);
             V3 pl = along(p, s, ts);
-            double fts = pl.z - surf_values(sf, pl.x, pl.y);
+            double fts = pl.z - surf_values(sf, pl.x, pl.y, pc);
             double prod = fts * f2;
             if (prod < 0) {
                 t1 = t2;
@@ -417,14 +422,14 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
     }
     if (!pre) {
         hit = surf_mask(sf, ph.x, ph.y);
-        handle_abnormal(sf, p, s, ph, hit);
+        handle_abnormal(sf, p, s, ph, hit, pc);
     }
     if (sf.kind == OT_SURF_TILTED) {  // tilted_surface.py:119-120: abnormal handling once more, for all rays
         if (pre) {
             ph = ph_pre;
             hit = true;
         }
-        handle_abnormal(sf, p, s, ph, hit);
+        handle_abnormal(sf, p, s, ph, hit, pc);
     }
     return ok;
 }
