@@ -76,37 +76,36 @@ class BaseClass:
         self.long_desc = long_desc
 
     def crepr(self) -> list:
-        """State as nested tuples; used to detect geometry changes since the last trace."""
-        out = []
-        for val in self.__dict__.values():
-            if isinstance(val, BaseClass):
-                out.append(val.crepr())
-            elif isinstance(val, np.ndarray):
-                out.append(tuple(val.flat) if val.size < 20 else _array_token(val))
-            elif callable(val):
-                out.append(id(val))
-            elif isinstance(val, list):
-                out.append(tuple(val))
-            else:
-                out.append(val)
-        return out
+        """State as nested lists / tuples of plain values; compared to detect changes since the last trace
+        (base_class.py:27-58).  Small arrays go in by value, large ones as a token (`_array_token`), callables by id."""
+        def plain(v):
+            if isinstance(v, BaseClass):
+                return v.crepr()
+            if isinstance(v, np.ndarray):
+                return tuple(v.ravel().tolist()) if v.size < 20 else _array_token(v)
+            if isinstance(v, list):
+                return tuple(v)
+            return id(v) if callable(v) else v
+        return [plain(v) for v in vars(self).values()]
 
     def get_desc(self, fallback: str = "") -> str:
-        return self.desc if self.desc != "" else fallback
+        """The short description, or `fallback` if there is none."""
+        return self.desc or fallback
 
     def get_long_desc(self, fallback: str = "") -> str:
-        return self.long_desc if self.long_desc != "" else self.get_desc(fallback)
+        """The long description, else the short one, else `fallback`."""
+        return self.long_desc or self.get_desc(fallback)
 
     def copy(self):
+        """A fully independent copy."""
         return copy.deepcopy(self)
 
     def lock(self) -> None:
         """Make the object (and its arrays) read-only."""
-        for val in self.__dict__.values():
-            if isinstance(val, np.ndarray):
-                val.flags.writeable = False
-        self._lock = True
-        self._new_lock = True
+        for arr in vars(self).values():
+            if isinstance(arr, np.ndarray):
+                arr.setflags(write=False)
+        self._lock = self._new_lock = True
 
     def __str__(self) -> str:
         d = {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
