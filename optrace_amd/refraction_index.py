@@ -18,34 +18,33 @@ from .spectrum import Spectrum, wavelengths
 _FdC = [486.1327, 587.5618, 656.272]
 
 
+#: coefficient formulas: name -> (number of coefficients, device model code)
+_FORMULAS = {
+    "Cauchy": (4, _capi.N_CAUCHY), "Conrady": (3, _capi.N_CONRADY),
+    "Sellmeier1": (6, _capi.N_SELLMEIER1), "Sellmeier2": (5, _capi.N_SELLMEIER2),
+    "Sellmeier3": (8, _capi.N_SELLMEIER3), "Sellmeier4": (5, _capi.N_SELLMEIER4),
+    "Sellmeier5": (10, _capi.N_SELLMEIER5), "Herzberger": (6, _capi.N_HERZBERGER),
+    "Extended": (8, _capi.N_EXTENDED), "Extended2": (8, _capi.N_EXTENDED2), "Extended3": (9, _capi.N_EXTENDED3),
+    "Handbook of Optics 1": (4, _capi.N_HOO1), "Handbook of Optics 2": (4, _capi.N_HOO2),
+    "Schott": (6, _capi.N_SCHOTT),
+}
+
+
 class RefractionIndex(Spectrum):
 
-    coeff_count = {"Cauchy": 4, "Conrady": 3, "Sellmeier1": 6, "Sellmeier2": 5, "Sellmeier3": 8,
-                   "Sellmeier4": 5, "Sellmeier5": 10, "Herzberger": 6, "Extended": 8, "Extended2": 8,
-                   "Handbook of Optics 1": 4, "Handbook of Optics 2": 4, "Schott": 6, "Extended3": 9}
-
-    n_types = ["Abbe", "Cauchy", "Conrady", "Constant", "Data", "Extended", "Extended2", "Extended3",
-               "Function", "Handbook of Optics 1", "Handbook of Optics 2", "Sellmeier1", "Sellmeier2",
-               "Sellmeier3", "Sellmeier4", "Sellmeier5", "Herzberger", "Schott"]
+    coeff_count = {name: count for name, (count, _) in _FORMULAS.items()}
+    n_types = sorted(["Abbe", "Constant", "Data", "Function", *_FORMULAS])
     spectrum_types = n_types
     quantity = "Refraction Index n"
     unit = ""
-
-    _models = {"Cauchy": _capi.N_CAUCHY, "Conrady": _capi.N_CONRADY, "Sellmeier1": _capi.N_SELLMEIER1,
-               "Sellmeier2": _capi.N_SELLMEIER2, "Sellmeier3": _capi.N_SELLMEIER3,
-               "Sellmeier4": _capi.N_SELLMEIER4, "Sellmeier5": _capi.N_SELLMEIER5,
-               "Herzberger": _capi.N_HERZBERGER, "Extended": _capi.N_EXTENDED,
-               "Extended2": _capi.N_EXTENDED2, "Extended3": _capi.N_EXTENDED3,
-               "Handbook of Optics 1": _capi.N_HOO1, "Handbook of Optics 2": _capi.N_HOO2,
-               "Schott": _capi.N_SCHOTT}
+    _amplitude_checked = False   # `val` is an index (>= 1), `func` returns indices: own checks below
+    _models = {name: code for name, (_, code) in _FORMULAS.items()}
 
     def __init__(self, n_type: str = "Constant", n: float = 1.0, coeff: list = None, lines=None,
                  V: float = None, **kwargs) -> None:
-        self.spectrum_type = n_type
-        self.coeff = coeff
-        self.V = V
-        lines = lines if lines is not None else _FdC
-        super().__init__(n_type, val=n, lines=lines, **kwargs)
+        self.spectrum_type = n_type     # first: the coefficient count check needs it
+        self.coeff, self.V = coeff, V
+        super().__init__(n_type, val=n, lines=_FdC if lines is None else lines, **kwargs)
         self._new_lock = True
 
     # ---- device descriptor ----------------------------------------------------------------------
@@ -103,68 +102,76 @@ class RefractionIndex(Spectrum):
     def __call__(self, wl) -> np.ndarray:
         """n at the given wavelengths [nm] (refraction_index.py:62-169), computed on the GPU."""
         from . import ops
-        wl_ = np.asarray_chkfinite(wl, dtype=np.float64)
-        if self.spectrum_type == "Data" and wl_.size and (wl_.min() < self._wls[0] or wl_.max() > self._wls[-1]):
-            raise RuntimeError(f"Wavelength range [{wl_.min():.5g}, {wl_.max():.5g}] larger than data range"
-                               f" [{self._wls[0]}, {self._wls[-1]}] for this material.")
-        if self.spectrum_type == "Function":
-            ns = np.asarray(self.func(wl_, **self.func_args), dtype=np.float64)
+        x = np.asarray_chkfinite(wl, dtype=np.float64)
+        kind = self.spectrum_type
+        if kind == "Data" and x.size:
+            lo, hi = self._wls[0], self._wls[-1]
+            if x.min() < lo or x.max() > hi:
+                raise RuntimeError(f"Wavelength range [{x.min():.5g}, {x.max():.5g}] larger than data range"
+                                   f" [{lo}, {hi}] for this material.")
+        if kind == "Function":
+            ns = np.asarray(self.func(x, **self.func_args), dtype=np.float64)
         else:
             pool: list = []
-            md = self._desc(pool)
-            ns = ops.refraction_index(md, np.array(pool, dtype=np.float64), wl_.reshape(-1)).reshape(wl_.shape)
-        if ns.size and (nm := ns.min()) < 1:
-            raise RuntimeError(f"Refraction index below 1 with value {nm:.4g} at {wl_.flat[np.argmin(ns)]:.4g}nm.")
+            medium = self._desc(pool)
+            ns = ops.refraction_index(medium, np.array(pool, dtype=np.float64), x.reshape(-1)).reshape(x.shape)
+        if ns.size:
+            worst = int(np.argmin(ns))
+            if ns.flat[worst] < 1:
+                raise RuntimeError(f"Refraction index below 1 with value {ns.flat[worst]:.4g} at {x.flat[worst]:.4g}nm.")
         return ns
 
     def __eq__(self, other: Any) -> bool:
-        if type(self) is not type(other):
-            return False
-        if self is other or (self.spectrum_type != "Data" and self.crepr() == other.crepr()):
+        if self is other:
             return True
-        if self.spectrum_type == "Data" and other.spectrum_type == "Data":
-            return bool(np.all(self._wls == other._wls) and np.all(self._vals == other._vals))
-        return False
+        if type(other) is not type(self):
+            return False
+        if "Data" not in (self.spectrum_type, other.spectrum_type):
+            return self.crepr() == other.crepr()
+        if self.spectrum_type != other.spectrum_type:
+            return False
+        return bool(np.array_equal(self._wls, other._wls) and np.array_equal(self._vals, other._vals))
 
     def __ne__(self, other: Any) -> bool:
-        return not self.__eq__(other)
+        return not self == other
 
     __hash__ = object.__hash__
 
     def abbe_number(self, lines: list = None) -> float:
-        lines = lines if lines is not None else self.lines
-        ns, nc, nl = tuple(self(lines))
-        return float((nc - 1) / (ns - nl) if ns != nl else np.inf)
+        """(n_centre - 1) / (n_short - n_long) at the three lines; inf for a medium without dispersion."""
+        n_short, n_centre, n_long = self(self.lines if lines is None else lines)
+        spread = n_short - n_long
+        return float((n_centre - 1) / spread) if spread else float("inf")
 
     def is_dispersive(self) -> bool:
         return bool(np.isfinite(self.abbe_number()))
+
+    def _check_coeff(self, coeff: list) -> list:
+        check_type("coeff", coeff, list)
+        need = self.coeff_count[self.spectrum_type]
+        if len(coeff) != need:
+            raise ValueError(f"coeff needs to be a list with exactly {need} numeric coefficients for mode "
+                             f"{self.spectrum_type}, but got {len(coeff)}.")
+        return list(coeff)
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key == "val":
             check_type(key, val, (int, float))
             np.asarray_chkfinite(val)
             check_not_below(key, val, 1)
-        elif key == "coeff" and val is not None:
-            check_type(key, val, list)
-            cnt = self.coeff_count[self.spectrum_type]
-            if len(val) != cnt:
-                raise ValueError(f"{key} needs to be a list with exactly {cnt} numeric coefficients for mode "
-                                 f"{self.spectrum_type}, but got {len(val)}.")
-            val = val.copy()
-        elif key == "_vals" and val is not None:
-            if np.min(val) < 1:
-                raise ValueError("all vals values needs to be at least 1.")
-        elif key == "lines" and isinstance(val, (list, np.ndarray)):
-            if len(val) != 3:
-                raise ValueError("Property 'lines' for n_type='Abbe' needs to have exactly 3 elements")
-            if not val[0] < val[1] < val[2]:
-                raise ValueError("The values of property 'lines' need to be ascending.")
-        elif key == "func" and callable(val):
-            n = val(wavelengths(1000), **self.func_args)
-            if n.min() < 1:
-                raise ValueError("Function func needs to output values >= 1 over the whole visible range.")
         elif key == "V" and val is not None:
             check_type(key, val, (float, int))
             check_above(key, val, 0)
             np.asarray_chkfinite(val)
+        elif key == "coeff" and val is not None:
+            val = self._check_coeff(val)
+        elif key == "_vals" and val is not None and np.min(val) < 1:
+            raise ValueError("all vals values needs to be at least 1.")
+        elif key == "lines" and isinstance(val, (list, np.ndarray)):
+            if len(val) != 3:
+                raise ValueError("Property 'lines' for n_type='Abbe' needs to have exactly 3 elements")
+            if not (val[0] < val[1] and val[1] < val[2]):
+                raise ValueError("The values of property 'lines' need to be ascending.")
+        elif key == "func" and callable(val) and np.min(val(wavelengths(1000), **self.func_args)) < 1:
+            raise ValueError("Function func needs to output values >= 1 over the whole visible range.")
         super().__setattr__(key, val)

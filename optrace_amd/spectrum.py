@@ -49,10 +49,36 @@ def blackbody(wl: np.ndarray, T: float = 6504.) -> np.ndarray:
 
 def normalized_blackbody(wl: np.ndarray, T: float = 6504.) -> np.ndarray:
     """Blackbody curve with its maximum inside the visible range scaled to 1 (color/tools.py:46-61)."""
-    l_w = 2897.771955 * 1e3 / T
-    p_w, p_l, p_r = blackbody(np.array([l_w, *go.wavelength_range]), T)
-    p_max = p_w if go.wavelength_range[0] <= l_w <= go.wavelength_range[1] else max(p_l, p_r)
-    return blackbody(wl, T) / p_max
+    lo, hi = go.wavelength_range
+    peak = 2897.771955e3 / T  # Wien's displacement law, in nm
+    candidates = [peak] if lo <= peak <= hi else [lo, hi]
+    return blackbody(wl, T) / blackbody(np.array(candidates), T).max()
+
+
+def _finite(wl) -> np.ndarray:
+    return np.asarray_chkfinite(wl, dtype=np.float64)
+
+
+def _private(values, dtype) -> np.ndarray:
+    """Checked private copy that changes only by assignment (the scene's change detection relies on that)."""
+    arr = np.array(np.asarray_chkfinite(values, dtype=dtype))
+    arr.setflags(write=False)
+    return arr
+
+
+def _visible(key: str, v) -> float:
+    check_type(key, v, (int, float))
+    lo, hi = go.wavelength_range
+    if not lo <= v <= hi:
+        raise ValueError(f"Property '{key}' needs to be inside {go.wavelength_range}, but is {float(v)}.")
+    return float(v)
+
+
+def _above_zero(key: str, v) -> float:
+    check_type(key, v, (int, float))
+    if not v > 0:
+        raise ValueError(f"{key} needs to be above 0")
+    return float(v)
 
 
 class Spectrum(BaseClass):
@@ -61,110 +87,117 @@ class Spectrum(BaseClass):
     spectrum_types = ["Monochromatic", "Constant", "Data", "Lines", "Rectangle", "Gaussian", "Function"]
     unit = ""
     quantity = ""
+    _amplitude_checked = True    # RefractionIndex stores indices in `val` and `func`: no sign checks there
 
     def __init__(self, spectrum_type: str = "Gaussian", val: float = 1., lines=None, line_vals=None,
                  wl: float = 550., wl0: float = 400., wl1: float = 600., wls=None, vals=None,
                  func: Callable = None, mu: float = 550., sig: float = 50., unit: str = None,
                  quantity: str = None, func_args: dict = {}, **kwargs) -> None:
-        self.spectrum_type = spectrum_type
-        self.lines = lines
-        self.line_vals = line_vals
-        self.func_args = func_args
-        self.func = func
-        self.wl, self.wl0, self.wl1 = wl, wl0, wl1
-        self.val, self.mu, self.sig = val, mu, sig
-        self._wls, self._vals = wls, vals
-        self.unit = unit if unit is not None else self.unit
-        self.quantity = quantity if quantity is not None else self.quantity
+        given = dict(spectrum_type=spectrum_type, lines=lines, line_vals=line_vals, func_args=func_args, func=func,
+                     wl=wl, wl0=wl0, wl1=wl1, val=val, mu=mu, sig=sig, _wls=wls, _vals=vals)
+        for name, value in given.items():   # func_args before func: the function is probed with them
+            setattr(self, name, value)
+        for name, value in (("unit", unit), ("quantity", quantity)):
+            if value is not None:
+                setattr(self, name, value)
         super().__init__(**kwargs)
         self._new_lock = True
 
     def is_continuous(self) -> bool:
-        return self.spectrum_type not in ["Lines", "Monochromatic"]
+        return self.spectrum_type not in ("Lines", "Monochromatic")
 
     def _eval_host(self, wl) -> np.ndarray:
         """Spectrum values on the host -- scene set-up (tabulating callables) only (spectrum.py:81-120)."""
+        kind = self.spectrum_type
         if not self.is_continuous():
-            raise RuntimeError(f"Can't call discontinuous spectrum_type '{self.spectrum_type}'")
-        wl_ = np.asarray_chkfinite(wl, dtype=np.float64)
-        st = self.spectrum_type
-        if st == "Constant":
-            return np.broadcast_to(self.val, wl_.shape)
-        if st == "Data":
-            return np.interp(wl_, self._wls, self._vals, left=0, right=0)
-        if st == "Rectangle":
-            res = np.zeros_like(wl_, dtype=np.float64)
-            res[(self.wl0 <= wl_) & (wl_ <= self.wl1)] = self.val
-            return res
-        if st == "Gaussian":
-            return self.val * np.exp(-(wl_ - self.mu) ** 2 / (2 * self.sig ** 2))
-        if st == "Function":
-            return self.func(wl_, **self.func_args)
-        raise AssertionError(st)
+            raise RuntimeError(f"Can't call discontinuous spectrum_type '{kind}'")
+        x = _finite(wl)
+        if kind == "Constant":
+            return np.broadcast_to(self.val, x.shape)
+        if kind == "Data":
+            return np.interp(x, self._wls, self._vals, left=0., right=0.)
+        if kind == "Rectangle":
+            return np.where((x >= self.wl0) & (x <= self.wl1), self.val, 0.)
+        if kind == "Gaussian":
+            return self.val * np.exp(-(x - self.mu) ** 2 / (2 * self.sig ** 2))
+        if kind == "Function":
+            return self.func(x, **self.func_args)
+        raise AssertionError(kind)
 
     def __call__(self, wl) -> np.ndarray:
         return self._eval_host(wl)
 
     def get_desc(self, fallback: str = None) -> str:
-        fallback = str(self.val) if self.spectrum_type == "Constant" else self.spectrum_type
-        return super().get_desc(fallback=fallback)
+        own = self.spectrum_type if self.spectrum_type != "Constant" else str(self.val)
+        return super().get_desc(fallback=own)
+
+    # ---- property checks, one small method per group of properties
+    def _check_lines(self, key, v):
+        check_type(key, v, (list, np.ndarray))
+        arr = _private(v, np.float32)  # float32 like the reference (spectrum.py:168)
+        if not arr.shape[0]:
+            raise ValueError(f"'{key}' can't be empty.")
+        if key == "line_vals":
+            if arr.min() < 0:
+                raise ValueError("line_vals must be all positive.")
+            return arr
+        lo, hi = go.wavelength_range
+        if arr.min() < lo or arr.max() > hi:
+            raise ValueError(f"'lines' need to be inside visible range {go.wavelength_range}.")
+        if np.unique(v).size != len(v):
+            raise ValueError("All elements inside of 'lines' must be unique.")
+        return arr
+
+    def _check_table(self, key, v):
+        check_type(key, v, (list, np.ndarray))
+        arr = _private(v, np.float64)
+        if key == "_vals":
+            if arr.min() < 0:
+                raise ValueError("vals must be all positive")
+            return arr
+        lo, hi = go.wavelength_range
+        if arr[0] < lo or arr[-1] > hi:
+            raise ValueError("wls needs to be inside the visible range")
+        steps = np.diff(arr)
+        if steps.std() > 1e-4 or steps.min() <= 0 or steps[0] < 1e-6:
+            raise ValueError("wls needs to be monotonically increasing with the same step size.")
+        return arr
+
+    def _check_func(self, key, f):
+        if f is None:
+            return None
+        if not callable(f):
+            raise TypeError("func needs to be callable or None")
+        if self._amplitude_checked:
+            probe = f(wavelengths(10000), **self.func_args)
+            if np.min(probe) < 0 or not np.max(probe) > 0:
+                raise RuntimeError("Function func needs to return positive values over the visible range.")
+        return f
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key == "spectrum_type":
             check_type(key, val, str)
             check_in(key, val, self.spectrum_types)
-        elif key in ("lines", "line_vals") and val is not None:
-            check_type(key, val, (list, np.ndarray))
-            val2 = np.array(np.asarray_chkfinite(val, dtype=np.float32))  # float32 like the reference (spectrum.py:168)
-            if val2.shape[0] == 0:
-                raise ValueError(f"'{key}' can't be empty.")
-            if key == "lines" and (val2.min() < go.wavelength_range[0] or val2.max() > go.wavelength_range[1]):
-                raise ValueError(f"'lines' need to be inside visible range {go.wavelength_range}.")
-            if key == "line_vals" and val2.min() < 0:
-                raise ValueError("line_vals must be all positive.")
-            if key == "lines" and len(np.unique(val)) != len(val):
-                raise ValueError("All elements inside of 'lines' must be unique.")
-            val = val2
-            val.flags.writeable = False  # a private copy that changes only by assignment (change detection)
+        elif key in ("quantity", "unit"):
+            check_type(key, val, str)
         elif key == "func_args":
             check_type(key, val, dict)
             val = copy.deepcopy(val)
-        elif key in ("quantity", "unit"):
-            check_type(key, val, str)
         elif key == "func":
-            if val is not None and not callable(val):
-                raise TypeError("func needs to be callable or None")
-            if val is not None and type(self).__name__ != "RefractionIndex":
-                T = val(wavelengths(10000), **self.func_args)
-                if np.min(T) < 0 or np.max(T) <= 0:
-                    raise RuntimeError("Function func needs to return positive values over the visible range.")
-        elif key in ("_wls", "_vals") and val is not None:
-            check_type(key, val, (list, np.ndarray))
-            val2 = np.array(np.asarray_chkfinite(val, dtype=np.float64))
-            if key == "_wls":
-                if val2[0] < go.wavelength_range[0] or val2[-1] > go.wavelength_range[1]:
-                    raise ValueError("wls needs to be inside the visible range")
-                if np.std(np.diff(val2)) > 1e-4 or np.any(np.diff(val2) <= 0) or (val2[1] - val2[0] < 1e-6):
-                    raise ValueError("wls needs to be monotonically increasing with the same step size.")
-            elif val2.min() < 0:
-                raise ValueError("vals must be all positive")
-            val = val2
-            val.flags.writeable = False  # private copy, see `lines`
+            val = self._check_func(key, val)
         elif key in ("wl", "wl0", "wl1", "mu"):
-            check_type(key, val, (int, float))
-            val = float(val)
-            if val < go.wavelength_range[0] or val > go.wavelength_range[1]:
-                raise ValueError(f"Property '{key}' needs to be inside {go.wavelength_range}, but is {val}.")
+            val = _visible(key, val)
         elif key == "sig":
+            val = _above_zero(key, val)
+        elif key == "val" and self._amplitude_checked:
             check_type(key, val, (int, float))
-            val = float(val)
-            if val <= 0:
-                raise ValueError("sig needs to be above 0")
-        elif key == "val" and type(self).__name__ != "RefractionIndex":
-            check_type(key, val, (int, float))
-            val = float(val)
             if val < 0:
                 raise ValueError("val needs to be at least 0")
+            val = float(val)
+        elif val is not None and key in ("lines", "line_vals"):
+            val = self._check_lines(key, val)
+        elif val is not None and key in ("_wls", "_vals"):
+            val = self._check_table(key, val)
         super().__setattr__(key, val)
 
 
@@ -175,21 +208,20 @@ class LightSpectrum(Spectrum):
 
     def __init__(self, spectrum_type: str = "Blackbody", T: float = 5500, **sargs) -> None:
         self.T = T
-        line_spec = spectrum_type in ["Monochromatic", "Lines"]
-        unit = "W" if line_spec else "W/nm"
-        quantity = "Spectral Power" if line_spec else "Spectral Power Density"
-        super().__init__(spectrum_type, unit=unit, quantity=quantity, **sargs)
+        discrete = spectrum_type in ("Monochromatic", "Lines")   # powers per line, densities otherwise
+        super().__init__(spectrum_type, unit="W" if discrete else "W/nm",
+                         quantity="Spectral Power" + ("" if discrete else " Density"), **sargs)
 
     def _eval_host(self, wl) -> np.ndarray:
-        if self.spectrum_type == "Blackbody":
-            return self.val * normalized_blackbody(np.asarray_chkfinite(wl, dtype=np.float64), T=self.T)
-        if self.spectrum_type == "Histogram":
-            wl_ = np.asarray_chkfinite(wl, dtype=np.float64)
-            ind = np.digitize(wl_, self._wls)
-            ins = (ind > 0) & (ind < self._wls.shape[0])
-            res = np.zeros_like(wl_)
-            res[ins] = self._vals[ind[ins] - 1]
-            return res
+        kind = self.spectrum_type
+        if kind == "Blackbody":
+            return self.val * normalized_blackbody(_finite(wl), T=self.T)
+        if kind == "Histogram":
+            x = _finite(wl)
+            edges, heights = self._wls, self._vals
+            bin_ = np.searchsorted(edges, x, side="right") - 1    # bin i covers [edge i, edge i+1)
+            inside = (bin_ >= 0) & (bin_ < len(edges) - 1)
+            return np.where(inside, heights[np.clip(bin_, 0, len(heights) - 1)], 0.)
         return super()._eval_host(wl)
 
     @staticmethod
@@ -275,12 +307,7 @@ class LightSpectrum(Spectrum):
                     n_spec=len(x))
 
     def __setattr__(self, key, val):
-        if key == "T":
-            check_type(key, val, (int, float))
-            val = float(val)
-            if val <= 0:
-                raise ValueError("T needs to be above 0")
-        super().__setattr__(key, val)
+        super().__setattr__(key, _above_zero(key, val) if key == "T" else val)
 
 
 class TransmissionSpectrum(Spectrum):
