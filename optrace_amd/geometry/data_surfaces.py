@@ -77,48 +77,45 @@ class TiltedSurface(Surface):
     _kind = _capi.SURF_TILTED
 
     def __init__(self, r: float, normal=None, normal_sph=None, **kwargs) -> None:
-        self._lock = False
-        super().__init__(r, **kwargs)
-        self.r = r
-        self.parax_roc = None
-        self.z_min = self.z_max = self.pos[2]
-        if normal is not None:
-            self.normal = normal
-        elif normal_sph is not None:
+        Surface.__init__(self, r, **kwargs)
+        if normal is None:
+            if normal_sph is None:
+                raise RuntimeError("normal or normal_sph parameter needs to be specified.")
             check_type("normal_sph", normal_sph, (list, np.ndarray))
-            theta, phi = np.radians(normal_sph[0]), np.radians(normal_sph[1])
-            self.normal = [np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)]
-        else:
-            raise RuntimeError("normal or normal_sph parameter needs to be specified.")
-        # the extreme heights lie on the edge along the projected normal (tilted_surface.py:46-50)
-        phi = np.arctan2(self.normal[1], self.normal[0])
-        R = self.r
-        val1 = self.pos[2] + self._values_rel_host(np.array([R * np.cos(phi)]), np.array([R * np.sin(phi)]))[0]
-        val2 = self.pos[2] + self._values_rel_host(np.array([-R * np.cos(phi)]), np.array([-R * np.sin(phi)]))[0]
-        self.z_min, self.z_max = min(val1, val2), max(val1, val2)
+            polar, azimuth = (np.radians(angle) for angle in normal_sph[:2])
+            normal = [np.sin(polar) * np.cos(azimuth), np.sin(polar) * np.sin(azimuth), np.cos(polar)]
+        self.normal = normal
+        self.parax_roc = None
+        self._measure_z_range()
         self.lock()
+
+    def _measure_z_range(self) -> None:
+        """The extreme heights lie on the edge, in the direction of the projected normal and opposite to it
+        (tilted_surface.py:46-50)."""
+        azimuth = np.arctan2(self.normal[1], self.normal[0])
+        ex, ey = self.r * np.cos(azimuth), self.r * np.sin(azimuth)
+        ends = [self.pos[2] + self._values_rel_host(np.array([sx]), np.array([sy]))[0] for sx, sy in ((ex, ey), (-ex, -ey))]
+        self.z_min, self.z_max = min(ends), max(ends)
 
     @property
     def info(self) -> str:
-        return super().info + f", normal = [{self.normal[0]:.4f}, {self.normal[1]:.4f}, {self.normal[2]:.4f}]"
+        nx, ny, nz = self.normal
+        return f"{super().info}, normal = [{nx:.4f}, {ny:.4f}, {nz:.4f}]"
 
     def _values_rel_host(self, x, y):
-        mx = -self.normal[0] / self.normal[2]
-        my = -self.normal[1] / self.normal[2]
-        return x * mx + y * my
+        nx, ny, nz = self.normal
+        return x * (-nx / nz) + y * (-ny / nz)
+
+    def _turn_normal(self, nx: float, ny: float) -> None:
+        with self._edit():   # unit length is kept by both operations: stored as it is, not normalised again
+            Surface.__setattr__(self, "normal", np.array([nx, ny, self.normal[2]], dtype=np.float64))
 
     def flip(self) -> None:
         """Flip around the x-axis: [x, y, z] -> [x, -y, -z], negated to point towards +z: [-x, y, z]."""
-        self._lock = False
-        self.normal.flags.writeable = True
-        self.normal[0] *= -1
-        self.lock()
+        self._turn_normal(-self.normal[0], self.normal[1])
 
     def rotate(self, angle: float) -> None:
-        self._lock = False
-        self.normal.flags.writeable = True
-        self.normal[:2] = self._rotate_rc(self.normal[0], self.normal[1], np.deg2rad(angle))
-        self.lock()
+        self._turn_normal(*self._rotate_rc(self.normal[0], self.normal[1], np.deg2rad(angle)))
 
     def _desc(self):
         d = super()._desc()
@@ -128,14 +125,17 @@ class TiltedSurface(Surface):
     def __setattr__(self, key: str, val: Any) -> None:
         if key == "normal" and val is not None:
             check_type(key, val, (list, np.ndarray))
-            val2 = np.asarray_chkfinite(val, dtype=np.float64) / np.linalg.norm(val)
-            check_above("normal[2]", val2[2], 0)
-            super().__setattr__(key, val2)
-        else:
-            super().__setattr__(key, val)
+            val = np.asarray_chkfinite(val, dtype=np.float64) / np.linalg.norm(val)
+            check_above("normal[2]", val[2], 0)
+        super().__setattr__(key, val)
 
 
 # ---- data surfaces ---------------------------------------------------------------------------------------------
+def _mirrored(r0: np.ndarray, z: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Radial profile 0..r continued to -r..r: symmetric, the centre once (data_surface_2d.py:67-70)."""
+    return np.concatenate((-r0[:0:-1], r0)), np.concatenate((z[:0:-1], z))
+
+
 class DataSurface2D(Surface):
     """Surface given by a square grid of heights (data_surface_2d.py:10-227), interpolated by a quartic
     tensor-product B-spline (RectBivariateSpline(kx=4, ky=4)) that the device evaluates."""
@@ -144,88 +144,86 @@ class DataSurface2D(Surface):
     _1D = False
     _kind = _capi.SURF_DATA2D
 
+    def _reset_frame(self) -> None:
+        self._sign, self._angle = 1, 0
+        self._interp, self._offset, self._tab = None, 0., None
+
+    def _label(self) -> str:
+        return f"{type(self).__name__} {self.get_desc(hex(id(self)))}"
+
     def __init__(self, r: float, data: np.ndarray, parax_roc: float = None, **kwargs) -> None:
-        self._lock = False
-        super().__init__(r, **kwargs)
-        self._sign = 1
-        self._angle = 0
-        self._interp, self._offset = None, 0.
-        self._tab = None
+        Surface.__init__(self, r, **kwargs)
+        self._reset_frame()
         self.parax_roc = parax_roc
 
         check_type("data", data, (np.ndarray, list))
-        Z = np.asarray_chkfinite(data, dtype=np.float64).copy()
-        surf_name = f"{type(self).__name__} {self.get_desc(hex(id(self)))}"
-        nx = Z.shape[0]
-        if nx < 50:
+        heights = np.array(np.asarray_chkfinite(data, dtype=np.float64))
+        samples = heights.shape[0]
+        if samples < 50:
             raise ValueError("For a good surface representation 'data' should have at least 50 values per dimension")
-        if nx < 200:
-            warning(f"{surf_name}: At least 200 values per dimension are advised for a 'data' matrix, "
-                    f"but got {nx} values for surface {self.get_desc(hex(id(self)))}.")
-        z_range0 = self._fit(Z)
+        if samples < 200:
+            warning(f"{self._label()}: At least 200 values per dimension are advised for a 'data' matrix, but got "
+                    f"{samples} values for surface {self.get_desc(hex(id(self)))}.")
+        given = self._fit_profile(heights) if self._1D else self._fit_grid(heights)
 
-        # interpolation can enlarge the z range (data_surface_2d.py:108-119)
-        z_range1 = self.z_max - self.z_min
-        if np.abs(z_range0 - z_range1) > self.N_EPS:
-            z_change = (z_range1 - z_range0) / z_range0
-            add_warning = "WARNING: Deviations this high can be due to noise or abrupt changes in the data."\
-                          " DO NOT USE SUCH SURFACES HERE." if z_change > 0.05 else ""
-            warning(f"{surf_name}: Due to biquadratic interpolation the z_range of the surface"
-                    f" has increased from {z_range0:.9g} to {z_range1:.9g},"
-                    f" a change of {z_change*100:.5g}%. {add_warning}")
+        # the spline can overshoot the samples (data_surface_2d.py:108-119)
+        fitted = self.z_max - self.z_min
+        if abs(given - fitted) > self.N_EPS:
+            growth = (fitted - given) / given
+            alarm = ("WARNING: Deviations this high can be due to noise or abrupt changes in the data. "
+                     "DO NOT USE SUCH SURFACES HERE.") if growth > 0.05 else ""
+            warning(f"{self._label()}: Due to biquadratic interpolation the z_range of the surface has increased "
+                    f"from {given:.9g} to {fitted:.9g}, a change of {growth*100:.5g}%. {alarm}")
         self.lock()
 
-    def _fit(self, Z: np.ndarray) -> float:
-        """Spline fit + z range (data_surface_2d.py:59-104); returns the z range of the input data."""
-        if self._1D:
-            if Z.ndim != 1:
-                raise ValueError("data array needs to have exactly one dimension.")
-            Z -= Z[0]
-            r0 = np.linspace(0, self.r, Z.shape[0], dtype=np.float64)
-            # mirrored profile: symmetric, centre included (data_surface_2d.py:67-70)
-            r2 = np.concatenate((-np.flip(r0[1:]), r0))
-            z2 = np.concatenate((np.flip(Z[1:]), Z))
-            self._interp = scipy.interpolate.InterpolatedUnivariateSpline(r2, z2, k=_K)
-            self._tab, self._nknots = _table_1d(self._interp)
-            self._offset = float(self._call(0, 0))
-            rn = np.linspace(0, self.r, 10000)
-            zn = self._values_rel_host(rn, np.zeros_like(rn))
-            self.z_min, self.z_max = float(np.min(zn)), float(np.max(zn))
-            return float(np.ptp(Z))
+    def _fit_profile(self, z: np.ndarray) -> float:
+        """Spline through the mirrored radial profile (data_surface_2d.py:60-86); returns the z range of the data."""
+        if z.ndim != 1:
+            raise ValueError("data array needs to have exactly one dimension.")
+        z -= z[0]
+        radii = np.linspace(0., self.r, z.shape[0])
+        self._interp = scipy.interpolate.InterpolatedUnivariateSpline(*_mirrored(radii, z), k=_K)
+        self._tab, self._nknots = _table_1d(self._interp)
+        self._offset = float(self._call(0, 0))
+        self._measure_profile_range()
+        return float(z.max() - z.min())
 
+    def _measure_profile_range(self) -> None:
+        radii = np.linspace(0., self.r, 10000)
+        sag = self._values_rel_host(radii, np.zeros(radii.shape))
+        self.z_min, self.z_max = float(sag.min()), float(sag.max())
+
+    def _fit_grid(self, Z: np.ndarray) -> float:
+        """Tensor-product spline through the square grid (data_surface_2d.py:88-104); returns the z range of the
+        samples inside the disc."""
         if Z.ndim != 2:
             raise ValueError("data array needs to have exactly two dimensions.")
-        ny, nx = Z.shape
-        if nx != ny:
+        n = Z.shape[1]
+        if Z.shape[0] != n:
             raise ValueError("Array 'data' needs to be of square shape.")
-        if nx % 2:  # remove the offset at the centre (data_surface_2d.py:92-95)
-            Z -= np.array([Z[ny//2, nx//2], Z[ny//2+1, nx//2], Z[ny//2, nx//2+1], Z[ny//2+1, nx//2+1]]).mean()
-        else:
-            Z -= Z[ny//2, nx//2]
-        xy = np.linspace(-self.r, self.r, nx)
-        self._interp = scipy.interpolate.RectBivariateSpline(xy, xy, Z, kx=_K, ky=_K)
+        c = n // 2
+        # height at the centre goes; for odd n the reference averages these four samples, in this order
+        Z -= Z[[c, c + 1, c, c + 1], [c, c, c + 1, c + 1]].mean() if n % 2 else Z[c, c]
+        axis = np.linspace(-self.r, self.r, n)
+        self._interp = scipy.interpolate.RectBivariateSpline(axis, axis, Z, kx=_K, ky=_K)
         self._tab, self._nknots = _table_2d(self._interp)
         self._offset = float(self._call(0, 0))
         self.z_min, self.z_max = self._find_bounds()
-        X, Y = np.meshgrid(xy, xy)
-        M = self._mask_host(X.ravel(), Y.ravel()).reshape(X.shape)
-        return float(np.max(Z[M]) - np.min(Z[M]))
+        inside = self._mask_host(*(g.ravel() for g in np.meshgrid(axis, axis))).reshape(Z.shape)
+        return float(Z[inside].max() - Z[inside].min())
 
     def _find_bounds(self) -> tuple[float, float]:
         """z range from sunflower sampling of the disc plus its edge (surface.py:57-93); set-up only."""
-        N = 50000
-        ind = np.arange(0, N, dtype=np.float64)
-        r = np.sqrt(ind / N) * self.r
-        phi = 2 * np.pi * (1 + 5 ** 0.5) / 2 * ind
-        rcos, rsin = r * np.cos(phi), r * np.sin(phi)
-        vals = np.array(self._values_rel_host(rcos, rsin), dtype=np.float64)
-        mask = self._mask_host(rcos - self.pos[0], rsin - self.pos[1])
-        vals[~mask] = np.nan
-        xv, yv, vals2 = self.edge(3001)
-        vals2 = vals2 - self.pos[2]
-        mask = self._mask_host(xv, yv)
-        vals2[~mask] = np.nan
-        return float(min(np.nanmin(vals), np.nanmin(vals2))), float(max(np.nanmax(vals), np.nanmax(vals2)))
+        count = 50000
+        i = np.arange(count, dtype=np.float64)
+        rho, turn = np.sqrt(i / count) * self.r, 2 * np.pi * (1 + 5 ** 0.5) / 2 * i
+        sx, sy = rho * np.cos(turn), rho * np.sin(turn)
+        area = np.array(self._values_rel_host(sx, sy), dtype=np.float64)
+        area = area[self._mask_host(sx - self.pos[0], sy - self.pos[1])]
+        ex, ey, ez = self.edge(3001)
+        rim = (ez - self.pos[2])[self._mask_host(ex, ey)]
+        both = np.concatenate((area, rim))
+        return float(np.nanmin(both)), float(np.nanmax(both))
 
     def _call(self, x, y, **kwargs):
         if self._1D:
@@ -233,23 +231,22 @@ class DataSurface2D(Surface):
         return self._interp(x, y, grid=False, **kwargs)
 
     def _values_rel_host(self, x, y):
-        x_, y_ = self._rotate_rc(x, y, -self._angle) if not self.rotational_symmetry else (x, y)
-        return self._sign * (self._call(x_, self._sign * y_) - self._offset)
+        if not self.rotational_symmetry:
+            x, y = self._rotate_rc(x, y, -self._angle)
+        return self._sign * (self._call(x, self._sign * y) - self._offset)
 
     def flip(self) -> None:
-        self._lock = False
-        self._sign *= -1
-        self.parax_roc = self.parax_roc if self.parax_roc is None else -self.parax_roc
-        a = self.pos[2] - (self.z_max - self.pos[2])
-        b = self.pos[2] - (self.z_min - self.pos[2])
-        self.z_min, self.z_max = a, b
-        self.lock()
+        with self._edit():
+            self._sign = -self._sign
+            if self.parax_roc is not None:
+                self.parax_roc = -self.parax_roc
+            self._mirror_z_range()
 
     def rotate(self, angle: float) -> None:
-        if not self.rotational_symmetry:
-            self._lock = False
-            self._angle += np.deg2rad(angle)
-            self.lock()
+        if self.rotational_symmetry:
+            return
+        with self._edit():
+            self._angle = self._angle + np.deg2rad(angle)
 
     def _desc(self):
         d = super()._desc()
@@ -265,10 +262,6 @@ class DataSurface1D(DataSurface2D):
     rotational_symmetry = True
     _1D = True
     _kind = _capi.SURF_DATA1D
-
-    def __init__(self, r: float, data: np.ndarray, parax_roc: float = None, **kwargs) -> None:
-        self._lock = False
-        super().__init__(r=r, data=data, parax_roc=parax_roc, **kwargs)
 
 
 # ---- function surfaces -------------------------------------------------------------------------------------------
@@ -301,17 +294,11 @@ class FunctionSurface2D(DataSurface2D):
     def __init__(self, r: float, func: Callable, mask_func: Callable = None, deriv_func: Callable = None,
                  func_args: dict = {}, mask_args: dict = {}, deriv_args: dict = {}, z_min: float = None,
                  z_max: float = None, parax_roc: float = None, **kwargs) -> None:
-        self._lock = False
         Surface.__init__(self, r, **kwargs)
-        self._sign = 1
-        self._angle = 0
-        self._interp, self._offset, self._tab = None, 0., None
-        self.func = func
-        self.mask_func = mask_func
-        self.deriv_func = deriv_func
-        self._func_args = func_args
-        self._mask_args = mask_args
-        self._deriv_args = deriv_args
+        self._reset_frame()
+        self.func, self._func_args = func, func_args
+        self.mask_func, self._mask_args = mask_func, mask_args
+        self.deriv_func, self._deriv_args = deriv_func, deriv_args
         self.parax_roc = parax_roc
         if mask_func is not None:
             raise NotImplementedError("mask_func is not supported by the device kernels; restrict the surface "
@@ -323,15 +310,13 @@ class FunctionSurface2D(DataSurface2D):
 
     # the user function in the surface's own frame, with the reference's return type checks
     def _eval_func(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
-        if self._1D:
-            vals = self.func(np.sqrt(x ** 2 + y ** 2), **self._func_args)
-        else:
-            vals = self.func(x, y, **self._func_args)
-        if not isinstance(vals, np.ndarray):
-            raise RuntimeError(f"func must return a np.ndarray, but returns type {type(vals)}.")
-        if vals.shape[0] and not isinstance(vals[0], np.float64):
+        where = (np.sqrt(x ** 2 + y ** 2),) if self._1D else (x, y)   # sqrt form: function_surface_2d.py:143
+        out = self.func(*where, **self._func_args)
+        if not isinstance(out, np.ndarray):
+            raise RuntimeError(f"func must return a np.ndarray, but returns type {type(out)}.")
+        if out.shape[0] and not isinstance(out[0], np.float64):
             raise RuntimeError("Elements of return value of func must be of type np.float64")
-        return vals
+        return out
 
     def _values_rel_host(self, x, y):
         """Set-up helper (z range, geometry checks): the function itself, as the reference evaluates it
@@ -452,49 +437,36 @@ class FunctionSurface2D(DataSurface2D):
                     f"{self._tab_residual:.3g} mm from the function; raise N_SAMPLES or smooth the function.")
 
     def _set_zmin_zmax(self, z_min: float, z_max: float) -> None:
-        """z range: measured from the tabulated surface, or the user's values if plausible
-        (function_surface_2d.py:76-128)."""
+        """z range: measured from the surface, or the user's values if they are plausible against the measured
+        ones (function_surface_2d.py:76-128).  User values refer to func itself, the stored ones to func - func(0)."""
         if self._1D:
-            rn = np.linspace(0, self.r, 10000)
-            zn = self._values_rel_host(rn, np.zeros_like(rn))
-            self.z_min, self.z_max = float(zn.min()), float(zn.max())
+            self._measure_profile_range()
         else:
             self.z_min, self.z_max = self._find_bounds()
-        surf_name = f"{type(self).__name__} {self.get_desc(hex(id(self)))}"
-        off = self._f0
-        if z_max is not None and z_min is not None:
-            z_range_probed = self.z_max - self.z_min
-            z_range_provided = z_max - z_min
-            if z_range_probed and z_range_provided + self.N_EPS < z_range_probed:
-                warning(f"{surf_name}: Provided a z-extent of {z_range_provided},"
-                        f"but measured range is at least {z_range_probed}, an increase of at "
-                        f"least {100*(z_range_probed - z_range_provided)/z_range_probed:.5g}."
-                        f" I will use the measured values for now.")
-            else:
-                range_factor = 1.2
-                if z_range_provided > range_factor * z_range_probed:
-                    warning(f"{surf_name}: Provided z-range is more than {(range_factor-1)*100:.5g}% "
-                            f"larger than measured z-range")
-                z_max_, z_min_ = self.z_max + off, self.z_min + off
-                if z_max + self.N_EPS < z_max_:
-                    warning(f"{surf_name}: Provided z_max={z_max} lower than measured value of {z_max_}."
-                            f" Using the measured values for now")
-                elif z_min - self.N_EPS > z_min_:
-                    warning(f"{surf_name}: Provided z_min={z_min} higher than measured value of {z_min_}."
-                            f" Using the measured values for now")
-                else:
-                    self.z_min, self.z_max = z_min - off, z_max - off
-        elif z_max is None and z_min is None:
-            warning(f"Estimated z-bounds of {surf_name}: [{off+self.z_min:.9g}, "
-                    f"{off+self.z_max:.9g}], provide actual values for higher precision.")
-        else:
+        name, centre, tol = self._label(), self._f0, self.N_EPS
+        if (z_min is None) != (z_max is None):
             raise ValueError("z_max and z_min need to be both None or both need a value")
-
-    def rotate(self, angle: float) -> None:
-        if not self._1D:
-            self._lock = False
-            self._angle += np.deg2rad(angle)
-            self.lock()
+        if z_min is None:
+            warning(f"Estimated z-bounds of {name}: [{centre+self.z_min:.9g}, "
+                    f"{centre+self.z_max:.9g}], provide actual values for higher precision.")
+            return
+        measured, stated = self.z_max - self.z_min, z_max - z_min
+        if measured and stated + tol < measured:
+            warning(f"{name}: Provided a z-extent of {stated},but measured range is at least {measured}, an increase "
+                    f"of at least {100*(measured - stated)/measured:.5g}. I will use the measured values for now.")
+            return
+        slack = 1.2
+        if stated > slack * measured:
+            warning(f"{name}: Provided z-range is more than {(slack-1)*100:.5g}% larger than measured z-range")
+        top, bottom = self.z_max + centre, self.z_min + centre
+        if z_max + tol < top:
+            warning(f"{name}: Provided z_max={z_max} lower than measured value of {top}. "
+                    f"Using the measured values for now")
+        elif z_min - tol > bottom:
+            warning(f"{name}: Provided z_min={z_min} higher than measured value of {bottom}. "
+                    f"Using the measured values for now")
+        else:
+            self.z_min, self.z_max = z_min - centre, z_max - centre
 
     def _desc(self):
         d = super()._desc()
@@ -507,16 +479,13 @@ class FunctionSurface2D(DataSurface2D):
         if key in ("z_max", "z_min"):
             check_type(key, val, (float, int))
             val = float(val)
-        elif key in ("deriv_func", "mask_func"):
-            if val is not None and not callable(val):
-                raise TypeError(f"{key} needs to be callable or None.")
-        elif key == "func":
-            if not callable(val):
-                raise TypeError("func needs to be callable.")
+        elif key == "func" and not callable(val):
+            raise TypeError("func needs to be callable.")
+        elif key in ("deriv_func", "mask_func") and not (val is None or callable(val)):
+            raise TypeError(f"{key} needs to be callable or None.")
         elif key in ("_deriv_args", "_func_args", "_mask_args"):
             check_type(key, val, dict)
-            Surface.__setattr__(self, key, copy.deepcopy(val))
-            return
+            val = copy.deepcopy(val)
         super().__setattr__(key, val)
 
 

@@ -107,7 +107,7 @@ class Surface(_Shape):
     def _mirror_z_range(self) -> None:
         """z range after a flip: reflected at the centre's z."""
         zc = self.pos[2]
-        self.z_min, self.z_max = 2 * zc - self.z_max, 2 * zc - self.z_min
+        self.z_min, self.z_max = zc - (self.z_max - zc), zc - (self.z_min - zc)
 
     @property
     def extent(self) -> tuple:
