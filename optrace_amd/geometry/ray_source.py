@@ -40,53 +40,30 @@ class RaySource(Element):
                  **kwargs) -> None:
         self._new_lock = False
 
-        if isinstance(surface, RGBImage):
-            surface_ = RectangularSurface(dim=surface.s)
-            self._image = surface
-            sRGBL = srgb_to_srgb_linear(self._image._data)
-            If = power_from_srgb_linear(sRGBL).flatten()
-            self._pIf = 1 / If.sum() * If
-        elif isinstance(surface, GrayscaleImage):
-            surface_ = RectangularSurface(dim=surface.s)
-            self._image = surface
-            If = srgb_to_srgb_linear(surface.data).ravel()
-            self._pIf = 1 / If.sum() * If
-        else:
-            surface_ = surface
-            self._image = None
-            self._pIf = None
+        # an image as the emitting area: a rectangle of its size, pixels chosen with probability ~ their power
+        self._image = surface if isinstance(surface, (RGBImage, GrayscaleImage)) else None
+        self._pIf = None
+        if self._image is not None:
+            linear = srgb_to_srgb_linear(surface._data if isinstance(surface, RGBImage) else surface.data)
+            weight = (power_from_srgb_linear(linear) if isinstance(surface, RGBImage) else linear).ravel()
+            self._pIf = 1 / weight.sum() * weight
+            surface = RectangularSurface(dim=surface.s)
+        Element.__init__(self, surface, [0, 0, 0] if pos is None else pos, **kwargs)
 
-        pos = pos if pos is not None else [0, 0, 0]
-        super().__init__(surface_, pos, **kwargs)
-
-        self.power = power
-        self.spectrum = spectrum if spectrum is not None else d65_spectrum
-
-        self.polarization = polarization
-        self.pol_angle = pol_angle
-        self.pol_func = pol_func
-        self.pol_angles = pol_angles
-        self.pol_probs = pol_probs
-        self.pol_args = pol_args
-
-        self.divergence = divergence
-        self.div_angle = div_angle
-        self.orientation = orientation
-        self.conv_pos = conv_pos if conv_pos is not None else [0, 0, 0]
-        self.or_func = or_func
-        self.or_args = or_args
-
-        if s_sph is None:
-            self.s = s if s is not None else [0, 0, 1]
-        else:
+        if s_sph is not None:
             check_type("s_sph", s_sph, (list, np.ndarray))
-            theta, phi = np.radians(s_sph[0]), np.radians(s_sph[1])
-            self.s = [np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)]
-
-        self.div_axis_angle = div_axis_angle
-        self.div_func = div_func
-        self.div_2d = div_2d
-        self.div_args = div_args
+            polar, azimuth = (np.radians(angle) for angle in s_sph[:2])
+            s = [np.sin(polar) * np.cos(azimuth), np.sin(polar) * np.sin(azimuth), np.cos(polar)]
+        settings = dict(
+            power=power, spectrum=d65_spectrum if spectrum is None else spectrum,
+            polarization=polarization, pol_angle=pol_angle, pol_func=pol_func, pol_angles=pol_angles,
+            pol_probs=pol_probs, pol_args=pol_args,
+            divergence=divergence, div_angle=div_angle, div_axis_angle=div_axis_angle, div_func=div_func,
+            div_2d=div_2d, div_args=div_args,
+            orientation=orientation, s=[0, 0, 1] if s is None else s,
+            conv_pos=[0, 0, 0] if conv_pos is None else conv_pos, or_func=or_func, or_args=or_args)
+        for name, value in settings.items():
+            setattr(self, name, value)
         self._new_lock = True
 
     # ---- device descriptor ----------------------------------------------------------------------

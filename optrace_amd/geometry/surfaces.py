@@ -38,6 +38,10 @@ def _pair(key: str, val: np.ndarray, what: str) -> None:
         raise ValueError(f"Dimensions {what} need to be positive, but are {val}")
 
 
+def _side_lengths(sides) -> np.ndarray:
+    return np.asarray_chkfinite(sides, dtype=np.float64)
+
+
 class _Shape(BaseClass):
     """What surfaces, points and lines share: a position and locked-by-default state."""
 
@@ -74,7 +78,7 @@ class Surface(_Shape):
 
     C_EPS: float = 1e-6   #: solution precision of numerical hit finding (surface.py:17)
     N_EPS: float = 1e-10  #: comparison epsilon (surface.py:20)
-    rotational_symmetry: bool = False
+    rotational_symmetry = False   #: True for surfaces that look the same after any rotate()
     _kind: int = _capi.SURF_CIRCLE
 
     def __init__(self, r: float, **kwargs) -> None:
@@ -134,7 +138,7 @@ class Surface(_Shape):
         assert self.is_flat()
 
     def rotate(self, angle: float) -> None:
-        assert self.rotational_symmetry
+        assert self.rotational_symmetry, "subclasses without rotational symmetry bring their own rotate()"
 
     @staticmethod
     def _rotate_rc(x, y, alpha):
@@ -274,7 +278,7 @@ class RectangularSurface(Surface):
     def __init__(self, dim, **kwargs) -> None:
         Surface.__init__(self, 1, **kwargs)
         self._angle = 0.0  # rotation about z in radians
-        self.dim = np.asarray_chkfinite(dim, dtype=np.float64)
+        self.dim = _side_lengths(dim)
         self._set_flat()
         self.lock()
 
@@ -335,7 +339,7 @@ class SlitSurface(RectangularSurface):
     def __init__(self, dim, dimi, **kwargs) -> None:
         RectangularSurface.__init__(self, dim, **kwargs)
         self._lock = self._new_lock = False
-        self.dimi = np.asarray_chkfinite(dimi, dtype=np.float64)
+        self.dimi = _side_lengths(dimi)
         self.lock()
 
     def _mask_host(self, x, y):

@@ -19,9 +19,10 @@ _WL_MIN0, _WL_MAX0 = 380., 780.
 def srgb_to_srgb_linear(rgb: np.ndarray) -> np.ndarray:
     """Remove the sRGB gamma (color/srgb.py:30-47)."""
     a = 0.055
-    below = np.abs(rgb) <= 0.04045
-    lin = np.sign(rgb) * (1 / (1 + a) * (np.abs(rgb) + a)) ** 2.4
-    lin[below] = 1 / 12.92 * rgb[below]
+    size = np.abs(rgb)
+    lin = np.sign(rgb) * (1 / (1 + a) * (size + a)) ** 2.4
+    toe = size <= 0.04045     # linear segment near black
+    lin[toe] = 1 / 12.92 * rgb[toe]
     return lin
 
 
@@ -67,23 +68,24 @@ class _BaseImage(BaseClass):
         if isinstance(data, str):
             data = self._load_image(data)
         self._data = data
-        if extent is None and s is None:
-            raise ValueError("Either s or extent need to be provided for Images")
-        if extent is None:
-            check_type("s", s, (list, tuple, np.ndarray))
-            s2 = np.asarray_chkfinite(s, dtype=np.float64)
-            if s2.shape[0] != 2:
-                raise ValueError("s needs to have 2 elements.")
-            check_above("s[0]", s2[0], 0)
-            check_above("s[1]", s2[1], 0)
-            self.extent = [-s2[0] / 2, s2[0] / 2, -s2[1] / 2, s2[1] / 2]
-        else:
-            self.extent = extent
-        self.quantity = quantity
-        self.projection = projection
-        self.limit = limit
-        super().__init__(**kwargs)
+        self.extent = extent if extent is not None else self._centred_extent(s)
+        self.quantity, self.projection, self.limit = quantity, projection, limit
+        BaseClass.__init__(self, **kwargs)
         self._new_lock = True
+
+    @staticmethod
+    def _centred_extent(s) -> list:
+        """Extent of an image with side lengths s = (sx, sy) around the origin."""
+        if s is None:
+            raise ValueError("Either s or extent need to be provided for Images")
+        check_type("s", s, (list, tuple, np.ndarray))
+        sides = np.asarray_chkfinite(s, dtype=np.float64)
+        if sides.shape[0] != 2:
+            raise ValueError("s needs to have 2 elements.")
+        for i, side in enumerate(sides):
+            check_above(f"s[{i}]", side, 0)
+        sx, sy = sides
+        return [-sx / 2, sx / 2, -sy / 2, sy / 2]
 
     def _load_image(self, path: str) -> np.ndarray:
         """Image file -> array in [0, 1], element [0, 0] in the lower left corner (base_image.py:67-83).
@@ -107,11 +109,13 @@ class _BaseImage(BaseClass):
 
     @property
     def s(self) -> list:
-        return [float(self.extent[1] - self.extent[0]), float(self.extent[3] - self.extent[2])]
+        x0, x1, y0, y1 = (float(v) for v in self.extent)
+        return [x1 - x0, y1 - y0]
 
     @property
     def Apx(self) -> float:
-        return float(self.s[0] * self.s[1] / (self.shape[1] * self.shape[0]))
+        (sx, sy), (rows, cols) = self.s, self.shape[:2]
+        return float(sx * sy / (cols * rows))
 
     def profile(self, x: float = None, y: float = None):
         """Cut through the image at one x or one y position (base_image.py:149-186): the pixel column / row that

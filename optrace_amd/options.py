@@ -20,37 +20,38 @@ class _GlobalOptions:
         self.show_warnings = True
         self.wavelength_range = [380., 780.]
 
+    _SWITCHES = ("multithreading", "show_progress_bar", "show_warnings")
+
     def __setattr__(self, key, val):
-        if key in ("multithreading", "show_progress_bar", "show_warnings"):
-            if not isinstance(val, bool):
+        if key in self._SWITCHES:
+            if type(val) is not bool:
                 raise TypeError(f"Property '{key}' needs to be of type bool, but is {type(val).__name__}.")
-        elif key == "wavelength_range":
+        elif key != "wavelength_range":
+            raise AttributeError(f"Invalid property {key}")
+        else:
             if not isinstance(val, (list, tuple)) or len(val) != 2:
                 raise TypeError("wavelength_range needs to be a two element list")
             val = [float(val[0]), float(val[1])]
             if val[0] > 380. or val[1] < 780.:
                 raise ValueError("wavelength_range needs to include at least [380, 780] nm")
-        else:
-            raise AttributeError(f"Invalid property {key}")
         object.__setattr__(self, key, val)
 
     @contextlib.contextmanager
-    def no_warnings(self):
-        state = self.show_warnings
-        self.show_warnings = False
+    def _switched_off(self, switch: str):
+        before = getattr(self, switch)
+        setattr(self, switch, False)
         try:
             yield
         finally:
-            self.show_warnings = state
+            setattr(self, switch, before)
 
-    @contextlib.contextmanager
+    def no_warnings(self):
+        """Context manager: no library warnings inside."""
+        return self._switched_off("show_warnings")
+
     def no_progress_bar(self):
-        state = self.show_progress_bar
-        self.show_progress_bar = False
-        try:
-            yield
-        finally:
-            self.show_progress_bar = state
+        """Context manager: no progress bar inside."""
+        return self._switched_off("show_progress_bar")
 
 
 global_options = _GlobalOptions()

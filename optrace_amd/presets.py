@@ -35,32 +35,31 @@ light_spectrum.FdC = LightSpectrum("Lines", lines=spectral_lines.FdC, line_vals=
 def arizona_eye(adaptation: float = 0., pupil: float = 5.7, r_det: float = 8, pos: list = None) -> Group:
     """Arizona eye model (Schwiegerling, Field Guide to Visual and Ophthalmic Optics, SPIE 2004), as in
     presets/geometry.py:54-108: cornea, pupil, lens with accommodation-dependent conics, spherical retina."""
-    pos0 = np.array(pos if pos is not None else [0, 0, 0])
-    geom = Group(long_desc="Arizona Eye Model", desc="Eye")
+    origin = np.zeros(3) if pos is None else np.array(pos, dtype=np.float64)
     A = adaptation
-    d_Aq = 2.97 - 0.04 * A
-    d_Lens = 3.767 + 0.04 * A
+    gap_aqueous, gap_lens, cornea_thickness = 2.97 - 0.04 * A, 3.767 + 0.04 * A, 0.55
 
-    n_Cornea = RefractionIndex("Abbe", n=1.377, V=57.1, desc="n_Cornea")
-    n_Aqueous = RefractionIndex("Abbe", n=1.337, V=61.3, desc="n_Aqueous")
-    n_Lens = RefractionIndex("Abbe", n=1.42 + 0.00256 * A - 0.00022 * A ** 2, V=51.9, desc="n_Lens")
-    n_Vitreous = RefractionIndex("Abbe", n=1.336, V=61.1, desc="n_Vitreous")
+    def at(z: float) -> np.ndarray:
+        return origin + [0, 0, z]
 
-    front = ConicSurface(r=5.45, R=7.8, k=-0.25, long_desc="Cornea Anterior")
-    back = ConicSurface(r=5.45, R=6.5, k=-0.25, long_desc="Cornea Posterior")
-    L0 = Lens(front, back, d1=0, d2=0.55, pos=pos0 + [0, 0, 0], n=n_Cornea, n2=n_Aqueous, desc="Cornea")
-    geom.add(L0)
+    # media: name -> (n at the centre line, Abbe number)
+    table = dict(Cornea=(1.377, 57.1), Aqueous=(1.337, 61.3), Vitreous=(1.336, 61.1),
+                 Lens=(1.42 + 0.00256 * A - 0.00022 * A ** 2, 51.9))
+    n = {name: RefractionIndex("Abbe", n=nc, V=V, desc=f"n_{name}") for name, (nc, V) in table.items()}
 
-    ap = RingSurface(r=5.45, ri=pupil / 2, desc="Pupil")
-    geom.add(Aperture(ap, pos=pos0 + [0, 0, L0.back.pos[2] + d_Aq - 1e-9], desc="Pupil"))
-
-    front = ConicSurface(r=5.1, R=12 - 0.4 * A, k=-7.518749 + 1.285720 * A, long_desc="Lens Anterior")
-    back = ConicSurface(r=5.1, R=-5.224557 + 0.2 * A, k=-1.353971 - 0.431762 * A, long_desc="Lens Posterior")
-    geom.add(Lens(front, back, d1=0, d2=d_Lens, pos=pos0 + [0, 0, d_Aq + 0.55], n=n_Lens, n2=n_Vitreous,
-                  desc="Lens"))
-
-    geom.add(Detector(SphericalSurface(r=r_det, R=-13.4, desc="Retina"), pos=pos0 + [0, 0, 24], desc="Retina"))
-    return geom
+    eye = Group(desc="Eye", long_desc="Arizona Eye Model")
+    cornea = Lens(ConicSurface(r=5.45, R=7.8, k=-0.25, long_desc="Cornea Anterior"),
+                  ConicSurface(r=5.45, R=6.5, k=-0.25, long_desc="Cornea Posterior"),
+                  d1=0, d2=cornea_thickness, pos=at(0), n=n["Cornea"], n2=n["Aqueous"], desc="Cornea")
+    eye.add(cornea)
+    eye.add(Aperture(RingSurface(r=5.45, ri=pupil / 2, desc="Pupil"),
+                     pos=at(cornea.back.pos[2] + gap_aqueous - 1e-9), desc="Pupil"))
+    eye.add(Lens(ConicSurface(r=5.1, R=12 - 0.4 * A, k=-7.518749 + 1.285720 * A, long_desc="Lens Anterior"),
+                 ConicSurface(r=5.1, R=-5.224557 + 0.2 * A, k=-1.353971 - 0.431762 * A, long_desc="Lens Posterior"),
+                 d1=0, d2=gap_lens, pos=at(gap_aqueous + cornea_thickness), n=n["Lens"], n2=n["Vitreous"],
+                 desc="Lens"))
+    eye.add(Detector(SphericalSurface(r=r_det, R=-13.4, desc="Retina"), pos=at(24), desc="Retina"))
+    return eye
 
 
 geometry = types.SimpleNamespace(arizona_eye=arizona_eye)

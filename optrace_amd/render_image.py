@@ -25,20 +25,18 @@ class RenderImage(BaseClass):
     EPS: float = 1e-9
     K: float = 683.0  # luminous efficacy [lm/W] (scipy.constants "luminous efficacy", render_image.py:35)
     SIZES = [1, 3, 5, 7, 9, 15, 21, 27, 35, 45, 63, 105, 135, 189, 315, 945]
-    MAX_IMAGE_SIDE: int = SIZES[-1]
-    MAX_IMAGE_RATIO: int = SIZES[2]
+    MAX_IMAGE_SIDE: int = max(SIZES)   # pixels of the smaller side of the stored histogram
+    MAX_IMAGE_RATIO: int = 5           # side ratio at most; a member of SIZES, so coarser views divide evenly
     image_modes = ["sRGB (Absolute RI)", "sRGB (Perceptual RI)", "Outside sRGB Gamut", "Irradiance",
                    "Illuminance", "Lightness (CIELUV)", "Hue (CIELUV)", "Chroma (CIELUV)", "Saturation (CIELUV)"]
 
     def __init__(self, extent, projection: str = None, **kwargs) -> None:
         self._new_lock = False
         self.extent = extent
-        self._extent0 = self.extent.copy()
-        self._host = None  # host copy of the image, made when `_data` is first read
-        self._dev = None
-        self._limit = None
-        self.projection = projection
-        super().__init__(**kwargs)
+        self._extent0 = np.array(self.extent)   # as given: `extent` itself is widened for degenerate images
+        self._host = self._dev = None  # host copy of the image (made when `_data` is first read), device histogram
+        self._limit, self.projection = None, projection
+        BaseClass.__init__(self, **kwargs)
         self._new_lock = True
 
     @property
@@ -58,7 +56,8 @@ class RenderImage(BaseClass):
 
     @property
     def s(self) -> list:
-        return [float(self.extent[1] - self.extent[0]), float(self.extent[3] - self.extent[2])]
+        x0, x1, y0, y1 = (float(v) for v in self.extent)
+        return [x1 - x0, y1 - y0]
 
     @property
     def shape(self) -> tuple:
@@ -73,19 +72,22 @@ class RenderImage(BaseClass):
     @property
     def Apx(self) -> float:
         self._check_for_image()
-        return self.s[0] * self.s[1] / (self.shape[1] * self.shape[0])
+        (sx, sy), (ny, nx) = self.s, self.shape[:2]
+        return sx * sy / (nx * ny)
 
     def power(self) -> float:
         self._check_for_image()
-        if self._host is None:  # no host copy yet: reduce on the device instead of moving 28-143 MB
-            return float(self._dev[:, :, 3].sum())
-        return float(np.sum(self._data[:, :, 3]))
+        return self._plane_sum(3)
 
     def luminous_power(self) -> float:
         self._check_for_image()
-        if self._host is None:
-            return float(self.K * self._dev[:, :, 1].sum())
-        return float(self.K * np.sum(self._data[:, :, 1]))
+        return self.K * self._plane_sum(1)
+
+    def _plane_sum(self, plane: int) -> float:
+        """Sum of one of the X, Y, Z, W planes; without a host copy it is reduced on the device instead of moving
+        28-143 MB."""
+        source = self._dev if self._host is None else self._host
+        return float(source[:, :, plane].sum())
 
     @property
     def limit(self) -> float:
@@ -95,9 +97,10 @@ class RenderImage(BaseClass):
         """Give point / line / extreme-ratio images a valid 2D extent (render_image.py:224-255)."""
         sx, sy = self.s
         MR = self.MAX_IMAGE_RATIO
-        self.extent = self._extent0.copy()
-        if sx < 2 * self.EPS and sy < 2 * self.EPS:
-            self.extent += self.EPS * np.array([-1, 1, -1, 1])
+        outwards = np.array([-1.0, 1.0, -1.0, 1.0])
+        self.extent = np.array(self._extent0)
+        if max(sx, sy) < 2 * self.EPS:
+            self.extent += self.EPS * outwards
         elif not sx or sy / sx > MR:
             xm = (self._extent0[0] + self._extent0[1]) / 2
             self.extent[0] = xm - sy / MR / 2
@@ -106,8 +109,8 @@ class RenderImage(BaseClass):
             ym = (self._extent0[2] + self._extent0[3]) / 2
             self.extent[2] = ym - sx / MR / 2
             self.extent[3] = ym + sx / MR / 2
-        if self._limit is not None:
-            self.extent += np.array([-1.0, 1.0, -1.0, 1.0]) * 2.7 * self._limit / 1000.0
+        if self._limit:
+            self.extent += outwards * 2.7 * self._limit / 1000.0
 
     def _pixel_counts(self) -> tuple[int, int]:
         """Nx, Ny: the smaller side has 945 px, the ratio snaps to 1, 3 or 5 (render_image.py:383-387)."""
@@ -154,7 +157,7 @@ class RenderImage(BaseClass):
                                                  ptr(hist), stream_ptr()))
         self._dev = hist.view(Ny, Nx, 4)
         self._host = None
-        if not _dont_filter and self._limit is not None:
+        if self._limit is not None and not _dont_filter:
             self._apply_rayleigh_filter()
 
     _MODES = {"Irradiance": 0, "Illuminance": 1, "sRGB (Absolute RI)": 2, "sRGB (Perceptual RI)": 3,
@@ -202,11 +205,10 @@ class RenderImage(BaseClass):
     def save(self, path: str) -> None:
         """Save as .npz archive (keys _data, extent, limit, desc, long_desc, proj); existing files are replaced."""
         self._check_for_image()
-        limit = self._limit if self._limit is not None else np.nan
-        sdict = dict(_data=self._data, extent=self.extent, limit=limit,
-                     desc=self.desc, long_desc=self.long_desc, proj=str(self.projection))
-        path_ = path if path[-4:] == ".npz" else path + ".npz"
-        np.savez_compressed(path_, **sdict)
+        if not path.endswith(".npz"):
+            path += ".npz"
+        np.savez_compressed(path, _data=self._data, extent=self.extent, desc=self.desc, long_desc=self.long_desc,
+                            limit=np.nan if self._limit is None else self._limit, proj=str(self.projection))
 
     @staticmethod
     def load(path: str) -> "RenderImage":
@@ -214,7 +216,8 @@ class RenderImage(BaseClass):
         io = np.load(path)
         im = RenderImage(io["extent"], long_desc=str(io["long_desc"][()]), desc=str(io["desc"][()]),
                          projection=str(io["proj"][()]))
-        im._limit = io["limit"][()] if not np.isnan(io["limit"]) else None
+        stored_limit = float(io["limit"][()])
+        im._limit = None if np.isnan(stored_limit) else stored_limit
         im.projection = None if im.projection == "None" else im.projection  # None is stored as a string
         im._data = np.ascontiguousarray(io["_data"], dtype=np.float64)  # uploaded on first use (get / filter)
         return im
@@ -223,7 +226,7 @@ class RenderImage(BaseClass):
         """Resolution-limit filter: convolve every channel with an Airy disc whose first zero lies at `limit`
         micrometres (render_image.py:257-296); the convolution runs on the GPU (`ot_image_convolve`)."""
         import scipy.special
-        if self._limit is not None and self.projection is not None:
+        if None not in (self._limit, self.projection):
             raise RuntimeError("Resolution limit filter is not applicable for a projected image.")
         px = self._limit / 1000.0 / (self.s[0] / self.shape[1])
         py = self._limit / 1000.0 / (self.s[1] / self.shape[0])
