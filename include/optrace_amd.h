@@ -99,6 +99,16 @@ typedef struct ot_surface {
  * rotates the resulting gradient (function_surface_2d.py:229-244); without deriv_func normals come from central
  * differences of the (rotated) surface.  The flag selects the first behaviour so results match the reference. */
 #define OT_SURF_FLAG_DERIV_UNROTATED 1
+/* FunctionSurface mask_func (function_surface_2d.py:158-191): a Python callable cannot run per ray, so the mask travels
+ * as a bitmap sampled at cell centres in the function's own frame (before rotate() and flip(), like the spline).
+ * With this flag `tab` continues behind the spline tables with
+ *     n (as a double) | ceil(cells / 64) doubles whose bytes are little-endian uint32 words, bit (i & 31) of word i >> 5
+ * DATA1D: cells = n over the radius [0, r], cell i covers [i, i + 1) * r / n;
+ * DATA2D: cells = n * n over [-r, r]^2, index iy * n + ix, cell (ix, iy) covers [-r + ix h, -r + (ix + 1) h) with
+ *         h = 2 r / n in x and likewise in y.
+ * A position is on the surface if it is inside r (+ N_EPS) and its cell's bit is set; positions closer to the mask's
+ * edge than one cell can therefore differ from the callable.  tab_len counts these doubles too. */
+#define OT_SURF_FLAG_MASK_TABLE 2
 #define OT_SPL_K 4
 
 /* ---- media: RefractionIndex.__call__ refraction_index.py:62-169 ----------------------------- */

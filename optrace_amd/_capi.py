@@ -20,6 +20,7 @@ OT_MAX_LINES = 8
 SURF_CIRCLE, SURF_RING, SURF_RECT, SURF_SLIT, SURF_CONIC, SURF_ASPHERE, SURF_TILTED, SURF_DATA1D, SURF_DATA2D = range(9)
 SPL_K = 4  # OT_SPL_K
 SURF_FLAG_DERIV_UNROTATED = 1
+SURF_FLAG_MASK_TABLE = 2
 (N_CONSTANT, N_ABBE, N_CAUCHY, N_CONRADY, N_SELLMEIER1, N_SELLMEIER2, N_SELLMEIER3, N_SELLMEIER4,
  N_SELLMEIER5, N_SCHOTT, N_HERZBERGER, N_HOO1, N_HOO2, N_EXTENDED, N_EXTENDED2, N_EXTENDED3,
  N_DATA, N_LINES) = range(18)

@@ -60,11 +60,29 @@ static int require_device() {
 // ---------------------------------------------------------------------------------------------------------
 static double conic_sag(double rho, double k1rho2, double r2) { return rho * r2 / (1 + std::sqrt(1 - k1rho2 * r2)); }
 
-static int64_t surface_table_len(const ot_surface& s) {
+static int64_t spline_table_len(const ot_surface& s) {
     const int64_t n = s.nknots, nc = n - OT_SPL_K - 1;
     if (s.kind == OT_SURF_DATA1D) return 3 * n;
     if (s.kind == OT_SURF_DATA2D) return n + nc * nc + 2 * (nc - 1) * nc;
     return 0;
+}
+
+// cells per dimension of the mask bitmap behind the spline tables (OT_SURF_FLAG_MASK_TABLE), 0 without one, -1 if
+// the count stored there is not a whole number in 1 .. 2^15 (2D) or 1 .. 2^20 (1D)
+static int64_t mask_table_cells(const ot_surface& s) {
+    if (!(s.flags & OT_SURF_FLAG_MASK_TABLE)) return 0;
+    const int64_t at = spline_table_len(s);
+    if (!s.tab || s.tab_len <= at) return -1;
+    const double n = s.tab[at];
+    if (!(n >= 1.0 && n <= (s.kind == OT_SURF_DATA1D ? 1048576.0 : 32768.0)) || n != std::floor(n)) return -1;
+    return (int64_t)n;
+}
+
+static int64_t surface_table_len(const ot_surface& s) {
+    int64_t len = spline_table_len(s);
+    const int64_t n = mask_table_cells(s);
+    if (n > 0) len += 1 + ((s.kind == OT_SURF_DATA1D ? n : n * n) + 63) / 64;
+    return len;
 }
 
 static int compile_surface(const ot_surface& s, SurfDev& d) {
@@ -174,6 +192,7 @@ static int compile_surface(const ot_surface& s, SurfDev& d) {
         case OT_SURF_DATA2D: {
             const int n = s.nknots, nc = n - OT_SPL_K - 1;
             if (!s.tab || nc < OT_SPL_K + 1) return fail(OT_ERR_INVALID, "data surface: spline tables missing or too short");
+            if (mask_table_cells(s) < 0) return fail(OT_ERR_INVALID, "data surface: mask table header missing or out of range");
             if (s.tab_len != surface_table_len(s)) return fail(OT_ERR_INVALID, "data surface: tab_len does not match nknots");
             if (!(s.sign == 1.0 || s.sign == -1.0)) return fail(OT_ERR_INVALID, "data surface: sign must be +1 or -1");
             d.r_eps2 = std::pow(s.r + NE, 2.0);
@@ -181,9 +200,32 @@ static int compile_surface(const ot_surface& s, SurfDev& d) {
             d.offs = s.offset;
             d.nk = n;
             d.deriv_unrot = (s.flags & OT_SURF_FLAG_DERIV_UNROTATED) ? 1 : 0;
+            d.mask_n = (int32_t)mask_table_cells(s);
+            if (d.mask_n) {
+                d.mask_off = spline_table_len(s) + 1;
+                d.mask_r = s.r;
+                d.mask_scale = (s.kind == OT_SURF_DATA1D ? (double)d.mask_n : 0.5 * (double)d.mask_n) / s.r;
+            }
             const double span = s.tab[nc] - s.tab[OT_SPL_K];  // t(nk1 + 1) - t(k1)
             if (!(span > 0.0)) return fail(OT_ERR_INVALID, "data surface: knots must increase");
             d.inv_h = (double)(nc - OT_SPL_K - 1 > 0 ? nc - OT_SPL_K - 1 : 1) / span;
+            {   // equidistant part of the knots: indices K + 1 .. n - K - 2 (ot_spline.hpp::bspl_basis)
+                const int ulo = OT_SPL_K + 1, uhi = n - OT_SPL_K - 2;
+                d.ku_lo = s.tab[OT_SPL_K];  // t(k1), t(nk1 + 1): the range arguments are clamped to
+                d.ku_hi = s.tab[nc];
+                d.ku_t0 = d.ku_h = d.ku_inv_h = 0.0;  // ku_h == 0: no equidistant part (table path everywhere)
+                if (uhi - ulo >= 2 * OT_SPL_K) {
+                    const double h = (s.tab[uhi] - s.tab[ulo]) / (double)(uhi - ulo);
+                    bool uniform = h > 0.0;
+                    for (int i = ulo; i <= uhi && uniform; i++)
+                        uniform = std::fabs(s.tab[i] - (s.tab[ulo] + (i - ulo) * h)) <= 1e-9 * h;
+                    if (uniform) {
+                        d.ku_t0 = s.tab[ulo];
+                        d.ku_h = h;
+                        d.ku_inv_h = 1.0 / h;
+                    }
+                }
+            }
             if (s.kind == OT_SURF_DATA2D) {
                 d.rot = (s.angle != 0.0);
                 d.cna = std::cos(-s.angle);

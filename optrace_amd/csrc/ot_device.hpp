@@ -98,15 +98,20 @@ OT_HD double data_values_rel(SF& sf, double x, double y, PatchCache* pc = nullpt
     const double* t = sf.tab;
     const int n = sf.nk;
     double v;
+    // (ku_h == 0: no equidistant part -- an empty index range, so every point takes the table path; the pointer itself
+    // stays a compile-time constant, which keeps the struct in registers)
+    const UniformKnots ukv = {sf.ku_t0, sf.ku_h, sf.ku_inv_h, sf.ku_lo, sf.ku_hi,
+                              (sf.ku_h > 0.0) ? OT_SPL_K + 1 : (1 << 30), n - OT_SPL_K - 2};
+    const UniformKnots* const uk = &ukv;
     if (sf.kind == OT_SURF_DATA1D) {
-        v = spl1_eval<OT_SPL_K>(t, n, t + n, sf.inv_h, hypot(x, y));
+        v = spl1_eval<OT_SPL_K>(t, n, t + n, sf.inv_h, hypot(x, y), uk, pc);
     } else {
         double xr = x, yr = y;
         if (sf.rot) {  // _rotate_rc(x, y, -angle)
             xr = x * sf.cna - y * sf.sna;
             yr = x * sf.sna + y * sf.cna;
         }
-        v = spl2_eval<OT_SPL_K, OT_SPL_K>(t, n, t, n, t + n, sf.inv_h, xr, sf.sgn * yr, pc);
+        v = spl2_eval<OT_SPL_K, OT_SPL_K>(t, n, t, n, t + n, sf.inv_h, xr, sf.sgn * yr, pc, uk);
     }
     return sf.sgn * (v - sf.offs);
 }
@@ -116,9 +121,16 @@ template <class SF>
 OT_HD void data_gradient(SF& sf, double x, double y, double& gx, double& gy, PatchCache* pc = nullptr) {
     const double* t = sf.tab;
     const int n = sf.nk;
+    // (ku_h == 0: no equidistant part -- an empty index range, so every point takes the table path; the pointer itself
+    // stays a compile-time constant, which keeps the struct in registers)
+    const UniformKnots ukv = {sf.ku_t0, sf.ku_h, sf.ku_inv_h, sf.ku_lo, sf.ku_hi,
+                              (sf.ku_h > 0.0) ? OT_SPL_K + 1 : (1 << 30), n - OT_SPL_K - 2};
+    const UniformKnots* const uk = &ukv;
     if (sf.kind == OT_SURF_DATA1D) {
         const double r = hypot(x, y);
-        const double nr = sf.sgn * spl1_eval<OT_SPL_K - 1>(t, n, t + 2 * n, sf.inv_h, r);
+        double d1;
+        if (!spl1_grad_cached(t + n, r, uk, pc, d1)) d1 = spl1_eval<OT_SPL_K - 1>(t, n, t + 2 * n, sf.inv_h, r, uk);
+        const double nr = sf.sgn * d1;
         const double rr = sqrt(x * x + y * y);
         gx = nr * ((rr > 0.0) ? x / rr : 1.0);  // cos(arctan2(y, x))
         gy = nr * ((rr > 0.0) ? y / rr : 0.0);
@@ -132,7 +144,7 @@ OT_HD void data_gradient(SF& sf, double x, double y, double& gx, double& gy, Pat
     const int nc = (n - OT_SPL_K - 1), ncx = (n - OT_SPL_K - 2) * nc;
     const double* c = t + n;
     double nxn, nyn;
-    if (spl2_grad_cached(t, n, c, sf.inv_h, xr, sf.sgn * yr, pc, nxn, nyn)) {  // from the patch of the hit search
+    if (spl2_grad_cached(t, n, c, sf.inv_h, xr, sf.sgn * yr, pc, nxn, nyn, uk)) {  // from the patch of the hit search
         nxn = nxn * sf.sgn;
     } else {
         nxn = spl2_eval<OT_SPL_K - 1, OT_SPL_K>(t + 1, n - 2, t, n, c + nc * nc, sf.inv_h, xr, sf.sgn * yr) * sf.sgn;
@@ -147,8 +159,34 @@ OT_HD void data_gradient(SF& sf, double x, double y, double& gx, double& gy, Pat
     }
 }
 
-// ---- masks: surface.py:235, ring_surface.py:123, rectangular_surface.py:100, slit_surface.py:89 ----------
+// mask_func of a function surface as a bitmap (layout: include/optrace_amd.h, OT_SURF_FLAG_MASK_TABLE): the cell of
+// (dx, dy) relative to the centre, taken back into the function's frame like the values (function_surface_2d.py:170-181)
 template <class SF>
+OT_HD bool mask_table(SF& sf, double dx, double dy) {
+    const uint32_t* words = (const uint32_t*)(sf.tab + sf.mask_off);
+    const int n = sf.mask_n;
+    int64_t cell;
+    if (sf.kind == OT_SURF_DATA1D) {
+        const int i = (int)(sqrt(dx * dx + dy * dy) * sf.mask_scale);
+        cell = i < n ? i : n - 1;
+    } else {
+        double xr = dx, yr = dy;
+        if (sf.rot) {
+            xr = dx * sf.cna - dy * sf.sna;
+            yr = dx * sf.sna + dy * sf.cna;
+        }
+        yr = sf.sgn * yr;
+        int ix = (int)floor((xr + sf.mask_r) * sf.mask_scale), iy = (int)floor((yr + sf.mask_r) * sf.mask_scale);
+        ix = ix < 0 ? 0 : (ix < n ? ix : n - 1);
+        iy = iy < 0 ? 0 : (iy < n ? iy : n - 1);
+        cell = (int64_t)iy * n + ix;
+    }
+    return (words[cell >> 5] >> (uint32_t)(cell & 31)) & 1u;
+}
+
+// ---- masks: surface.py:235, ring_surface.py:123, rectangular_surface.py:100, slit_surface.py:89 ----------
+// TABLES = false: call sites that cannot meet a spline surface (conic hit, kernels without numeric surfaces)
+template <bool TABLES = true, class SF>
 OT_DEV bool surf_mask(SF& sf, double x, double y) {
     if (sf.kind == OT_SURF_RECT || sf.kind == OT_SURF_SLIT) {
         double dx = x - sf.px, dy = y - sf.py;
@@ -166,6 +204,9 @@ OT_DEV bool surf_mask(SF& sf, double x, double y) {
     double r2 = dx * dx + dy * dy;
     bool in = r2 <= sf.r_eps2;
     if (sf.kind == OT_SURF_RING) in = in && (sf.ri_eps2 <= r2);
+    if (TABLES && (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) && sf.mask_n) {
+        if (in) in = mask_table(sf, dx, dy);
+    }
     return in;
 }
 
@@ -319,11 +360,11 @@ OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) 
     bool c2 = (sf.z_lo <= z2) && (z2 <= sf.z_hi) && (z2 >= z) && (t2 < t1);
     double t = (c1 && !c2) ? t1 : t2;
     ph = along(p, s, t);
-    hit = surf_mask(sf, ph.x, ph.y);
+    hit = surf_mask<false>(sf, ph.x, ph.y);
     if (!sphere && A == 0 && B != 0) {
         t = -C / (2 * B);
         ph = along(p, s, t);
-        hit = surf_mask(sf, ph.x, ph.y);
+        hit = surf_mask<false>(sf, ph.x, ph.y);
     }
     bool nh = !hit || !isfinite(D) || (!sphere && A == 0 && B == 0) || (ph.z < sf.z_lo) || (ph.z > sf.z_hi);
     if (nh) {
@@ -352,7 +393,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
     if (sf.flat) {
         double t = ot_div(sf.pz - p.z, s.z);
         ph = along(p, s, t);
-        hit = surf_mask(sf, ph.x, ph.y);
+        hit = surf_mask<NUMERIC>(sf, ph.x, ph.y);
         handle_abnormal(sf, p, s, ph, hit);
         return true;
     }

@@ -43,8 +43,15 @@ struct SurfDev {
     // spline surfaces (DATA1D / DATA2D): sign, centre offset, knots per unit length (interval guess),
     // device pointer to the tables laid out as include/optrace_amd.h describes, knots per dimension
     double sgn, offs, inv_h;
+    // the equidistant part of the knots (ot_spline.hpp::UniformKnots): first such knot, spacing and its inverse, clamp range
+    double ku_t0, ku_h, ku_inv_h, ku_lo, ku_hi;
     const double* tab;
     int32_t nk, deriv_unrot;
+    // mask bitmap of a function surface (OT_SURF_FLAG_MASK_TABLE): offset of the words in `tab` (in doubles), cells per
+    // dimension (0 = no bitmap), radius and cells per unit length
+    int64_t mask_off;
+    int32_t mask_n, mask_pad;
+    double mask_r, mask_scale;
 };
 
 // One step per tracing surface, in ray order (the element list of raytracer.py:492-508 flattened).

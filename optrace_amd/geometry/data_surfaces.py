@@ -191,6 +191,8 @@ class DataSurface2D(Surface):
     def _measure_profile_range(self) -> None:
         radii = np.linspace(0., self.r, 10000)
         sag = self._values_rel_host(radii, np.zeros(radii.shape))
+        if getattr(self, "mask_func", None) is not None:   # function_surface_2d.py:86-90: where the mask holds
+            sag = sag[self._mask_host(radii + self.pos[0], self.pos[1] + np.zeros(radii.shape))]
         self.z_min, self.z_max = float(sag.min()), float(sag.max())
 
     def _fit_grid(self, Z: np.ndarray) -> float:
@@ -264,6 +266,16 @@ class DataSurface1D(DataSurface2D):
     _kind = _capi.SURF_DATA1D
 
 
+def _nearest_finite(Z: np.ndarray) -> np.ndarray:
+    """Samples that are not finite (func undefined outside its mask) replaced by the nearest finite one."""
+    bad = ~np.isfinite(Z)
+    if not bad.any():
+        return Z
+    import scipy.ndimage
+    nearest = scipy.ndimage.distance_transform_edt(bad, return_distances=False, return_indices=True)
+    return Z[tuple(nearest)]
+
+
 # ---- function surfaces -------------------------------------------------------------------------------------------
 class FunctionSurface2D(DataSurface2D):
     """Surface defined by a Python callable z = func(x, y) (function_surface_2d.py:12-309), carried on the
@@ -275,7 +287,11 @@ class FunctionSurface2D(DataSurface2D):
     * `deriv_func` is used only for that check -- normals are the spline's analytic derivative;
     * samples outside the disc (the square's corners) are filled by a quadratic radial continuation from the
       edge, so `func` is never evaluated outside r;
-    * `mask_func` is not supported on the device.
+    * `mask_func` travels as a bitmap of `N_MASK` x `N_MASK` cells over the square around the disc (`N_MASK_1D`
+      cells along the radius for the 1-D class), sampled at the cell centres at construction: a position closer to the
+      mask's edge than one cell (2 r / N_MASK) can be classified differently from the callable.  Mask edges that fall on
+      cell borders are exact.  `func` is still sampled on the whole disc; where it is not finite outside the mask the
+      nearest finite sample stands in.
     """
 
     N_SAMPLES: tuple = (17, 33, 65, 129, 257, 401, 801, 1601)
@@ -284,6 +300,8 @@ class FunctionSurface2D(DataSurface2D):
     N_SAMPLES_1D: tuple = (17, 33, 65, 129, 257, 513, 1025, 2049, 4001)
     """samples of the radial profile (1D), tried in turn like N_SAMPLES: a finer grid than the function needs only
     amplifies the rounding noise of func in the slopes (noise / spacing)"""
+    N_MASK: int = 4096       #: cells per dimension of the mask bitmap (2D): 2 MiB, resolution 2 r / 4096
+    N_MASK_1D: int = 65536   #: cells of the radial mask bitmap (1D)
     TAB_TOL: float = 1e-9  #: accepted spline residual relative to r
     GRAD_TOL: float = 2e-9  #: accepted residual of the spline gradient (2D; against central differences of func)
 
@@ -300,11 +318,10 @@ class FunctionSurface2D(DataSurface2D):
         self.mask_func, self._mask_args = mask_func, mask_args
         self.deriv_func, self._deriv_args = deriv_func, deriv_args
         self.parax_roc = parax_roc
-        if mask_func is not None:
-            raise NotImplementedError("mask_func is not supported by the device kernels; restrict the surface "
-                                      "with r or an aperture instead.")
         self._f0 = self._eval_func(np.array([0.]), np.array([0.]))[0]  # the reference's _offset (centre value)
         self._tabulate()
+        if mask_func is not None:
+            self._tab = np.concatenate((self._tab, self._tabulate_mask()))   # behind the spline tables
         self._set_zmin_zmax(z_min, z_max)
         self.lock()
 
@@ -317,6 +334,48 @@ class FunctionSurface2D(DataSurface2D):
         if out.shape[0] and not isinstance(out[0], np.float64):
             raise RuntimeError("Elements of return value of func must be of type np.float64")
         return out
+
+    def _eval_mask(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        """mask_func in the surface's own frame, with the reference's return type checks
+        (function_surface_2d.py:175-187)."""
+        where = (np.sqrt(x ** 2 + y ** 2),) if self._1D else (x, y)
+        out = self.mask_func(*where, **self._mask_args)
+        if not isinstance(out, np.ndarray):
+            raise RuntimeError(f"mask_func must return a np.ndarray, but returns type {type(out)}.")
+        if out.shape[0] and not isinstance(out[0], (bool, np.bool_)):
+            raise RuntimeError("Elements of return value of mask_func must be of type bool")
+        return out
+
+    def _mask_host(self, x, y):
+        """Set-up helper: inside r and, with a mask_func, inside that too (function_surface_2d.py:158-191)."""
+        inside = Surface._mask_host(self, x, y)
+        if self.mask_func is None:
+            return inside
+        dx, dy = np.asarray(x, dtype=np.float64) - self.pos[0], np.asarray(y, dtype=np.float64) - self.pos[1]
+        if not self._1D:
+            dx, dy = self._rotate_rc(dx, dy, -self._angle)
+            dy = self._sign * dy
+        return inside & self._eval_mask(dx, dy)
+
+    def _tabulate_mask(self) -> np.ndarray:
+        """The mask bitmap for the device (layout: include/optrace_amd.h, OT_SURF_FLAG_MASK_TABLE): mask_func at the
+        cell centres, in the function's own frame; -> cell count followed by the packed bits, as float64 words."""
+        R = self.r
+        if self._1D:
+            n = int(self.N_MASK_1D)
+            centres = (np.arange(n) + 0.5) * (R / n)
+            bits = np.asarray(self._eval_mask(centres, np.zeros(n)), dtype=bool)
+        else:
+            n = int(self.N_MASK)
+            centres = -R + (np.arange(n) + 0.5) * (2 * R / n)
+            bits = np.empty((n, n), dtype=bool)   # [iy, ix]
+            rows = max(1, (1 << 20) // n)         # about a million points per call of mask_func
+            for y0 in range(0, n, rows):
+                X, Y = np.meshgrid(centres, centres[y0:y0 + rows])
+                bits[y0:y0 + rows] = np.asarray(self._eval_mask(X.ravel(), Y.ravel()), dtype=bool).reshape(X.shape)
+        packed = np.packbits(bits.ravel(), bitorder="little")
+        packed = np.concatenate((packed, np.zeros(-packed.size % 8, dtype=np.uint8)))
+        return np.concatenate(([float(n)], packed.view(np.float64)))
 
     def _values_rel_host(self, x, y):
         """Set-up helper (z range, geometry checks): the function itself, as the reference evaluates it
@@ -337,13 +396,12 @@ class FunctionSurface2D(DataSurface2D):
             best = None
             for n in self.N_SAMPLES_1D:
                 r0 = np.linspace(0, R, n)
-                Z = self._eval_func(r0, np.zeros_like(r0)) - self._f0
-                r2 = np.concatenate((-np.flip(r0[1:]), r0))
-                z2 = np.concatenate((np.flip(Z[1:]), Z))
-                self._interp = scipy.interpolate.InterpolatedUnivariateSpline(r2, z2, k=_K)
+                Z = self._sample(r0, np.zeros_like(r0))
+                self._interp = scipy.interpolate.InterpolatedUnivariateSpline(*_mirrored(r0, _nearest_finite(Z)), k=_K)
                 # residuals at the interval midpoints and at points anywhere on the profile: values, and slopes against
                 # central differences of func
                 rm = np.concatenate(((r0[1:] + r0[:-1]) / 2, R * np.random.default_rng(n).random(512)))
+                rm = rm[self._checked(rm, np.zeros_like(rm))]
                 res = np.abs(self._interp(rm) - (self._eval_func(rm, np.zeros_like(rm)) - self._f0))
                 gres = 0.
                 rg = rm[(rm > eps) & (rm < R - eps)]
@@ -351,7 +409,7 @@ class FunctionSurface2D(DataSurface2D):
                     zero = np.zeros_like(rg)
                     fd = (self._eval_func(rg + eps, zero) - self._eval_func(rg - eps, zero)) / (2 * eps)
                     gres = float(np.max(np.abs(self._interp.derivative()(rg) - fd)))
-                ok = res.max() <= self.TAB_TOL * R
+                ok = res.max(initial=0.) <= self.TAB_TOL * R
                 if best is None or (ok, -gres) > (best[0], -best[1]):
                     best = (ok, gres, self._interp, res)
                 if ok and gres <= self.GRAD_TOL:
@@ -385,7 +443,7 @@ class FunctionSurface2D(DataSurface2D):
         rr = np.hypot(X, Y)
         inside = rr <= R
         Z = np.zeros_like(X)
-        Z[inside] = self._eval_func(X[inside], Y[inside]) - self._f0
+        Z[inside] = self._sample(X[inside], Y[inside])
         # corners of the square (never touched by the reference): the function itself where it is defined there,
         # otherwise a quadratic radial continuation from three points at the edge
         out = ~inside
@@ -405,7 +463,7 @@ class FunctionSurface2D(DataSurface2D):
                 d1 = (3 * f0 - 4 * f1 + f2) / (2 * h)
                 d2 = (f0 - 2 * f1 + f2) / h ** 2
                 Z[bad] = f0 + d1 * d + d2 / 2 * d ** 2
-        self._interp = scipy.interpolate.RectBivariateSpline(xy, xy, Z, kx=_K, ky=_K)
+        self._interp = scipy.interpolate.RectBivariateSpline(xy, xy, _nearest_finite(Z), kx=_K, ky=_K)
         self._tab, self._nknots = _table_2d(self._interp)
         xm = (xy[1:] + xy[:-1]) / 2
         Xm, Ym = np.meshgrid(xm, xm, indexing="ij")
@@ -416,6 +474,8 @@ class FunctionSurface2D(DataSurface2D):
         rng = np.random.default_rng(n)
         pr, pa = R * np.sqrt(rng.random(2048)), 2 * np.pi * rng.random(2048)
         xs, ys = np.concatenate((xs, pr * np.cos(pa))), np.concatenate((ys, pr * np.sin(pa)))
+        keep = self._checked(xs, ys)
+        xs, ys = xs[keep], ys[keep]
         res = np.abs(self._interp(xs, ys, grid=False) - (self._eval_func(xs, ys) - self._f0))
         eps = (3 * np.finfo(np.float64).eps * 50) ** (1 / 3)
         keep = np.hypot(xs, ys) <= R - max(2 * R / (n - 1), 2 * eps)
@@ -427,6 +487,17 @@ class FunctionSurface2D(DataSurface2D):
         gres = max(np.abs(self._interp(xs, ys, dx=1, grid=False) - gx).max(initial=0.),
                    np.abs(self._interp(xs, ys, dy=1, grid=False) - gy).max(initial=0.))
         return res, float(gres)
+
+    def _sample(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        """func - func(0, 0) for the tabulation; outside a mask_func the function may be undefined (not finite)."""
+        with np.errstate(all="ignore"):
+            return self._eval_func(x, y) - self._f0
+
+    def _checked(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        """Which of the points (own frame) count for the residuals of the tabulation: those the mask_func keeps."""
+        if self.mask_func is None:
+            return np.ones(x.shape, dtype=bool)
+        return np.asarray(self._eval_mask(x, y), dtype=bool)
 
     def _finish_tabulation(self, res: np.ndarray) -> None:
         R = self.r
@@ -473,6 +544,8 @@ class FunctionSurface2D(DataSurface2D):
         if self.deriv_func is not None and not self._1D:
             # the reference calls deriv_func at the unrotated coordinates (function_surface_2d.py:235)
             d.flags |= _capi.SURF_FLAG_DERIV_UNROTATED
+        if self.mask_func is not None:
+            d.flags |= _capi.SURF_FLAG_MASK_TABLE
         return d
 
     def __setattr__(self, key: str, val: Any) -> None:

@@ -69,6 +69,30 @@ static inline void rotate_rc(double x, double y, double alpha, double* xr, doubl
 
 static inline int surf_is_flat(const ot_surface* sf) { return sf->z_max == sf->z_min; } /* surface.py:47 */
 
+/* FunctionSurface2D.mask function_surface_2d.py:158-191 with the callable restated as the bitmap the framework carries
+ * (include/optrace_amd.h, OT_SURF_FLAG_MASK_TABLE): relative coordinates, rotated back by the surface's angle and
+ * mirrored by its sign (2D), the radius (1D); the bit of the cell that holds the position. */
+static int mask_func_cell(const ot_surface* sf, double dx, double dy) {
+    int64_t n_t = sf->nknots, nc = n_t - OT_SPL_K - 1;
+    int64_t at = (sf->kind == OT_SURF_DATA1D) ? 3 * n_t : n_t + nc * nc + 2 * (nc - 1) * nc;
+    int64_t n = (int64_t)sf->tab[at], cell;
+    const uint32_t* words = (const uint32_t*)(sf->tab + at + 1);
+    if (sf->kind == OT_SURF_DATA1D) {
+        int64_t i = (int64_t)(sqrt(dx * dx + dy * dy) * ((double)n / sf->r));
+        cell = i < n ? i : n - 1;
+    } else {
+        double xr, yr;
+        rotate_rc(dx, dy, -sf->angle, &xr, &yr);
+        yr = sf->sign * yr;
+        double scale = 0.5 * (double)n / sf->r;
+        int64_t ix = (int64_t)floor((xr + sf->r) * scale), iy = (int64_t)floor((yr + sf->r) * scale);
+        ix = ix < 0 ? 0 : (ix < n ? ix : n - 1);
+        iy = iy < 0 ? 0 : (iy < n ? iy : n - 1);
+        cell = iy * n + ix;
+    }
+    return (int)((words[cell >> 5] >> (cell & 31)) & 1u);
+}
+
 /* Surface.mask surface.py:235-245; RingSurface.mask ring_surface.py:123-133;
  * RectangularSurface.mask rectangular_surface.py:100-112; SlitSurface.mask slit_surface.py:89-102 */
 int orc_mask1(const ot_surface* sf, double x, double y) {
@@ -91,7 +115,9 @@ int orc_mask1(const ot_surface* sf, double x, double y) {
         }
         default: { /* CIRCLE, CONIC, ASPHERE, TILTED, DATA1D, DATA2D */
             double dx = x - sf->pos[0], dy = y - sf->pos[1];
-            return dx * dx + dy * dy <= pow(sf->r + N_EPS, 2.0);
+            int in = dx * dx + dy * dy <= pow(sf->r + N_EPS, 2.0);
+            if (in && (sf->flags & OT_SURF_FLAG_MASK_TABLE)) in = mask_func_cell(sf, dx, dy);
+            return in;
         }
     }
 }

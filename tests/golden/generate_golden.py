@@ -186,6 +186,7 @@ def trace_recorded(builder, N: int, seed: int, **rt_args):
 TRACE_CASES = {name: (builder, N, 100 + j, {}) for j, (name, (builder, N)) in enumerate(scenes.SCENES.items())}
 TRACE_CASES["double_gauss_nopol"] = (scenes.double_gauss, 1200, 300, dict(no_pol=True))
 TRACE_CASES["asphere_nopol"] = (scenes.asphere_scene, 1500, 301, dict(no_pol=True))
+TRACE_CASES3 = {name: (builder, N, 600 + j, {}) for j, (name, (builder, N)) in enumerate(scenes.SCENES3.items())}
 TRACE_CASES2 = {name: (builder, N, 500 + j, {}) for j, (name, (builder, N)) in enumerate(scenes.SCENES2.items())}
 
 
@@ -465,7 +466,7 @@ def gen_convolve():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["leaf", "leaf2", "media", "trace", "trace2", "sources", "images", "spectra", "focus", "file"]
+    which = sys.argv[1:] or ["leaf", "leaf2", "media", "trace", "trace2", "trace3", "sources", "images", "spectra", "focus", "file"]
     if "convolve" in which:
         gen_convolve()
     if "leaf" in which:
@@ -479,6 +480,9 @@ if __name__ == "__main__":
             gen_trace(name, builder, N, seed=seed, **rt_args)
     if "trace2" in which:
         for name, (builder, N, seed, rt_args) in TRACE_CASES2.items():
+            gen_trace(name, builder, N, seed=seed, **rt_args)
+    if "trace3" in which:
+        for name, (builder, N, seed, rt_args) in TRACE_CASES3.items():
             gen_trace(name, builder, N, seed=seed, **rt_args)
     if "sources" in which:
         gen_sources()

@@ -196,6 +196,50 @@ def freeform_scene(ot, **rt_args):
     return RT
 
 
+# ---- function surfaces with a mask_func -------------------------------------------------------------------------------
+def _paraboloid(x, y):
+    return 0.02 * (x ** 2 + 0.6 * y ** 2)
+
+
+def _window(x, y):
+    """Rectangular window: its borders fall on cell borders of the mask bitmap (r = 5, a power-of-two cell count), where
+    the bitmap classifies exactly like the callable."""
+    return (np.abs(x) <= 2.5) & (np.abs(y) <= 1.875)
+
+
+def _bowl(r):
+    return -0.015 * r ** 2
+
+
+def _inner_disc(r):
+    return r <= 2.5
+
+
+def _half_plane(x, y):
+    return x >= -0.625
+
+
+def masked_scene(ot, **rt_args):
+    """FunctionSurface2D / FunctionSurface1D with mask_func (function_surface_2d.py:158-191): a lens whose front is
+    defined on a rectangular window and whose back on an inner disc, then a plate whose front keeps a half plane and
+    is flipped and rotated by 90 degrees.  Rays outside a mask do not hit the lens and are absorbed."""
+    RT = ot.Raytracer(outline=[-12, 12, -12, 12, 0, 60], **rt_args)
+    RT.add(ot.RaySource(ot.CircularSurface(r=3.2), divergence="Isotropic", div_angle=1.5, s=[0, 0, 1], pos=[0, 0, 0],
+                        spectrum=ot.LightSpectrum("Rectangle", wl0=480., wl1=620.)))
+    front = ot.FunctionSurface2D(func=_paraboloid, mask_func=_window, r=5)
+    back = ot.FunctionSurface1D(func=_bowl, mask_func=_inner_disc, r=5)
+    RT.add(ot.Lens(front, back, d=1.2, pos=[0, 0, 12], n=ot.RefractionIndex("Constant", n=1.52)))
+    half = ot.FunctionSurface2D(func=_paraboloid, mask_func=_half_plane, r=5)
+    half.flip()
+    half.rotate(90)
+    RT.add(ot.Lens(half, ot.CircularSurface(r=5), d=0.8, pos=[0, 0, 22], n=ot.RefractionIndex("Constant", n=1.6)))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[12, 12]), pos=[0, 0, 40]))
+    return RT
+
+
+SCENES3 = {"masked": (masked_scene, 3000)}
+
+
 # ---- random scenes (tests/test_gpu_random_scenes.py, golden trace_random*.npz) -------------------------------------
 def random_surface(ot, rng, r):
     kind = rng.integers(0, 5)

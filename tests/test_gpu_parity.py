@@ -97,8 +97,8 @@ def test_sphere_projection(media):
 
 
 # ---------------------------------------------------------------------------------------------------------
-TRACES = list(scenes.SCENES.keys()) + ["double_gauss_nopol", "asphere_nopol"] + list(scenes.SCENES2.keys())
-ALL_SCENES = {**scenes.SCENES, **scenes.SCENES2}
+TRACES = list(scenes.SCENES.keys()) + ["double_gauss_nopol", "asphere_nopol"] + list(scenes.SCENES2.keys()) + list(scenes.SCENES3.keys())
+ALL_SCENES = {**scenes.SCENES, **scenes.SCENES2, **scenes.SCENES3}
 
 
 def build(name):
@@ -128,10 +128,10 @@ def test_trace_matches_reference(name):
     assert r.w_list.dtype == np.float32 and r.wl_list.dtype == np.float32 and r.n_list.dtype == np.float64
     assert np.array_equal(RT._msgs, g["msgs"]), f"counters differ:\n{RT._msgs}\n{g['msgs']}"
     assert np.array_equal(r.w_list > 0, g["w_list"] > 0), "alive masks per section must be bit-exact"
-    tab = name == "freeform"  # FunctionSurface2D carried as a spline table: bounded by the tabulation residual
+    tab = name in ("freeform", "masked")  # FunctionSurface2D carried as a spline table: bounded by the tabulation residual
     assert_close(r.p_list, g["p_list"], rtol=1e-11, atol=1e-7 if tab else 1e-11, what="p_list")
     assert_close(r.n_list, g["n_list"], rtol=1e-13, what="n_list")
-    loose = name.startswith(("asphere", "mixed", "freeform"))
+    loose = name.startswith(("asphere", "mixed", "freeform", "masked"))
     assert_close(r.w_list, g["w_list"], rtol=1e-6 if loose else 2e-7, atol=1e-15 if loose else 1e-30, what="w_list")
     assert_close(r.s0_list, g["s_final"], rtol=1e-10, atol=1e-8 if tab else 1e-12, what="s_final")
     if not RT.no_pol:

@@ -239,3 +239,68 @@ def test_hit_finding_properties_on_every_surface():
             behind[:, 2] = S.z_max + 2
             p2, hit2, _ = S.find_hit(behind, s)
             assert np.allclose(p2 - behind, 0) and not np.any(hit2), name
+
+
+def _disc_mask(x, y):
+    return (x - 0.7) ** 2 + (y + 0.4) ** 2 <= 2.2 ** 2
+
+
+def _annulus(r):
+    return (r >= 0.9) & (r <= 3.1)
+
+
+def test_mask_func_bitmap_against_the_callable():
+    """mask_func travels as a bitmap (include/optrace_amd.h, OT_SURF_FLAG_MASK_TABLE): mask / values / normals / find_hit
+    on the device agree with the oracle on the same bitmap everywhere, and with the Python callable
+    (function_surface_2d.py:158-191) except within one cell of the mask's edge."""
+    rng = np.random.default_rng(77)
+    with ot.global_options.no_warnings():
+        f2 = ot.FunctionSurface2D(r=4, func=lambda x, y: 0.01 * (x ** 2 + 2 * y ** 2), mask_func=_disc_mask)
+        f2.flip()
+        f2.rotate(25)
+        f2.move_to([0.3, -0.2, 5])
+        f1 = ot.FunctionSurface1D(r=4, func=lambda r: 0.02 * r ** 2, mask_func=_annulus)
+        f1.move_to([-0.1, 0.25, 3])
+    n = 200_000
+    for sf in (f2, f1):
+        x, y = sf.pos[0] + rng.uniform(-4.5, 4.5, n), sf.pos[1] + rng.uniform(-4.5, 4.5, n)
+        sd = sf._desc()
+        m = sf.mask(x, y)
+        assert np.array_equal(m, ob.mask(sd, x, y)), "same bitmap, same cells"
+        callable_mask = sf._mask_host(x, y)
+        differ = m != callable_mask
+        dx, dy = x - sf.pos[0], y - sf.pos[1]
+        if sf is f2:
+            cell = 2 * sf.r / sf.N_MASK
+            xr, yr = sf._rotate_rc(dx, dy, -sf._angle)
+            edge_dist = np.abs(np.hypot(xr - 0.7, sf._sign * yr + 0.4) - 2.2)
+        else:
+            cell = sf.r / sf.N_MASK_1D
+            rr = np.hypot(dx, dy)
+            edge_dist = np.minimum(np.abs(rr - 0.9), np.abs(rr - 3.1))
+        assert np.all(edge_dist[differ] <= cell), "only positions within one cell of the edge may differ"
+        assert differ.mean() < 2e-3 and 0.1 < m.mean() < 0.6
+        assert_close(sf.values(x, y), ob.values(sd, x, y), rtol=1e-13, atol=1e-14, what="values vs oracle")
+        assert_close(sf.normals(x, y), ob.normals(sd, x, y), rtol=1e-11, atol=1e-13, what="normals vs oracle")
+        assert np.all(sf.normals(x, y)[~m] == [0, 0, 1]), "no surface, no slope (function_surface_2d.py:210-214)"
+        p = np.column_stack((x, y, np.full(n, sf.pos[2] - 2.0)))
+        s = np.column_stack((rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), np.ones(n)))
+        s /= np.linalg.norm(s, axis=1)[:, None]
+        ph, hit, ill = sf.find_hit(p, s)
+        ph_o, hit_o, ill_o, st = ob.find_hit(sd, p, s)
+        assert st == 0 and np.array_equal(hit, hit_o) and np.array_equal(ill, ill_o)
+        assert_close(ph, ph_o, rtol=1e-11, atol=1e-11, what="p_hit vs oracle")
+        assert np.array_equal(hit, sf.mask(ph[:, 0], ph[:, 1]) & hit), "a hit lies inside the mask"
+
+
+def test_mask_func_scene_image_matches_reference():
+    """The masked scene (fixture from the reference, which calls mask_func per ray): detector image."""
+    from helpers import sparse_to_dense, image_rel_l1
+    g, RT = gpu_trace("masked")
+    with ot.global_options.no_warnings():
+        ph, hw, wl, ext, projection, ill = RT._hit_detector("x", 0, None, None, None)
+        assert np.count_nonzero(hw.cpu().numpy() > 0) == g["det0/None/w"].shape[0]
+        img = RT.detector_image(detector_index=0)
+    pw = float(g["det0/None/img/power"])
+    assert abs(img.power() - pw) <= 1e-6 * pw
+    assert np.all(image_rel_l1(img._data, sparse_to_dense(g, "det0/None/img")) < 2e-3)

@@ -309,8 +309,26 @@ def test_tilted_data_function_surfaces_host_logic():
             ot.FunctionSurface2D(r=2, func=3)
         with pytest.raises(RuntimeError):
             ot.FunctionSurface2D(r=2, func=lambda x, y: 1.0)  # must return an array
-        with pytest.raises(NotImplementedError):
-            ot.FunctionSurface2D(r=2, func=lambda x, y: x * 0.1, mask_func=lambda x, y: x > 0)
+        with pytest.raises(RuntimeError):   # mask_func must return booleans (function_surface_2d.py:186)
+            ot.FunctionSurface2D(r=2, func=lambda x, y: x * 0.1, mask_func=lambda x, y: x * 1.0)
+        # mask_func travels as a bitmap behind the spline tables (include/optrace_amd.h, OT_SURF_FLAG_MASK_TABLE)
+        fm = ot.FunctionSurface2D(r=2, func=lambda x, y: x * 0.1, mask_func=lambda x, y: (x > 0) & (np.abs(y) <= 1))
+        dm, n = fm._desc(), ot.FunctionSurface2D.N_MASK
+        nc = dm.nknots - _capi.SPL_K - 1
+        spline_len = dm.nknots + nc * nc + 2 * (nc - 1) * nc
+        assert dm.flags == _capi.SURF_FLAG_MASK_TABLE and dm.tab_len == spline_len + 1 + n * n // 64
+        assert fm._tab[spline_len] == n
+        bits = np.unpackbits(fm._tab[spline_len + 1:].view(np.uint8), bitorder="little").reshape(n, n)  # [iy, ix]
+        assert bits[n // 2, n // 2 + 5] and not bits[n // 2, n // 2 - 5] and not bits[n - 10, n // 2 + 5]
+        assert bits.sum() == (n // 2) * (n // 2)       # x > 0: half the columns; |y| <= 1: half the rows
+        assert 0 <= fm.z_min < 1e-4 and abs(fm.z_max - 0.2) < 1e-4     # z range over the masked part only
+        assert fm._mask_host(np.array([0.5, -0.5, 0.5]), np.array([0.5, 0.5, 1.5])).tolist() == [True, False, False]
+        fm.rotate(90)   # the frame turns with the surface: the kept half is now y > 0
+        assert fm._mask_host(np.array([0.5, -0.5, 0.5]), np.array([0.5, 0.5, -0.5])).tolist() == [True, True, False]
+        fm1 = ot.FunctionSurface1D(r=2, func=lambda r: r ** 2 / 10, mask_func=lambda r: r <= 1.0)
+        d1m = fm1._desc()
+        assert d1m.flags == _capi.SURF_FLAG_MASK_TABLE and d1m.tab_len == 3 * d1m.nknots + 1 + fm1.N_MASK_1D // 64
+        assert abs(fm1.z_max - 0.1) < 1e-4 and fm1.z_min == 0
         with pytest.raises(ValueError):
             ot.FunctionSurface1D(r=2, func=lambda r: r ** 2 / 10, z_min=0.)  # z_min and z_max only together
         f1 = ot.FunctionSurface1D(r=2, func=lambda r: 0.5 + r ** 2 / 10, z_min=0.5, z_max=0.9)

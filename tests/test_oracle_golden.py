@@ -109,8 +109,8 @@ def test_oracle_binning(media):
 
 
 # --------------------------------------------------------------------------------------------------------
-TRACES = list(scenes.SCENES.keys()) + ["double_gauss_nopol", "asphere_nopol"] + list(scenes.SCENES2.keys())
-ALL_SCENES = {**scenes.SCENES, **scenes.SCENES2}
+TRACES = list(scenes.SCENES.keys()) + ["double_gauss_nopol", "asphere_nopol"] + list(scenes.SCENES2.keys()) + list(scenes.SCENES3.keys())
+ALL_SCENES = {**scenes.SCENES, **scenes.SCENES2, **scenes.SCENES3}
 
 
 def build(name):
@@ -144,12 +144,12 @@ def test_oracle_trace(name):
     assert np.array_equal(rays.w_list > 0, g["w_list"] > 0)
     # "freeform" holds a FunctionSurface2D, which this framework carries as a spline table (the reference calls
     # the Python function per ray): agreement there is bounded by the tabulation residual, not by rounding
-    tab = name == "freeform"
+    tab = name in ("freeform", "masked")
     assert_close(rays.p_list, g["p_list"], rtol=1e-12, atol=1e-7 if tab else 1e-12, what="p_list")
     assert_close(rays.n_list, g["n_list"], rtol=1e-14, what="n_list")
     # float32 storage rounding; scenes with a float32-evaluated Gaussian filter (spectrum.py:113) or a
     # host-tabulated "Function" spectrum get the north-star bar of 1e-6
-    loose = name.startswith(("asphere", "mixed", "freeform"))
+    loose = name.startswith(("asphere", "mixed", "freeform", "masked"))
     assert_close(rays.w_list, g["w_list"], rtol=1e-6 if loose else 2e-7, atol=1e-15 if loose else 1e-30, what="w_list")
     assert_close(rays.s_final, g["s_final"], rtol=1e-11, atol=1e-8 if tab else 1e-13, what="s_final")
     if not RT.no_pol:
