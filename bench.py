@@ -199,10 +199,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl" and world > ndev:
             backend = "gloo"
+        import datetime
+        limit = datetime.timedelta(seconds=300)  # a rank that never arrives fails the run instead of hanging it
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % ndev))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % ndev), timeout=limit)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=limit)
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
