@@ -1765,7 +1765,10 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     const size_t o_tn = carve(sizeof(unsigned int) * Kmax);
     const size_t o_ts = carve(sizeof(unsigned int) * (Kmax + 1));
     const size_t o_list = carve(sizeof(unsigned int) * capmax);
-    const size_t o_slabs = carve(KT ? sizeof(double) * OT_TILE_PX * 4 * (size_t)Kmax * OT_FUSE_SPLIT : 0);
+    const size_t o_ws = carve(sizeof(unsigned int) * (Kmax + 1));
+    // one slab per accumulation workgroup: a tile with n chunks takes ceil(n / OT_FUSE_CPW) of them
+    const unsigned n_slabs = (unsigned)((capmax + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)Kmax;
+    const size_t o_slabs = carve(KT ? sizeof(double) * OT_TILE_PX * 4 * (size_t)n_slabs : 0);
     char* ws = nullptr;
     if (KT) HIP_TRY(keep_async_pool(dev));
     if (hipMallocAsync((void**)&ws, off, st) != hipSuccess || !ws) {
@@ -1844,6 +1847,8 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
             FuseIndex ix;
             ix.tile_n = (unsigned int*)(ws + o_tn);
             ix.tstart = (unsigned int*)(ws + o_ts);
+            ix.wstart = (unsigned int*)(ws + o_ws);
+            ix.n_slabs = (unsigned)((f.cap + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)f.K;
             ix.list = (unsigned int*)(ws + o_list);
             ix.slabs = (double*)(ws + o_slabs);
             err = hipMemsetAsync(ix.tile_n, 0, sizeof(unsigned int) * f.K, st);
@@ -1852,7 +1857,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
             hipLaunchKernelGGL(fuse_chunk_hist_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
             hipLaunchKernelGGL(fuse_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, f, ix);
             hipLaunchKernelGGL(fuse_chunk_place_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
-            hipLaunchKernelGGL(fuse_accum_kernel, dim3(OT_FUSE_SPLIT, (unsigned)f.K), dim3(1024), lds_accum, st, f, ix, table);
+            hipLaunchKernelGGL(fuse_accum_kernel, dim3(ix.n_slabs), dim3(1024), lds_accum, st, f, ix, table);
             hipLaunchKernelGGL(fuse_reduce_kernel, dim3(OT_TILE_PX / 256, (unsigned)f.K), dim3(256), 0, st, f, ix);
             err = hipGetLastError();
         }

@@ -115,12 +115,22 @@ __global__ __launch_bounds__(256) void projection_kernel(double x0, double y0, d
 }
 
 // direction of section k re-derived from the stored positions (RayStorage.rays_by_mask ray_storage.py:274-279)
+// a / |a| with the division-free cores of ot_device.hpp (ot_sqrt, ot_rcp3, ot_div_r): the same bits as sqrt and `/` for
+// the magnitudes of section vectors (a zero vector -- a ray that no longer moves -- gives NaN either way), 27 instead of
+// 56 instructions per ray in the detector kernels
+OT_DEV V3 direction_of(const V3& a) {
+    const double l = ot_sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    const double il = ot_rcp3(l);
+    V3 r = {ot_div_r(a.x, l, il), ot_div_r(a.y, l, il), ot_div_r(a.z, l, il)};
+    return r;
+}
+
 OT_DEV V3 section_dir(const ot_rays& R, int64_t r, int k) {
     const int64_t N = R.N, nt = R.nt;
     int k1 = (k < R.nt - 1) ? k + 1 : k;
     V3 d = {R.p[r + N * k1] - R.p[r + N * k], R.p[r + N * (k1 + nt)] - R.p[r + N * (k + nt)],
             R.p[r + N * (k1 + 2 * nt)] - R.p[r + N * (k + 2 * nt)]};
-    return normalize3(d);
+    return direction_of(d);
 }
 
 struct Crop {
@@ -155,7 +165,31 @@ struct SectionPair {  // the last two sections of a ray and the weight of the la
 // direction of the last but one section, re-derived from the stored positions (ray_storage.py:274-279)
 OT_DEV V3 pair_direction(const SectionPair& sp) {
     V3 d = {sp.xl - sp.xq, sp.yl - sp.yq, sp.zl - sp.zq};
-    return normalize3(d);
+    return direction_of(d);
+}
+
+// The usual place of a detector is behind the last surface: the ray's last section starts before it and ends behind it.
+// That case, for a flat detector, settled from the prefetched pair of sections without the section search of
+// detector_hit (same arithmetic, same results: the search would pick this section, raytracer.py:929-985); rays that
+// end before the detector are settled too (no hit).  Returns false for a lane that needs the general search.
+template <class DET>
+OT_DEV bool detector_hit_last(DET& D, int nt, bool active, const SectionPair& sp, const V3& sdir, V3& ph, float& w,
+                              bool& valid) {
+    const auto& det = D.det;
+    valid = false;
+    w = 0.f;
+    ph = {0.0, 0.0, 0.0};
+    if (!active) return true;
+    const bool reaches = sp.zl >= det.z_min;
+    if (!reaches && !(sp.zl >= det.z_max)) return true;  // np.all(~bh_zmin & ~bh_zmax): ends before the detector
+    if (!(det.flat && nt >= 2 && reaches && !(sp.zq >= det.z_min))) return false;
+    const V3 p = {sp.xq, sp.yq, sp.zq};
+    bool ish, ill;
+    find_hit<false>(det, p, sdir, ph, ish, ill);
+    w = (ph.z > sp.zl + OT_C_EPS) ? 0.f : sp.wq;  // a hit behind the end of the ray is none (raytracer.py:985)
+    valid = ish && (w > 0);
+    if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
+    return true;
 }
 
 // The hit of one ray on one detector: section search, intersection, projection, user extent.

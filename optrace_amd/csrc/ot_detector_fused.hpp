@@ -20,7 +20,7 @@
 
 #define OT_FUSE_CH 256       // records per chunk (3 KB)
 #define OT_FUSE_BR 512       // rays per sub-block = threads per workgroup of the tile kernel
-#define OT_FUSE_SPLIT 8      // accumulation workgroups (and slabs) per tile
+#define OT_FUSE_CPW 256      // chunks per accumulation workgroup (and slab): 64 records per thread
 #define OT_FUSE_NONE 0xffffffffu
 #define OT_FUSE_LDS_ENTRIES 2400  // (detector, tile) entries a tile-kernel workgroup can keep (20 B each)
 
@@ -295,8 +295,14 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
                 if (!F.spread[0]) continue;
                 V3 ph;
                 float w;
-                bool valid, ill, to;
-                detector_hit<GENERAL, GENERAL>(R, r, act[j], F, sp[j], sdir, ph, w, valid, ill, to);
+                bool valid, ill = false, to = false;
+                // flat detector behind the last surface (the usual case): no section search; the wave takes the general
+                // path only if one of its lanes needs it
+                bool settled = false;
+                if (!GENERAL) settled = detector_hit_last(F, R.nt, act[j], sp[j], sdir, ph, w, valid);
+                if (GENERAL || __ballot(!settled) != 0ull) {
+                    if (!settled) detector_hit<GENERAL, GENERAL>(R, r, act[j], F, sp[j], sdir, ph, w, valid, ill, to);
+                }
                 if (GENERAL) fuse_count_ill(F, ill, to);
                 if (!valid) continue;
                 int32_t ix, iy;
@@ -390,8 +396,10 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
 struct FuseIndex {
     unsigned int* tile_n;   // [K] chunks of each tile, later the placement cursor
     unsigned int* tstart;   // [K + 1]
+    unsigned int* wstart;   // [K + 1] first accumulation workgroup (= slab) of each tile: ceil(chunks / OT_FUSE_CPW) each
     unsigned int* list;     // [cap] chunk numbers grouped by tile
-    double* slabs;          // [K * OT_FUSE_SPLIT][TILE_PX * 4]
+    double* slabs;          // [n_slabs][TILE_PX * 4]
+    unsigned int n_slabs;   // workgroups of the accumulation launch: cap / OT_FUSE_CPW + K bounds the number needed
 };
 
 // chunks per tile: LDS histogram per workgroup (16 chunk numbers per thread), one global add per tile and workgroup
@@ -422,12 +430,15 @@ __global__ __launch_bounds__(1024) void fuse_chunk_scan_kernel(FuseOne F, FuseIn
     for (int i = threadIdx.x; i < F.K; i += blockDim.x) n_s[i] = ix.tile_n[i];
     __syncthreads();
     if (threadIdx.x == 0) {  // K <= 2048 entries in LDS: a serial scan costs a few microseconds
-        unsigned int acc = 0;
+        unsigned int acc = 0, wg = 0;
         for (int i = 0; i < F.K; i++) {
             ix.tstart[i] = acc;
+            ix.wstart[i] = wg;
             acc += n_s[i];
+            wg += (n_s[i] + OT_FUSE_CPW - 1) / OT_FUSE_CPW;
         }
         ix.tstart[F.K] = acc;
+        ix.wstart[F.K] = wg;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < F.K; i += blockDim.x) ix.tile_n[i] = 0u;  // becomes the placement cursor
@@ -462,29 +473,45 @@ __global__ __launch_bounds__(1024) void fuse_chunk_place_kernel(FuseOne F, FuseI
         if (tl[k] != OT_FUSE_NONE) ix.list[h[tl[k]] + rank[k]] = c0 + k * 1024 + threadIdx.x;
 }
 
-// grid (OT_FUSE_SPLIT, K): workgroup (s, t) adds the chunks s, s + SPLIT, ... of tile t into an LDS tile -> its slab
+// Accumulation, one workgroup per OT_FUSE_CPW chunks of a tile (wstart): the hits of an image are rarely spread evenly
+// -- C4's picture covers a fifth of the detector, 42 of 225 tiles hold every record -- and a fixed number of workgroups
+// per tile left most CUs idle behind the few heavy tiles (1.7 of 4 waves per SIMD resident on average).  Workgroup b
+// finds its tile by bisection of wstart in LDS, adds its chunks into an LDS tile and writes slab b.
 __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex ix, const double* __restrict__ table) {
     if (!F.spread[0]) return;
-    const int t = blockIdx.y, s = blockIdx.x;
-    const unsigned int c0 = ix.tstart[t], n_t = ix.tstart[t + 1] - c0;
-    if ((unsigned int)s >= n_t) return;
-    extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 3 observer table]
+    extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 3 observer table]; the tile part first holds wstart
     double* tile = lds;
     double* obs = lds + OT_TILE_PX * 4;
+    unsigned int* ws = (unsigned int*)lds;
+    const int K = F.K;
+    for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
+    __syncthreads();
+    const unsigned int b = blockIdx.x;
+    if (b >= ws[K]) return;
+    int lo = 0, hi = K;  // ws[lo] <= b < ws[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ws[mid] <= b) lo = mid; else hi = mid;
+    }
+    const int t = lo;
+    const unsigned int part = b - ws[t];
+    __syncthreads();  // everyone has read ws: the tile may be cleared
+    const unsigned int c0 = ix.tstart[t], n_t = ix.tstart[t + 1] - c0;
+    const unsigned int j_begin = part * OT_FUSE_CPW;
+    const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
     for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
     for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
     __syncthreads();
     constexpr int PER = 1024 / OT_FUSE_CH;  // chunks a workgroup handles at once
     constexpr int DEPTH = 8;                // chunk rounds in flight per thread (list -> fill -> record are dependent loads)
     const int g = threadIdx.x / OT_FUSE_CH, slot = threadIdx.x % OT_FUSE_CH;
-    const unsigned int stride = OT_FUSE_SPLIT * PER;
-    for (unsigned int j0 = (unsigned int)s + (unsigned int)(OT_FUSE_SPLIT * g); j0 < n_t; j0 += stride * DEPTH) {
+    for (unsigned int j0 = j_begin + (unsigned int)g; j0 < j_end; j0 += PER * DEPTH) {
         TileRec rec[DEPTH];
         bool ok[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) {
-            const unsigned int j = j0 + k * stride;
-            ok[k] = j < n_t;
+            const unsigned int j = j0 + k * PER;
+            ok[k] = j < j_end;
             if (ok[k]) {
                 const unsigned int c = ix.list[c0 + j];
                 ok[k] = (unsigned int)slot < F.chunk_fill[c];
@@ -507,7 +534,7 @@ __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex i
         }
     }
     __syncthreads();
-    double* slab = ix.slabs + ((size_t)t * OT_FUSE_SPLIT + s) * (OT_TILE_PX * 4);
+    double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
     for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) slab[i] = tile[i];
 }
 
@@ -515,16 +542,15 @@ __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex i
 __global__ __launch_bounds__(256) void fuse_reduce_kernel(FuseOne F, FuseIndex ix) {
     if (!F.spread[0]) return;
     const int tl = blockIdx.y;
-    const unsigned int n_t = ix.tstart[tl + 1] - ix.tstart[tl];
-    if (!n_t) return;
-    const int ns = n_t < OT_FUSE_SPLIT ? (int)n_t : OT_FUSE_SPLIT;
+    const unsigned int s_first = ix.wstart[tl], s_end = ix.wstart[tl + 1];
+    if (s_end == s_first) return;
     const int local = blockIdx.x * blockDim.x + threadIdx.x;
     const int px = (tl % F.tx) * OT_TILE_W + (local & (OT_TILE_W - 1));
     const int py = (tl / F.tx) * OT_TILE_W + (local >> 6);
     if (px >= F.a.Nx || py >= F.a.Ny) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int s = 0; s < ns; s++) {
-        const double* sl = ix.slabs + ((size_t)tl * OT_FUSE_SPLIT + s) * (OT_TILE_PX * 4) + local;  // plane-major slab
+    for (unsigned int s = s_first; s < s_end; s++) {
+        const double* sl = ix.slabs + (size_t)s * (OT_TILE_PX * 4) + local;  // plane-major slab
         s0 += sl[0 * OT_TILE_PX];
         s1 += sl[1 * OT_TILE_PX];
         s2 += sl[2 * OT_TILE_PX];
