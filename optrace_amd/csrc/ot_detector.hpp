@@ -293,8 +293,14 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
     {
     V3 ph;
     float w;
-    bool valid, any_ill, timeout;
-    detector_hit<NUMERIC>(R, r, active, D, sp, sdir, ph, w, valid, any_ill, timeout);
+    bool valid, any_ill = false, timeout = false;
+    // flat detector behind the last surface without a sphere projection (the usual case): settled from the prefetched
+    // pair of sections; the section search only if a lane of the wave needs it
+    bool settled = false;
+    if (!NUMERIC && (D.projection == OT_PROJ_NONE || D.projection == OT_PROJ_ORTHOGRAPHIC)) settled = detector_hit_last(D, R.nt, active, sp, sdir, ph, w, valid);
+    if (__ballot(!settled) != 0ull) {
+        if (!settled) detector_hit<NUMERIC>(R, r, active, D, sp, sdir, ph, w, valid, any_ill, timeout);
+    }
     if (active) {
         D.ph[q] = valid ? ph.x : 0.0;
         D.ph[q + count] = valid ? ph.y : 0.0;
