@@ -762,6 +762,12 @@ extern "C" void ot_sources_destroy(ot_sources* s) {
 #ifndef OT_TRACE_MIN_WAVES
 #define OT_TRACE_MIN_WAVES 1
 #endif
+// Feature level 0 kernels (flat and conic surfaces only): five waves per SIMD asked for.  The discrete-spectrum variants
+// need 64-78 registers anyway; the continuous-spectrum ones (C3, C4) come down from 115-122 to 96 with a few spilled
+// values, and they wait on the dependent table loads of the generator half of the time: C4 10.5 -> 10.0 ms.
+#ifndef OT_TRACE_MIN_WAVES_F0
+#define OT_TRACE_MIN_WAVES_F0 5
+#endif
 
 struct RangeRec {  // one source range in device memory (scenes with more than OT_MAX_RANGES ranges)
     int64_t first, count;
@@ -888,7 +894,7 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
 // The launch covers the rays [ray_base, ray_base + count) of the bundle; R's pointers are advanced to ray_base by
 // the host (R.N stays the plane stride), so lanes address their ray with a 32-bit offset (count <= 2^28).
 template <bool POL, bool GEN, int SPEC, int FEAT>
-__global__ __launch_bounds__(256, OT_TRACE_MIN_WAVES) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
+__global__ __launch_bounds__(256, (FEAT == 0 ? OT_TRACE_MIN_WAVES_F0 : OT_TRACE_MIN_WAVES)) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
                                                     const SourceDev* __restrict__ sources, RangeArgs rg,
                                                     const double* __restrict__ hurb_normals, uint64_t seed,
                                                     unsigned int* __restrict__ slots, int64_t ray_base,

@@ -53,6 +53,13 @@ with ot.global_options.no_warnings():
         RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Data", wls=wls, vals=1 + 0.5 * np.sin(wls / 30)), **plain))
     elif which == "point_gauss_plain":
         RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Gaussian", mu=550., sig=30.), **plain))
+    elif which in ("point_mono_lamb", "point_mono_iso2d", "point_mono_iso_pol"):
+        kw = dict(divergence="Lambertian" if which.endswith("lamb") else "Isotropic", div_angle=16., s=[0, 0, 1])
+        if which.endswith("2d"):
+            kw.update(div_2d=True, div_axis_angle=20.)
+        RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Monochromatic", wl=550.), **kw))
+    elif which == "ring_mono_plain":
+        RT.add(ot.RaySource(ot.CircularSurface(r=2), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Monochromatic", wl=550.), **plain))
     elif which in ("inject_cont", "inject_lines"):
         RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Constant") if which == "inject_cont"
                             else ot.presets.light_spectrum.FDC, **plain))
