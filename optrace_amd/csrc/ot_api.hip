@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256, (FEAT == 0 ? OT_TRACE_MIN_WAVES_F0 : OT_TRACE_
                 r.polx = (float)nr.polx;
                 r.poly = (float)nr.poly;
                 r.polz = (float)nr.polz;
-                R.wl[local] = r.wl;
+                __builtin_nontemporal_store(r.wl, &R.wl[local]);  // written once, streamed (see OT_STORE_HINT)
             }
         } else {
             const int64_t N = R.N, nt = R.nt;

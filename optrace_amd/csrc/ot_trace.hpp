@@ -256,13 +256,19 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
 // than five wait states earlier uses the OLD value (gfx9 hazard).  The compiler pads that hazard for its own
 // instructions but cannot see into an asm statement; a scalar move in between is interlocked by the hardware on both
 // sides.  (Found as stray final directions in 1 of ~3 runs of the kernel variants that spill SGPRs.)
+#ifndef OT_STORE_HINT
+// Cache-policy bits of the section stores.  Every section is written once and never read by this kernel: as non-temporal
+// stores they stream past the caches instead of being allocated there (A/B on one box, tools/ab_bench.py,
+// profiles/r2/store_hints.txt: kernel 1.671 -> 1.622 ms with " nt"; " sc0 sc1" alone 1.667; " sc0 sc1 nt" 1.619, shipped).
+#define OT_STORE_HINT " sc0 sc1 nt"
+#endif
 OT_DEV void store_f64(const void* base, uint32_t off, double v) {
     const void* b;
-    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0" : "=&s"(b) : "v"(off), "v"(v), "s"(base));
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0" OT_STORE_HINT : "=&s"(b) : "v"(off), "v"(v), "s"(base));
 }
 OT_DEV void store_f32(const void* base, uint32_t off, float v) {
     const void* b;
-    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" : "=&s"(b) : "v"(off), "v"(v), "s"(base));
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" OT_STORE_HINT : "=&s"(b) : "v"(off), "v"(v), "s"(base));
 }
 
 // One section of one ray.  The plane base addresses (array + N * plane) are wave-uniform and stay in SGPRs; the
