@@ -253,7 +253,7 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
         const uint32_t q = i0 + j * OT_FUSE_BR + threadIdx.x;
         act_n[j] = q < i1;
         sp_n[j] = load_section_pair(R, (int64_t)(act_n[j] ? q : 0u), act_n[j]);
-        wl_n[j] = act_n[j] ? R.wl[q] : 0.f;
+        wl_n[j] = act_n[j] ? OT_STREAM_LOAD(&R.wl[q]) : 0.f;
     }
     int par = 0;
     for (uint32_t s = i0; s < i1; s += BRT, par ^= 1) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
             const uint32_t q = s + BRT + j * OT_FUSE_BR + threadIdx.x;
             act_n[j] = q < i1;  // (count < 2^31: no wrap)
             sp_n[j] = load_section_pair(R, (int64_t)(act_n[j] ? q : 0u), act_n[j]);
-            wl_n[j] = act_n[j] ? R.wl[q] : 0.f;
+            wl_n[j] = act_n[j] ? OT_STREAM_LOAD(&R.wl[q]) : 0.f;
         }
 
         // The detector records are read through a pointer the optimiser cannot see through, once per sub-block:
