@@ -8,6 +8,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests"), str(ROOT / "tools")]
 which = sys.argv[1] if len(sys.argv) > 1 else "C4"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+AUTO = "auto" in sys.argv
 sys.argv = [sys.argv[0], "NONE"]
 import torch
 
@@ -19,7 +20,7 @@ build, N = bc.CONFIGS[name]
 with ot.global_options.no_warnings():
     RT = build(ot)
     RT.trace(N)
-    ext = [-8., 8., -8., 8.] if which == "C4" else None
+    ext = [-8., 8., -8., 8.] if which == "C4" and not AUTO else None
     for _ in range(reps):
         img = RT.detector_image(extent=ext) if ext else RT.detector_image()
 torch.cuda.synchronize()
