@@ -8,7 +8,8 @@ class OptraceWarning(UserWarning):
     """Warning category of this package."""
 
 
-def warning(text: str) -> None:
+def warning(text: str):
     """Emit an OptraceWarning unless warnings are globally disabled."""
-    if global_options.show_warnings:
-        _w.warn(text, OptraceWarning, stacklevel=3)
+    if not global_options.show_warnings:
+        return
+    _w.warn(text, OptraceWarning, stacklevel=3)
