@@ -66,10 +66,9 @@ class Raytracer(Group):
         self.seed = seed  #: base seed of the device RNG (None: drawn from numpy's global RNG per trace)
         self.rays = RayStorage()
         self._msgs = np.array([])
-        self._ignore_geometry_error = False
-        self.geometry_error = False
-        self._last_trace_snapshot = None
-        self.fault_pos = np.array([])
+        self.geometry_error = self._ignore_geometry_error = False   # found by the checks / tracing goes on regardless
+        self.fault_pos = np.array([])        # where the geometry checks found surfaces colliding
+        self._last_trace_snapshot = None     # tracing_snapshot() of the last trace
         self._scene = None
         self._scene_handle = None
         self._scene_key = None
@@ -192,7 +191,7 @@ class Raytracer(Group):
         if self._checked_key is None or key != self._checked_key or self.geometry_error:
             self._geometry_checks()
             self._checked_key = key if not self.geometry_error else None
-        if self.geometry_error and not self._ignore_geometry_error:
+        if self.geometry_error and not self._ignore_geometry_error:  # (flag of the reference's test suite)
             warning("ABORTED TRACING")
             return True
         return False
@@ -557,9 +556,9 @@ class Raytracer(Group):
         return xy, d["w"][Ns:Ne], d["wl"][Ns:Ne], self.ray_sources[source_index].extent[:4]
 
     def _source_label(self, source_index: int) -> str:
-        rs = self.ray_sources[source_index]
-        title = f": {rs.desc}" if rs.desc else ""
-        return f"{RaySource.abbr}{source_index}{title} at z = {rs.pos[2]:.5g} mm"
+        source = self.ray_sources[source_index]
+        title = f": {source.desc}" if source.desc else ""
+        return f"{RaySource.abbr}{source_index}{title} at z = {source.pos[2]:.5g} mm"
 
     def source_spectrum(self, source_index: int = 0, **kwargs) -> LightSpectrum:
         """Spectrum emitted by a source, from its traced rays (raytracer.py:1311-1329)."""
@@ -608,11 +607,11 @@ class Raytracer(Group):
         # the search runs in the free gap around z_start: from the last surface (or source end) before it to the
         # first surface (or the outline's far face) behind it
         gap = [self.N_EPS + max(rs.extent[5] for rs in self.ray_sources), self.outline[5] - self.N_EPS]
-        for surf in self.tracing_surfaces:
-            if surf.z_max > z_start:
-                gap[1] = surf.z_min
+        for surface in self.tracing_surfaces:
+            if surface.z_max > z_start:
+                gap[1] = surface.z_min
                 break
-            gap[0] = surf.z_max
+            gap[0] = surface.z_max
         bounds = [float(gap[0]), float(gap[1])]
 
         Nt = 320  # cost function sampling points
@@ -700,7 +699,7 @@ class Raytracer(Group):
         pos = (float((sm[1] + sm[3] * res.x) / sm[0]), float((sm[2] + sm[4] * res.x) / sm[0]), float(res.x))
         if not return_cost:
             r = vals = None
-        return res, dict(pos=pos, bounds=bounds, z=r, cost=vals, N=N_use)
+        return res, {"pos": pos, "bounds": bounds, "z": r, "cost": vals, "N": N_use}
 
     # ---- iterative rendering (raytracer.py:1134-1279) -------------------------------------------------------
     def iterative_render(self, N, detector_index=0, limit=None, projection_method="Equidistant", pos=None,
@@ -718,7 +717,7 @@ class Raytracer(Group):
         if pos is None:
             if isinstance(detector_index, list):
                 raise ValueError("detector_index list needs to have the same length as pos list")
-            pos = [self.detectors[detector_index].pos]
+            pos = [np.array(self.detectors[detector_index].pos)]
         elif not isinstance(pos[0], (list, np.ndarray)):
             pos = [pos]
         n_img = len(pos)
@@ -737,7 +736,7 @@ class Raytracer(Group):
         extentc = per_image(extent, "extent", isinstance(extent, list) and not isinstance(extent[0], (int, float)))
 
         n_sec = len(self.tracing_surfaces) + 2
-        rays_step = self.ITER_RAYS_STEP
+        rays_step = self.ITER_RAYS_STEP  # None: sized by storage, below
         if rays_step is None:
             # chunk = what ITER_STORAGE_BYTES of ray storage hold (the reference's 1 M rays are sized for a few GB of
             # host RAM, raytracer.py:40); chunks of equal size, at least 1 M rays
@@ -753,10 +752,10 @@ class Raytracer(Group):
             raise RuntimeError("Geometry checks failed. Tracing aborted. Check the warnings.")
 
         nt = n_sec
-        msgs_cum = np.zeros((len(self.INFOS), nt), dtype=int)
+        msgs_cum = np.zeros((len(self.INFOS), n_sec), dtype=int)
         scale0, scaled = 1.0, False
 
-        for i in range(iterations):
+        for i in range(iterations):  # one chunk of rays per iteration (raytracer.py:1235-1267)
             if i == iterations - 1:
                 rays_step += int(N - iterations * rays_step)
             with global_options.no_warnings():
