@@ -115,22 +115,12 @@ __global__ __launch_bounds__(256) void projection_kernel(double x0, double y0, d
 }
 
 // direction of section k re-derived from the stored positions (RayStorage.rays_by_mask ray_storage.py:274-279)
-// a / |a| with the division-free cores of ot_device.hpp (ot_sqrt, ot_rcp3, ot_div_r): the same bits as sqrt and `/` for
-// the magnitudes of section vectors (a zero vector -- a ray that no longer moves -- gives NaN either way), 27 instead of
-// 56 instructions per ray in the detector kernels
-OT_DEV V3 direction_of(const V3& a) {
-    const double l = ot_sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
-    const double il = ot_rcp3(l);
-    V3 r = {ot_div_r(a.x, l, il), ot_div_r(a.y, l, il), ot_div_r(a.z, l, il)};
-    return r;
-}
-
 OT_DEV V3 section_dir(const ot_rays& R, int64_t r, int k) {
     const int64_t N = R.N, nt = R.nt;
     int k1 = (k < R.nt - 1) ? k + 1 : k;
     V3 d = {R.p[r + N * k1] - R.p[r + N * k], R.p[r + N * (k1 + nt)] - R.p[r + N * (k + nt)],
             R.p[r + N * (k1 + 2 * nt)] - R.p[r + N * (k + 2 * nt)]};
-    return direction_of(d);
+    return normalize3(d);
 }
 
 struct Crop {
@@ -165,7 +155,7 @@ struct SectionPair {  // the last two sections of a ray and the weight of the la
 // direction of the last but one section, re-derived from the stored positions (ray_storage.py:274-279)
 OT_DEV V3 pair_direction(const SectionPair& sp) {
     V3 d = {sp.xl - sp.xq, sp.yl - sp.yq, sp.zl - sp.zq};
-    return direction_of(d);
+    return normalize3(d);
 }
 
 // The usual place of a detector is behind the last surface: the ray's last section starts before it and ends behind it.

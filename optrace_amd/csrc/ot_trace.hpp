@@ -222,12 +222,12 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
     V3 a = {-b.y, b.x, b.z};
     V3 s = r.s;
     double sa_ = dot3(s, a), sb_ = dot3(s, b);
-    double cos_psi_a = sqrt(1 - sa_ * sa_);
-    double cos_psi_b = sqrt(1 - sb_ * sb_);
+    double cos_psi_a = ot_sqrt(1 - sa_ * sa_);
+    double cos_psi_b = ot_sqrt(1 - sb_ * sb_);
     float wlm = r.wl * (float)1e-9;  // float32 product in the reference (wl_list is float32)
-    double k = 2 * M_PI * r.n_cur / (double)wlm;
-    double tan_sig_b = sc.hurb_factor / (2 * b_ * cos_psi_b * 1e-3 * k);
-    double tan_sig_a = sc.hurb_factor / (2 * a_ * cos_psi_a * 1e-3 * k);
+    double k = ot_div(2 * M_PI * r.n_cur, (double)wlm);
+    double tan_sig_b = ot_div(sc.hurb_factor, 2 * b_ * cos_psi_b * 1e-3 * k);
+    double tan_sig_a = ot_div(sc.hurb_factor, 2 * a_ * cos_psi_a * 1e-3 * k);
     double tan_tha = fabs(tan_sig_a) * za;
     double tan_thb = fabs(tan_sig_b) * zb;
     V3 sa = normalize3(cross3(b, s));
