@@ -693,9 +693,9 @@ OT_DEV void philox_u2(uint64_t seed, uint64_t idx, uint32_t stream, uint32_t sub
 OT_DEV void philox_normal2(uint64_t seed, uint64_t idx, uint32_t stream, uint32_t sub, double& z0, double& z1) {
     double u0, u1;
     philox_u2(seed, idx, stream, sub, u0, u1);
-    double r = sqrt(-2.0 * log(1.0 - u0));  // 1-u0 in (0, 1]
+    double r = ot_sqrt(-2.0 * log(1.0 - u0));  // 1-u0 in (0, 1]
     double sn, cs;
-    sincos(6.283185307179586 * u1, &sn, &cs);
+    sincospi_small(2.0 * u1, &sn, &cs);  // angle 2 pi u1 without the general range reduction of sincos
     z0 = r * cs;
     z1 = r * sn;
 }
