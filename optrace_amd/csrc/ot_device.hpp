@@ -318,9 +318,18 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y, PatchCache* pc = nullptr) {
 
 // Surface._find_hit_handle_abnormal surface.py:436-479
 template <class SF>
+OT_DEV void handle_abnormal_f(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, double f);
+template <class SF>
 OT_DEV void handle_abnormal(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, PatchCache* pc = nullptr) {
     double zs = surf_values(sf, ph.x, ph.y, pc);
-    bool dev = fabs(ph.z - zs) > OT_C_EPS;
+    handle_abnormal_f(sf, p, s, ph, hit, ph.z - zs);
+}
+
+// the same with f = ph.z - values(ph) known: the numeric hit search has just evaluated it at the point it returns
+// (surface.py:369 computes exactly this difference for the point that becomes p_hit), one surface evaluation less
+template <class SF>
+OT_DEV void handle_abnormal_f(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, double f) {
+    bool dev = fabs(f) > OT_C_EPS;
     bool beh = p.z > sf.z_beh;
     bool neg = ph.z < p.z - OT_C_EPS;
     if ((neg || dev) && !beh) {
@@ -427,6 +436,8 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
     bool w = !pre && isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
     ph.x = ph.y = ph.z = 0.0;
     if (!w) ph = p1;
+    double f_ph = f1;  // cost function at ph: at p1 for lanes without a search, re-set when a lane converges (a lane
+                       // that runs into the iteration limit fails the whole trace, surface.py:403)
     ill = !pre && f1 * f2 > 0;
     bool ok = true;
     int it = 1;
@@ -453,6 +464,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
             }
             if (fabs(t2 - t1) < OT_C_EPS / 10) {
                 ph = pl;
+                f_ph = fts;
                 w = false;
             }
         }
@@ -464,7 +476,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
     }
     if (!pre) {
         hit = surf_mask(sf, ph.x, ph.y);
-        handle_abnormal(sf, p, s, ph, hit, pc);
+        handle_abnormal_f(sf, p, s, ph, hit, f_ph);
     }
     if (sf.kind == OT_SURF_TILTED) {  // tilted_surface.py:119-120: abnormal handling once more, for all rays
         if (pre) {
