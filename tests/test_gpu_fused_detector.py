@@ -146,3 +146,27 @@ def test_iterative_render_positions_equal_single_images(path):
         assert imgs[j]._data.shape == ref[j].shape
         assert np.abs(imgs[j]._data - ref[j]).max() <= 1e-11 * np.abs(ref[j]).max()
         assert abs(imgs[j].power() - ref[j][..., 3].sum()) <= 1e-11 * ref[j][..., 3].sum()
+
+
+@pytest.mark.parametrize("path", ["direct", "tiles"])
+def test_fused_detector_not_behind_the_last_surface(path):
+    """The fused kernels settle a flat detector behind the last surface from the last two sections of a ray
+    (`detector_hit_last`); everywhere else -- before the lens, inside it, in a lens stack -- a wave falls back to the
+    section search.  Both give the two-step chain's image, also when the two cases meet in one wave (rays that die at
+    the stop next to rays that reach the detector)."""
+    with ot.global_options.no_warnings():
+        RT = image_scene(N=300_000, seed=11)
+        for z in (6.0, 12.0, 12.9, 20.0):          # before the lens, at its centre plane, behind its back vertex, far behind
+            RT.detectors[0].move_to([0, 0, z])
+            with pinned(path):
+                same_image(RT.detector_image(extent=[-6., 6., -6., 6.]),
+                           RT.detector_image(extent=[-6., 6., -6., 6.], _unfused=True))
+        RT2 = scenes.double_gauss(ot, seed=4)
+        RT2.trace(200_000)
+        z_last = max(s.z_max for s in RT2.tracing_surfaces[:-1])
+        stop_z = [el for el in RT2.apertures][0].pos[2]
+        for z in (stop_z + 2.0, z_last + 1.0, z_last + 60.0):   # inside the stack (behind the stop), just behind, far behind
+            RT2.detectors[0].move_to([0, 0, z])
+            with pinned(path):
+                same_image(RT2.detector_image(extent=[-40., 40., -40., 40.]),
+                           RT2.detector_image(extent=[-40., 40., -40., 40.], _unfused=True))

@@ -60,6 +60,14 @@ with ot.global_options.no_warnings():
         RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Monochromatic", wl=550.), **kw))
     elif which == "ring_mono_plain":
         RT.add(ot.RaySource(ot.CircularSurface(r=2), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Monochromatic", wl=550.), **plain))
+    elif which in ("eye_point_lines", "eye_point_cont", "eye_none"):
+        # the Arizona eye of C3 (conic surfaces, k != 0, polarisation on) behind a cheap source: cost of its surface steps
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -610, 28], seed=31)
+        spec = ot.presets.light_spectrum.FDC if which == "eye_point_lines" else ot.LightSpectrum("Constant")
+        RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", div_angle=0.25, s=[0, 0, 1], pos=[0, 0, -600], spectrum=spec))
+        if which != "eye_none":
+            RT.add(ot.presets.geometry.arizona_eye(adaptation=1 / 0.6, pupil=4))
+        N = 50_000_000
     elif which in ("inject_cont", "inject_lines"):
         RT.add(ot.RaySource(ot.Point(), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Constant") if which == "inject_cont"
                             else ot.presets.light_spectrum.FDC, **plain))
