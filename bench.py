@@ -95,7 +95,7 @@ def cpu_baseline(RT, scene, seconds: float) -> dict:
     threads = int(os.environ.get("OT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
 
     d, N, nt = r._dev, r.N, scene.nt
-    pv = d["p"].view(3, nt, N)  # element (ray, section, component) lives at ray + N * (section + nt * component)
+    pv = d["p"].view(3, nt, r._Np)  # element (ray, section, component) lives at ray + stride * (section + nt * component)
 
     def run(n, th):
         rays = ob.HostRays(n, scene.nt, RT.no_pol)
@@ -103,7 +103,7 @@ def cpu_baseline(RT, scene, seconds: float) -> dict:
         p0 = pv[:, 0, :n].t().cpu().numpy()
         dirs = pv[:, 1, :n].t().cpu().numpy() - p0
         s0 = dirs / np.linalg.norm(dirs, axis=1)[:, None]
-        pol0 = None if RT.no_pol else d["pol"].view(3, nt, N)[:, 0, :n].t().cpu().numpy()
+        pol0 = None if RT.no_pol else d["pol"].view(3, nt, r._Np)[:, 0, :n].t().cpu().numpy()
         rays.set_initial(p0, s0, pol0, d["w"][:n].cpu().numpy(), d["wl"][:n].cpu().numpy())
         t0 = time.perf_counter()
         ob.trace(scene.desc, rays, None, threads=th)

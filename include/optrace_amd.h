@@ -268,7 +268,8 @@ typedef struct ot_source {
     const double* s_or; int64_t n_or;
 } ot_source;
 
-/* A contiguous block of rays generated from one source: rays [first, first+count) of the launch.  A block
+/* A contiguous block of rays generated from one source: rays [first, first+count) of the launch (the blocks of a
+ * launch follow each other without gaps from ray 0 on; slots of the storage behind the last block stay unused).  A block
  * is one stratification domain, as one thread's share is in the reference (ray_storage.py:147-166); a source
  * may be cut into several.  Blocks whose count is a power of two are the cheapest to generate (their stratum
  * permutation needs no rejection step). */
@@ -284,8 +285,14 @@ typedef struct ot_source_range {
 typedef struct ot_sources ot_sources; /* opaque: device copy of sources + tables */
 
 /* ---- ray storage: RayStorage ray_storage.py:35-90 --------------------------------------------- */
+/* N is the number of ray slots AND the plane stride: element (ray r, section i, component c) of p lives at
+ * r + N * (i + nt * c).  A caller may make N larger than its ray count so that every plane starts on a 128-byte line
+ * (a multiple of 32 rays; with planes off the lines the tracing kernel runs 30-50 % slower): the source ranges of
+ * ot_generate_and_trace / ot_rays_generate then cover the first rays only and the slots behind are neither generated
+ * nor traced; ot_trace (rays handed in) walks all N slots, so the unused ones must hold weight 0 and a finite
+ * direction; every detector / spectrum / focus entry point takes its own first / count. */
 typedef struct ot_rays {
-    int64_t N;   /* rays in this launch                                                            */
+    int64_t N;   /* ray slots = plane stride (>= rays of the launch, see above)                     */
     int32_t nt;  /* sections per ray = n tracing surfaces + 2 (raytracer.py:278)                   */
     int32_t _pad;
     double* p;   /* (N, nt, 3) f64 F-order  p_list                                                 */

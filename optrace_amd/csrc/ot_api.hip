@@ -1161,7 +1161,8 @@ static int make_ranges(const ot_source_range* ranges, int32_t n_ranges, const ot
         }
         covered += ranges[k].count;
     }
-    if (covered != N) return fail(OT_ERR_INVALID, "source ranges must cover all N rays exactly once");
+    // (covered <= N by the checks above; rays behind the last range -- the padding of a storage whose plane stride N is
+    // larger than its ray count -- are not generated and not traced)
     RangeRec* d = nullptr;
     if (big) {
         HIP_TRY(hipMalloc((void**)&d, sizeof(RangeRec) * recs.size()));

@@ -342,7 +342,10 @@ class Raytracer(Group):
             rays_obj.set_initial_rays(*_initial_rays)
             hn = None
             if _hurb_normals is not None:
-                hn = torch.from_numpy(np.ascontiguousarray(_hurb_normals, dtype=np.float64).reshape(-1)).to(dev)
+                rows = np.ascontiguousarray(_hurb_normals, dtype=np.float64).reshape(-1, N)
+                if rays_obj._Np > N:  # one row per (aperture, component), laid out with the storage's plane stride
+                    rows = np.pad(rows, ((0, 0), (0, rays_obj._Np - N)))
+                hn = torch.from_numpy(np.ascontiguousarray(rows).reshape(-1)).to(dev)
             msgs = torch.zeros(n_msgs, dtype=torch.int64, device=dev)
             _capi.check(lib.ot_trace(self._scene_handle, C.byref(rays), ptr(hn), seed, ptr(msgs), stream_ptr()))
             msgs_h = msgs.cpu().numpy()  # (synchronises the stream)
@@ -550,7 +553,7 @@ class Raytracer(Group):
         self._need_rays()
         Ns, Ne = self._ray_range(int(source_index))
         self._need_current()
-        N, nt, d = self.rays.N, self.rays.Nt, self.rays._dev
+        N, nt, d = self.rays._Np, self.rays.Nt, self.rays._dev  # (N: the plane stride of the storage)
         # element (ray r, section i, component c) of p lives at r + N * (i + nt * c); section 0 here
         xy = d["p"][Ns:Ne], d["p"][N * nt + Ns:N * nt + Ne]
         return xy, d["w"][Ns:Ne], d["wl"][Ns:Ne], self.ray_sources[source_index].extent[:4]

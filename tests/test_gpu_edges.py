@@ -583,3 +583,68 @@ def test_beam_along_a_face_normal_keeps_its_power():
         np.testing.assert_allclose(w[:, 1] / w[:, 0], T, rtol=2e-6)
         # direction unchanged up to rounding, polarisation still transverse and of unit length
         np.testing.assert_allclose(np.linalg.norm(pol[:, 1], axis=1), 1.0, atol=1e-6)
+
+
+def test_padded_plane_stride_equals_packed_storage(monkeypatch):
+    """From RayStorage.PAD_FROM rays on the planes of the device buffers are a multiple of 128 elements apart (an odd ray
+    count would put every plane off the 128-byte lines).  Everything a user can read is what the packed layout gives:
+    host lists, counters, detector images and spectra, source images, ray selections, and the same for rays handed in
+    (with HURB normals laid out with the stride)."""
+    import optrace_amd.ray_storage as rs_mod
+    N = (1 << 20) + 37
+
+    def run(pad: bool):
+        monkeypatch.setattr(rs_mod.RayStorage, "PAD_FROM", (1 << 20) if pad else (1 << 62))
+        with ot.global_options.no_warnings():
+            RT = scenes.double_gauss(ot, seed=17)
+            RT.trace(N)
+            assert (RT.rays._Np > N) == pad and RT.rays._Np % 128 == (0 if pad else N % 128)
+            r = RT.rays
+            out = dict(p=r.p_list.copy(), w=r.w_list.copy(), n=r.n_list.copy(), pol=r.pol_list.copy(), wl=r.wl_list.copy(),
+                       s=r.s0_list.copy(), msgs=RT._msgs.copy())
+            assert r.p_list.shape == (N, 17, 3) and r.p_list.flags.f_contiguous and r.s0_list.shape == (N, 3)
+            assert r.pol_list.flags.f_contiguous and r.w_list.shape == (N, 17) and r.wl_list.shape == (N,)
+            out["img_auto"] = RT.detector_image()._data.copy()
+            out["img_user"] = RT.detector_image(extent=[-30., 30., -40., 10.])._data.copy()
+            out["img_src"] = RT.detector_image(source_index=3)._data.copy()
+            sp = RT.detector_spectrum()
+            out["spec"] = np.array(sp._vals)
+            out["src_img"] = RT.source_image(2)._data.copy()
+            ch = np.zeros(N, dtype=bool)
+            ch[[0, 5, N // 2, N - 1]] = True
+            sel = r.rays_by_mask(ch)
+            out["sel"] = [np.array(a) for a in sel if a is not None]
+            out["sel2"] = [np.array(a) for a in r.rays_by_mask(ch, np.array([0, 3, 16, 8])) if a is not None]
+            out["sec"] = [np.array(a) for a in r.source_sections(4)]
+            # the same rays handed in again (ot_trace walks the whole stride: the padding must be dead)
+            init = (out["p"][:, 0], out["s"] * 0 + _dirs(out["p"]), out["pol"][:, 0], out["w"][:, 0], out["wl"])
+            RT.trace(N, _initial_rays=init, _N_list=r.N_list)
+            out["msgs_inj"] = RT._msgs.copy()
+            out["w_inj"] = RT.rays.w_list.copy()
+            out["p_inj"] = RT.rays.p_list.copy()
+            # HURB with injected normals
+            RH = scenes.hurb_slit_lens(ot, seed=5)
+            RH.trace(N)
+            hn = np.random.default_rng(3).normal(size=(2, N))
+            init = (RH.rays.p_list[:, 0].copy(), _dirs(RH.rays.p_list), RH.rays.pol_list[:, 0].copy(),
+                    RH.rays.w_list[:, 0].copy(), RH.rays.wl_list.copy())
+            RH.trace(N, _initial_rays=init, _hurb_normals=hn, _N_list=RH.rays.N_list)
+            out["hurb_p"], out["hurb_w"], out["hurb_msgs"] = RH.rays.p_list.copy(), RH.rays.w_list.copy(), RH._msgs.copy()
+        return out
+
+    def _dirs(p):
+        d = p[:, 1] - p[:, 0]
+        return d / np.linalg.norm(d, axis=1)[:, None]
+
+    a, b = run(True), run(False)
+    for key in a:
+        if isinstance(a[key], list):
+            assert len(a[key]) == len(b[key])
+            for x, y in zip(a[key], b[key]):
+                assert np.array_equal(x, y, equal_nan=True), key
+        elif key.startswith(("img_", "src_img", "spec")):  # sums of atomic adds: equal up to their order
+            assert a[key].shape == b[key].shape and np.array_equal(a[key] != 0, b[key] != 0), key
+            np.testing.assert_allclose(a[key], b[key], rtol=1e-11, atol=0, err_msg=key)
+        else:
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+    assert a["msgs"].sum() > 0 and a["img_auto"][..., 3].sum() > 0 and a["hurb_msgs"].sum() > 0
