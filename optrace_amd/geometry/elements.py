@@ -250,8 +250,12 @@ class Detector(_SingleSurface):
     abbr = "DET"
 
     def __setattr__(self, key, val):
-        if key == "front" and isinstance(val, AsphericSurface):
-            raise RuntimeError("Function-defined surfaces are not supported as Detector surfaces.")
+        if key == "front":
+            from .data_surfaces import DataSurface2D   # (data_surfaces imports surfaces: resolved at call time)
+            # detector.py:39-41: data and function surfaces and their subclasses (the asphere is one in the reference)
+            if isinstance(val, (DataSurface2D, AsphericSurface)):
+                raise RuntimeError("Classes and subclasses of DataSurface1D, DataSurface2D, FunctionSurface2D"
+                                   " are not supported as Detector surfaces.")
         Element.__setattr__(self, key, val)
 
 
