@@ -465,10 +465,22 @@ def gen_convolve():
     print("convolve.npz", len(out))
 
 
+def gen_host_objects():
+    """Numeric state of surfaces, lenses, groups, sources and spectra after construction, move_to, flip and rotate
+    (tests/host_cases.py run on the reference): pins the host classes of optrace_amd, which were written from the
+    contract, to the reference's bookkeeping."""
+    import host_cases
+    out = host_cases.all_cases(ot)
+    np.savez_compressed(HERE / "host_objects.npz", **out)
+    print("host_objects.npz", len(out))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["leaf", "leaf2", "media", "trace", "trace2", "trace3", "sources", "images", "spectra", "focus", "file"]
     if "convolve" in which:
         gen_convolve()
+    if "host" in which:
+        gen_host_objects()
     if "leaf" in which:
         gen_leaf_surfaces()
     if "leaf2" in which:
