@@ -38,7 +38,10 @@ def _samples(first, second, res: int):
     for obj in (first, second):
         if isinstance(obj, Line):
             t = np.linspace(-obj.r, obj.r, 10 * res)
-            phi = np.deg2rad(obj.angle)
+            # the reference feeds the angle, which is kept in degrees, to cos / sin as it is (raytracer.py:619-620): the
+            # sampled segment points elsewhere than the line does.  Kept, so that geometry checks give the same verdicts
+            # (tests/golden/host_objects.npz, collision/line_back)
+            phi = obj.angle
             return obj.pos[0] + t * np.cos(phi), obj.pos[1] + t * np.sin(phi)
     fa, fb = np.asarray(first.extent[:4]), np.asarray(second.extent[:4])
     x0, x1 = max(fa[0], fb[0]), min(fa[1], fb[1])

@@ -138,46 +138,64 @@ class _BaseImage(BaseClass):
             cut = img[k]
         return edges, ([cut] if cut.ndim == 1 else [cut[:, c] for c in range(cut.shape[1])])
 
+    def _check_pixels(self, px: np.ndarray) -> None:
+        """Shape and value range of the pixel array; the image classes differ in this only."""
+        raise NotImplementedError
+
     def __setattr__(self, key, val):
         if key == "_data":
             check_type(key, val, np.ndarray)
             val = np.asarray_chkfinite(val, dtype=np.float64)
-            if self._channels == 3 and (val.ndim != 3 or val.shape[2] != 3):
-                raise TypeError("Image data needs to have three dimensions with three channels")
-            if self._channels == 1 and val.ndim != 2:
-                raise TypeError("Image data needs to have two dimensions")
-            if val.min() < 0 or val.max() > 1:
-                raise ValueError("Image values need to be inside range [0, 1]")
+            self._check_pixels(val)
         elif key == "extent":
-            check_type(key, val, (list, np.ndarray))
+            check_type(key, val, (list, tuple, np.ndarray))
             val = np.asarray_chkfinite(val, dtype=np.float64)
-            if val.shape[0] != 4 or val[0] >= val[1] or val[2] >= val[3]:
-                raise ValueError("extent needs to be [x0, x1, y0, y1] with x1 > x0, y1 > y0")
+            if val.shape[0] != 4:
+                raise ValueError("Extent needs to have 4 elements.")
+            if val[0] > val[1] or val[2] > val[3]:   # (equal bounds pass here, as in base_image.py:203)
+                raise ValueError("Extent needs to be an array with [x0, x1, y0, y1] with x0 < x1 and y0 < y1.")
         super().__setattr__(key, val)
+
+
+def _no_negative(px: np.ndarray, wanted: str) -> None:
+    low = px.min() if px.size else 0.0
+    if low < 0.0:
+        raise ValueError(f"There is a negative value of {low} inside the image. Make sure all image data is {wanted}.")
+
+
+def _at_most_one(px: np.ndarray) -> None:
+    high = px.max() if px.size else 0.0
+    if high > 1.0:
+        raise ValueError(f"There is a value of {high} inside the image. Make sure all image data is in the range [0, 1].")
 
 
 class RGBImage(_BaseImage):
     """sRGB image with values in [0, 1] (rgb_image.py:12-75)."""
     _channels = 3
 
-
-class GrayscaleImage(_BaseImage):
-    """sRGB-gamma grayscale image with values in [0, 1] (grayscale_image.py:10-60)."""
-    _channels = 1
+    def _check_pixels(self, px):
+        if px.ndim != 3 or px.shape[2] != 3:
+            raise ValueError("Image needs to have three dimensions with 3 elements (RGB) in the third dimension, "
+                             f"but has shape {px.shape}.")
+        _no_negative(px, "in the range [0, 1]")
+        _at_most_one(px)
 
 
 class ScalarImage(_BaseImage):
     """Single-channel image of a physical quantity, non-negative (scalar_image.py:9-60)."""
     _channels = 1
 
-    def __setattr__(self, key, val):
-        if key == "_data":
-            check_type(key, val, np.ndarray)
-            val = np.asarray_chkfinite(val, dtype=np.float64)
-            if val.ndim != 2:
-                raise ValueError(f"Image needs to have two dimensions but has shape {val.shape}.")
-            if val.size and val.min() < 0:
-                raise ValueError("There is an negative value inside the image")
-            BaseClass.__setattr__(self, key, val)
-            return
-        super().__setattr__(key, val)
+    def _check_pixels(self, px):
+        if px.ndim == 3:
+            raise ValueError("Image can't have color information. Either use a RGBImage or remove color information.")
+        if px.ndim != 2:
+            raise ValueError(f"Image needs to have two dimensions but has shape {px.shape}.")
+        _no_negative(px, "non-negative")
+
+
+class GrayscaleImage(ScalarImage):
+    """sRGB-gamma grayscale image with values in [0, 1] (grayscale_image.py:10-60)."""
+
+    def _check_pixels(self, px):
+        _at_most_one(px)
+        ScalarImage._check_pixels(self, px)

@@ -173,5 +173,177 @@ def spectrum_cases(ot) -> dict:
     return out
 
 
+
+
+def _checks(RT):
+    f = getattr(RT, "_geometry_checks", None) or getattr(RT, "_Raytracer__geometry_checks")
+    f()
+    return float(bool(RT.geometry_error))
+
+
+def geometry_cases(ot) -> dict:
+    """Raytracer geometry checks (raytracer.py:510-580) and Raytracer.check_collision (:581-664) on legal and illegal
+    arrangements: the flag, and for collisions their number and lowest / highest point."""
+    out = {}
+    n = ot.RefractionIndex("Constant", n=1.5)
+
+    def tracer(**kw):
+        return ot.Raytracer(outline=kw.pop("outline", [-5, 5, -5, 5, -10, 40]), **kw)
+
+    def src(RT, z=-5., **kw):
+        RT.add(ot.RaySource(ot.CircularSurface(r=1), pos=[0, 0, z], **kw))
+
+    def lens(z, r=3, R1=10, R2=-10, **kw):
+        return ot.Lens(ot.SphericalSurface(r=r, R=R1), ot.SphericalSurface(r=r, R=R2), pos=[0, 0, z], n=n,
+                       **(kw or dict(de=0.2)))
+
+    with ot.global_options.no_warnings():
+        RT = tracer(); src(RT); RT.add(lens(5)); RT.add(lens(15))
+        out["geom/ok"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT); RT.add(lens(5)); RT.add(lens(5.6))          # second lens starts inside the first
+        out["geom/lenses_collide"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT); RT.add(lens(5, r=3)); RT.add(lens(5.9, r=3, R1=-10, R2=-12))   # nested menisci, close
+        out["geom/close_menisci"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT); RT.add(ot.Lens(ot.SphericalSurface(r=3, R=10), ot.SphericalSurface(r=3, R=-10), de=0.2,
+                                                pos=[3.5, 0, 5], n=n))      # sticks out of the outline in x
+        out["geom/outside_outline"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT, z=6.); RT.add(lens(5))                        # source behind the lens front
+        out["geom/source_in_lens"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT, z=20.); RT.add(lens(5))                       # source behind every lens
+        out["geom/source_behind"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT); RT.add(lens(5)); RT.add(ot.Aperture(ot.RingSurface(r=3, ri=1), pos=[0, 0, 5.3]))
+        out["geom/aperture_in_lens"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT); RT.add(lens(5)); RT.add(ot.Aperture(ot.RingSurface(r=3, ri=1), pos=[0, 0, 9.]))
+        out["geom/aperture_ok"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT); RT.add(lens(5)); RT.add(ot.Detector(ot.RectangularSurface(dim=[30, 30]), pos=[0, 0, 50]))
+        out["geom/detector_outside_is_fine"] = np.array([_checks(RT)])
+        RT = tracer(); RT.add(lens(5))
+        out["geom/no_source"] = np.array([_checks(RT)])
+        RT = tracer(); src(RT); RT.add(lens(5)); RT.add(ot.Filter(ot.CircularSurface(r=2), pos=[0, 0, 45.],
+                                                                  spectrum=ot.TransmissionSpectrum("Constant", val=1.)))
+        out["geom/filter_outside"] = np.array([_checks(RT)])
+
+        pairs = {
+            "spheres_apart": (ot.SphericalSurface(r=3, R=10), [0, 0, 0], ot.SphericalSurface(r=3, R=-10), [0, 0, 2]),
+            "spheres_cross": (ot.SphericalSurface(r=3, R=-10), [0, 0, 0], ot.SphericalSurface(r=3, R=10), [0, 0, 0.5]),
+            "shifted": (ot.ConicSurface(r=3, R=8, k=-1), [0, 0, 0], ot.CircularSurface(r=2), [1.5, 1, 0.3]),
+            "tilted_flat": (ot.TiltedSurface(r=2, normal=[0.3, 0, 1]), [0, 0, 0], ot.CircularSurface(r=2), [0, 0, 0.2]),
+            "rect_ring": (ot.RectangularSurface(dim=[2, 2]), [0, 0, 1.], ot.RingSurface(r=3, ri=0.5), [0, 0, 0.9]),
+            "point_front": (ot.Point(), [0.5, 0, 1.], ot.SphericalSurface(r=3, R=10), [0, 0, 0.5]),
+            "line_back": (ot.SphericalSurface(r=3, R=-10), [0, 0, 0.2], ot.Line(r=2, angle=30), [0, 0, 0.0]),
+        }
+        for name, (a, pa, b, pb) in pairs.items():
+            a.move_to(pa)
+            b.move_to(pb)
+            hit, x, y, z = ot.Raytracer.check_collision(a, b)
+            x, y, z = np.asarray(x), np.asarray(y), np.asarray(z)
+            stats = [float(bool(hit)), float(x.shape[0])]
+            stats += [float(z.min()), float(z.max()), float(x.min()), float(x.max())] if x.shape[0] else [0.] * 4
+            out[f"collision/{name}"] = np.array(stats)
+    return out
+
+
 def all_cases(ot) -> dict:
-    return {**surface_cases(ot), **element_cases(ot), **spectrum_cases(ot)}
+    return {**surface_cases(ot), **element_cases(ot), **spectrum_cases(ot), **geometry_cases(ot), **error_cases(ot)}
+
+
+def error_cases(ot) -> dict:
+    """What invalid arguments raise: the exception class name (or "ok") per case, as a string array."""
+    n = ot.RefractionIndex("Constant", n=1.5)
+    sph = lambda: ot.SphericalSurface(r=2, R=10)  # noqa: E731
+    wls = np.linspace(400., 700., 31)
+    cases = {
+        "circle_r_neg": lambda: ot.CircularSurface(r=-1),
+        "circle_r_str": lambda: ot.CircularSurface(r="1"),
+        "circle_r_zero": lambda: ot.CircularSurface(r=0),
+        "ring_ri_large": lambda: ot.RingSurface(r=1, ri=1.5),
+        "ring_ri_zero": lambda: ot.RingSurface(r=1, ri=0),
+        "rect_dim_neg": lambda: ot.RectangularSurface(dim=[1, -1]),
+        "rect_dim_len": lambda: ot.RectangularSurface(dim=[1, 2, 3]),
+        "slit_inner_large": lambda: ot.SlitSurface(dim=[1, 1], dimi=[2, 0.5]),
+        "conic_R_zero": lambda: ot.ConicSurface(r=1, R=0, k=0),
+        "conic_R_inf": lambda: ot.ConicSurface(r=1, R=np.inf, k=0),
+        "conic_r_too_large": lambda: ot.ConicSurface(r=5, R=4, k=0.5),
+        "sphere_r_gt_R": lambda: ot.SphericalSurface(r=3, R=2),
+        "asphere_no_coeff": lambda: ot.AsphericSurface(r=1, R=10, k=0, coeff=[]),
+        "asphere_coeff_type": lambda: ot.AsphericSurface(r=1, R=10, k=0, coeff=3),
+        "tilted_none": lambda: ot.TiltedSurface(r=1),
+        "tilted_nz_neg": lambda: ot.TiltedSurface(r=1, normal=[0, 1, -0.5]),
+        "data2d_small": lambda: ot.DataSurface2D(r=1, data=np.zeros((10, 10))),
+        "data2d_not_square": lambda: ot.DataSurface2D(r=1, data=np.zeros((60, 80))),
+        "data1d_2d": lambda: ot.DataSurface1D(r=1, data=np.zeros((60, 60))),
+        "func_not_callable": lambda: ot.FunctionSurface2D(r=1, func=2),
+        "func_zmin_only": lambda: ot.FunctionSurface1D(r=1, func=lambda r: r * 0.1, z_min=0.),
+        "line_r_neg": lambda: ot.Line(r=-1),
+        "surface_move_bad": lambda: sph().move_to([1, 2]),
+        "surface_locked": lambda: setattr(sph(), "r", 3),
+        "lens_no_thickness": lambda: ot.Lens(sph(), sph(), pos=[0, 0, 0], n=n),
+        "lens_d_and_de": lambda: ot.Lens(sph(), sph(), d=1, de=1, pos=[0, 0, 0], n=n),
+        "lens_n_type": lambda: ot.Lens(sph(), sph(), de=1, pos=[0, 0, 0], n=1.5),
+        "lens_pos_len": lambda: ot.Lens(sph(), sph(), de=1, pos=[0, 0], n=n),
+        "lens_d1_neg": lambda: ot.Lens(sph(), sph(), d1=-1, d2=1, pos=[0, 0, 0], n=n),
+        "filter_spectrum_type": lambda: ot.Filter(ot.CircularSurface(r=1), pos=[0, 0, 0], spectrum=ot.LightSpectrum("Constant")),
+        "detector_asphere": lambda: ot.Detector(ot.AsphericSurface(r=1, R=10, k=0, coeff=[1e-3]), pos=[0, 0, 0]),
+        "ideal_D_zero": lambda: ot.IdealLens(r=1, D=0, pos=[0, 0, 0]),
+        "ideal_D_str": lambda: ot.IdealLens(r=1, D="5", pos=[0, 0, 0]),
+        "source_div_name": lambda: ot.RaySource(ot.Point(), divergence="Cone"),
+        "source_power_neg": lambda: ot.RaySource(ot.Point(), power=-1),
+        "source_div_angle_zero": lambda: ot.RaySource(ot.Point(), div_angle=0),
+        "source_s_back": lambda: ot.RaySource(ot.Point(), s=[0, 0, -1]),
+        "source_s_len": lambda: ot.RaySource(ot.Point(), s=[0, 1]),
+        "source_surface_sphere": lambda: ot.RaySource(sph()),
+        "source_slit": lambda: ot.RaySource(ot.SlitSurface(dim=[1, 1], dimi=[0.1, 0.1])),
+        "source_spectrum_type": lambda: ot.RaySource(ot.Point(), spectrum=ot.TransmissionSpectrum("Constant", val=1.)),
+        "source_pol_name": lambda: ot.RaySource(ot.Point(), polarization="z"),
+        "source_or_func": lambda: ot.RaySource(ot.Point(), orientation="Function", or_func=3),
+        "source_black_image": lambda: ot.RaySource(ot.RGBImage(np.zeros((10, 10, 3)), [1, 1])),
+        "spec_type": lambda: ot.LightSpectrum("Sawtooth"),
+        "spec_wl_range": lambda: ot.LightSpectrum("Monochromatic", wl=100.),
+        "spec_val_neg": lambda: ot.LightSpectrum("Constant", val=-1.),
+        "spec_sig_zero": lambda: ot.LightSpectrum("Gaussian", sig=0.),
+        "spec_lines_dup": lambda: ot.LightSpectrum("Lines", lines=[500., 500.], line_vals=[1, 1]),
+        "spec_lines_empty": lambda: ot.LightSpectrum("Lines", lines=[], line_vals=[]),
+        "spec_line_vals_neg": lambda: ot.LightSpectrum("Lines", lines=[500., 600.], line_vals=[1, -1]),
+        "spec_wls_uneven": lambda: ot.LightSpectrum("Data", wls=[400., 500., 700.], vals=[1, 1, 1]),
+        "spec_vals_neg": lambda: ot.LightSpectrum("Data", wls=wls, vals=-np.ones(31)),
+        "spec_func_neg": lambda: ot.LightSpectrum("Function", func=lambda x: -x),
+        "spec_T_zero": lambda: ot.LightSpectrum("Blackbody", T=0.),
+        "spec_call_lines": lambda: ot.LightSpectrum("Lines", lines=[500., 600.], line_vals=[1, 1])(np.array([500.])),
+        "trans_val_gt1": lambda: ot.TransmissionSpectrum("Constant", val=1.5),
+        "trans_vals_gt1": lambda: ot.TransmissionSpectrum("Data", wls=wls, vals=2 * np.ones(31)),
+        "trans_type": lambda: ot.TransmissionSpectrum("Lines"),
+        "trans_inverse_type": lambda: ot.TransmissionSpectrum("Constant", val=0.5, inverse=1),
+        "index_n_below1": lambda: ot.RefractionIndex("Constant", n=0.9),
+        "index_type": lambda: ot.RefractionIndex("Glass"),
+        "index_coeff_count": lambda: ot.RefractionIndex("Cauchy", coeff=[1.5, 0.01]),
+        "index_coeff_type": lambda: ot.RefractionIndex("Cauchy", coeff=(1.5, 0.01, 0, 0)),
+        "index_V_neg": lambda: ot.RefractionIndex("Abbe", n=1.5, V=-10),
+        "index_lines_order": lambda: ot.RefractionIndex("Abbe", n=1.5, V=50, lines=[600., 500., 700.]),
+        "index_lines_count": lambda: ot.RefractionIndex("Abbe", n=1.5, V=50, lines=[500., 600.]),
+        "index_vals_below1": lambda: ot.RefractionIndex("Data", wls=wls, vals=0.5 * np.ones(31)),
+        "index_func_below1": lambda: ot.RefractionIndex("Function", func=lambda x: 0.9 + 0 * x),
+        "tracer_outline_order": lambda: ot.Raytracer(outline=[1, -1, -1, 1, 0, 10]),
+        "tracer_outline_len": lambda: ot.Raytracer(outline=[-1, 1, -1, 1]),
+        "tracer_n0_type": lambda: ot.Raytracer(outline=[-1, 1, -1, 1, 0, 10], n0=1.0),
+        "tracer_add_bad": lambda: ot.Raytracer(outline=[-1, 1, -1, 1, 0, 10]).add(5),
+        "group_add_surface": lambda: ot.Group().add(sph()),
+        "image_range": lambda: ot.RGBImage(2 * np.ones((5, 5, 3)), [1, 1]),
+        "image_no_size": lambda: ot.RGBImage(np.ones((5, 5, 3))),
+        "image_shape": lambda: ot.RGBImage(np.ones((5, 5)), [1, 1]),
+        "gray_shape": lambda: ot.GrayscaleImage(np.ones((5, 5, 3)), [1, 1]),
+        "image_s_neg": lambda: ot.GrayscaleImage(np.ones((5, 5)), [1, -1]),
+        "render_extent": lambda: ot.RenderImage([1, 0, 0, 1]),
+        "options_bool": lambda: setattr(ot.global_options, "show_warnings", 1),
+        "options_range": lambda: setattr(ot.global_options, "wavelength_range", [400., 700.]),
+    }
+    names, res = [], []
+    with ot.global_options.no_warnings():
+        for name, f in cases.items():
+            try:
+                f()
+                r = "ok"
+            except Exception as e:  # noqa: BLE001 - the class is the result
+                r = type(e).__name__
+            names.append(name)
+            res.append(r)
+    return {"errors/names": np.array(names), "errors/raised": np.array(res)}
