@@ -169,6 +169,12 @@ def spectrum_cases(ot) -> dict:
         }
         for name, sp in trans.items():
             out[f"trans/{name}"] = np.asarray(sp(wl), dtype=np.float64)
+        for name in ("a", "c", "d50", "d55", "d65", "d75", "f2", "f7", "f11", "led_b1", "led_b2", "led_b3", "led_b4", "led_b5",
+                     "led_bh1", "led_rgb1", "led_v1", "led_v2"):
+            out[f"light/preset_{name}"] = np.asarray(getattr(ot.presets.light_spectrum, name)(wl), dtype=np.float64)
+        sl = ot.presets.spectral_lines
+        out["light/spectral_lines"] = np.array([sl.h, sl.g, sl.F_, sl.F, sl.e, sl.d, sl.D, sl.C_, sl.C, sl.r, sl.A_,
+                                                *sl.FDC, *sl.FdC, *sl.FeC, *sl.F_eC_, *sl.rgb], dtype=np.float64)
         out["light/desc_lengths"] = np.array([len(light["constant"].get_desc()), len(light["gauss"].get_desc())], dtype=np.float64)
     return out
 
