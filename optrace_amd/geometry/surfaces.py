@@ -249,6 +249,11 @@ class RingSurface(Surface):
             raise ValueError("ri needs to be smaller than r.")
         self.lock()
 
+    @property
+    def info(self) -> str:
+        """(The reference's string ends in the unformatted text "{self.ri:.5g} mm", ring_surface.py:52; the value here.)"""
+        return f"{Surface.info.fget(self)}, ri = {self.ri:.5g} mm"
+
     def _mask_host(self, x, y):
         rr = (x - self.pos[0]) ** 2 + (y - self.pos[1]) ** 2
         return (rr >= (self.ri - self.N_EPS) ** 2) & Surface._mask_host(self, x, y)

@@ -250,7 +250,8 @@ def geometry_cases(ot) -> dict:
 
 
 def all_cases(ot) -> dict:
-    return {**surface_cases(ot), **element_cases(ot), **spectrum_cases(ot), **geometry_cases(ot), **error_cases(ot)}
+    return {**surface_cases(ot), **element_cases(ot), **spectrum_cases(ot), **geometry_cases(ot), **error_cases(ot),
+            **container_cases(ot)}
 
 
 def error_cases(ot) -> dict:
@@ -353,3 +354,59 @@ def error_cases(ot) -> dict:
             names.append(name)
             res.append(r)
     return {"errors/names": np.array(names), "errors/raised": np.array(res)}
+
+
+def _image_grid(ot, extent, limit):
+    """Extent and pixel counts a RenderImage settles on for a given hit extent (render_image.py:224-255, 383-387)."""
+    img = ot.RenderImage(extent)
+    if hasattr(img, "_pixel_counts"):   # optrace_amd: the grid is host logic, the binning itself a device call
+        img._limit = limit
+        img._fix_extent()
+        nx, ny = img._pixel_counts()
+    else:                               # the reference: render an empty hit list
+        img.render(np.zeros((0, 3)), np.zeros(0), np.zeros(0), limit=limit, _dont_filter=True)
+        ny, nx = img._data.shape[:2]
+    return np.array([*img.extent, nx, ny, *img.s], dtype=np.float64)
+
+
+def container_cases(ot) -> dict:
+    """Order and bookkeeping of Raytracer / Group containers, description strings, RenderImage grids."""
+    out = {}
+    n = ot.RefractionIndex("Constant", n=1.5)
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-6, 6, -6, 6, -10, 60])
+        mk = lambda z, **kw: ot.Lens(ot.SphericalSurface(r=2, R=9), ot.SphericalSurface(r=2, R=-9), de=0.2, pos=[0, 0, z], n=n, **kw)  # noqa: E731
+        L30, L10, L20 = mk(30., desc="far"), mk(10.), mk(20., long_desc="the middle lens")
+        ap = ot.Aperture(ot.RingSurface(r=2, ri=0.5), pos=[0, 0, 15.])
+        flt = ot.Filter(ot.CircularSurface(r=2), pos=[0, 0, 25.], spectrum=ot.TransmissionSpectrum("Constant", val=0.5))
+        det2, det1 = ot.Detector(ot.RectangularSurface(dim=[4, 4]), pos=[0, 0, 50.]), ot.Detector(ot.CircularSurface(r=3), pos=[0, 0, 40.])
+        src = ot.RaySource(ot.CircularSurface(r=1), pos=[0, 0, -5.], desc="lamp")
+        RT.add([L30, ap, det2, L10])
+        RT.add(flt)
+        RT.add(ot.Group([L20, det1, src]))
+        out["cont/lens_z"] = np.array([L.pos[2] for L in RT.lenses], dtype=np.float64)
+        out["cont/detector_z"] = np.array([d.pos[2] for d in RT.detectors], dtype=np.float64)
+        out["cont/surface_z"] = np.array([s.pos[2] for s in RT.tracing_surfaces], dtype=np.float64)
+        out["cont/counts"] = np.array([len(RT.lenses), len(RT.apertures), len(RT.filters), len(RT.detectors),
+                                       len(RT.ray_sources), len(RT.elements)], dtype=np.float64)
+        out["cont/extent"] = np.array(RT.extent, dtype=np.float64)
+        out["cont/pos"] = np.array(RT.pos, dtype=np.float64)
+        out["cont/has"] = np.array([RT.has(L10), RT.has(mk(1.))], dtype=np.float64)
+        removed = [RT.remove(L10), RT.remove(L10), RT.remove([ap, flt])]
+        out["cont/removed"] = np.array([float(bool(r)) for r in removed] + [len(RT.elements)], dtype=np.float64)
+        RT.clear()
+        out["cont/cleared"] = np.array([len(RT.elements)], dtype=np.float64)
+        texts = [L30.get_desc(), L30.get_long_desc(), L20.get_desc("fallback"), L20.get_long_desc(), L10.get_long_desc("fb"),
+                 src.get_desc(), ot.LightSpectrum("Constant", val=0.25).get_desc(), ot.LightSpectrum("Gaussian").get_desc(),
+                 ot.presets.light_spectrum.d65.get_long_desc(), ot.RefractionIndex("Abbe", n=1.5, V=50, desc="nX").get_desc(),
+                 ot.CircularSurface(r=1).info, ot.RectangularSurface(dim=[2, 1]).info, ot.TiltedSurface(r=1, normal=[0, 0.2, 1]).info,
+                 ot.ConicSurface(r=1, R=5, k=-1).info, ot.SphericalSurface(r=1, R=5).info,
+                 ot.AsphericSurface(r=1, R=5, k=0, coeff=[1e-3]).info]   # (not RingSurface.info: unformatted in the reference)
+        out["cont/texts"] = np.array(texts)
+        for name, (ext, limit) in {"point": ([0.5, 0.5, -1, -1], None), "line_x": ([-1, 1, 0.25, 0.25], None),
+                                   "line_y": ([2, 2, -3, 1], None), "ratio_10": ([-1, 1, -0.1, 0.1], None),
+                                   "ratio_2": ([-1, 1, -0.5, 0.5], None), "ratio_4_tall": ([0, 1, 0, 4], None),
+                                   "square_limit": ([-1, 1, -1, 1], 5.0), "point_limit": ([0, 0, 0, 0], 2.0),
+                                   "tiny": ([0, 1e-12, 0, 5e-13], None)}.items():
+            out[f"cont/grid_{name}"] = _image_grid(ot, ext, limit)
+    return out
