@@ -21,6 +21,14 @@ from ..image import RGBImage, GrayscaleImage, srgb_to_srgb_linear, power_from_sr
 d65_spectrum = LightSpectrum("Function", func=d65_illuminant, desc="D65", long_desc="Illuminant D65")
 
 
+def _usable_pdf(f: np.ndarray) -> None:
+    """What random.inverse_transform_sampling demands of a density before it samples from it (random.py:129-133)."""
+    if not f.sum():
+        raise RuntimeError("Cumulated probability is zero.")
+    if f.min() < 0:
+        raise RuntimeError("Got negative value in pdf.")
+
+
 class RaySource(Element):
 
     divergences = ["None", "Lambertian", "Isotropic", "Function"]
@@ -135,6 +143,7 @@ class RaySource(Element):
             pdf = np.asarray(self.div_func(x, **self.div_args), dtype=np.float64)
             if not self.div_2d:
                 pdf = pdf * np.sin(x)
+            _usable_pdf(pdf)
             F = np.concatenate(([0.], np.cumsum((pdf[1:] + pdf[:-1]) / 2)))
             f["divergence"] = _capi.DIV_TABLE
             f["div_tab"] = np.concatenate((x, F))
@@ -154,6 +163,7 @@ class RaySource(Element):
                 check_type("RaySource.pol_angles", self.pol_angles, (np.ndarray, list))
                 probs = np.ones_like(self.pol_angles) if self.pol_probs is None else np.asarray(self.pol_probs)
                 ang = np.radians(self.pol_angles)
+            _usable_pdf(np.asarray(probs, dtype=np.float64))
             keep = probs > 0
             f["polarization"] = _capi.POL_LIST
             f["pol_tab"] = np.concatenate((np.asarray(ang, dtype=np.float64)[keep], np.cumsum(probs[keep])))
@@ -163,6 +173,7 @@ class RaySource(Element):
                 raise TypeError("RaySource.pol_func needs to be callable")
             x = np.linspace(0, 2 * np.pi, 5000)
             pdf = np.asarray(self.pol_func(x, **self.pol_args), dtype=np.float64)
+            _usable_pdf(pdf)
             F = np.concatenate(([0.], np.cumsum((pdf[1:] + pdf[:-1]) / 2)))
             f["polarization"] = _capi.POL_TABLE
             # the reference converts the sampled angle with np.radians once more (ray_source.py:392)

@@ -307,6 +307,13 @@ class LightSpectrum(Spectrum):
                     n_spec=len(x))
 
     def __setattr__(self, key, val):
+        if key == "_vals" and val is not None and self.spectrum_type != "Histogram":
+            # a user's data spectrum: no negative values and not zero throughout (light_spectrum.py:418-426)
+            given = np.asarray_chkfinite(val, dtype=np.float64)
+            if (given < 0).any():
+                raise ValueError("Values below zero in LightSpectrum.")
+            if not (given > 0).any():
+                raise ValueError("LightSpectrum can't be constantly zero.")
         super().__setattr__(key, _above_zero(key, val) if key == "T" else val)
 
 

@@ -343,6 +343,30 @@ def error_cases(ot) -> dict:
         "options_bool": lambda: setattr(ot.global_options, "show_warnings", 1),
         "options_range": lambda: setattr(ot.global_options, "wavelength_range", [400., 700.]),
     }
+    def emit(**kw):
+        """What happens when a source with these options has to produce rays: RaySource.create_rays in the reference, the
+        host half of it (the source descriptor, where the same checks live) in optrace_amd."""
+        rs = ot.RaySource(kw.pop("surface", None) or ot.CircularSurface(r=1), pos=[0, 0, 0], **kw)
+        return rs._source_fields() if hasattr(rs, "_source_fields") else rs.create_rays(2000)
+
+    flat = np.linspace(400., 700., 31)
+    cases.update({
+        "emit_ok": lambda: emit(),
+        "emit_div_func_missing": lambda: emit(divergence="Function"),
+        "emit_div_func_negative": lambda: emit(divergence="Function", div_func=lambda e: -1 + 0 * e),
+        "emit_div_func_zero": lambda: emit(divergence="Function", div_func=lambda e: 0 * e),
+        "emit_or_func_missing": lambda: emit(orientation="Function"),
+        "emit_pol_func_missing": lambda: emit(polarization="Function"),
+        "emit_pol_list_missing": lambda: emit(polarization="List"),
+        "emit_pol_list_probs_missing": lambda: emit(polarization="List", pol_angles=[0., 45.]),
+        "emit_pol_list_lengths": lambda: emit(polarization="List", pol_angles=[0., 45.], pol_probs=[1.]),
+        "emit_pol_list_zero": lambda: emit(polarization="List", pol_angles=[0., 45.], pol_probs=[0., 0.]),
+        "emit_pol_list_ok": lambda: emit(polarization="List", pol_angles=[0., 45.], pol_probs=[1., 3.]),
+        "emit_lines_zero": lambda: emit(spectrum=ot.LightSpectrum("Lines", lines=[500., 600.], line_vals=[0., 0.])),
+        "emit_data_zero": lambda: emit(spectrum=ot.LightSpectrum("Data", wls=flat, vals=np.zeros(31))),
+        "emit_lambertian_2d": lambda: emit(divergence="Lambertian", div_angle=30., div_2d=True, div_axis_angle=10.),
+        "emit_image": lambda: emit(surface=ot.RGBImage(np.full((4, 4, 3), 0.5), [1, 1])),
+    })
     names, res = [], []
     with ot.global_options.no_warnings():
         for name, f in cases.items():
