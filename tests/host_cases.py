@@ -367,6 +367,36 @@ def error_cases(ot) -> dict:
         "emit_lambertian_2d": lambda: emit(divergence="Lambertian", div_angle=30., div_2d=True, div_axis_angle=10.),
         "emit_image": lambda: emit(surface=ot.RGBImage(np.full((4, 4, 3), 0.5), [1, 1])),
     })
+    def rt(sources=True, detector=True, lens=True):
+        RT = ot.Raytracer(outline=[-5, 5, -5, 5, -10, 40])
+        if sources:
+            RT.add(ot.RaySource(ot.CircularSurface(r=1), pos=[0, 0, -5]))
+        if lens:
+            RT.add(ot.Lens(sph(), ot.SphericalSurface(r=2, R=-10), de=0.2, pos=[0, 0, 5], n=n))
+        if detector:
+            RT.add(ot.Detector(ot.RectangularSurface(dim=[4, 4]), pos=[0, 0, 30]))
+        return RT
+
+    cases.update({   # a tracer that has not traced yet: every refusal comes before any ray exists
+        "rt_trace_no_source": lambda: rt(sources=False).trace(1000),
+        "rt_trace_N_zero": lambda: rt().trace(0),
+        "rt_trace_N_float": lambda: rt().trace(1000.5),
+        "rt_image_untraced": lambda: rt().detector_image(),
+        "rt_image_no_detector": lambda: rt(detector=False).detector_image(),
+        "rt_spectrum_untraced": lambda: rt().detector_spectrum(),
+        "rt_source_image_untraced": lambda: rt().source_image(),
+        "rt_source_spectrum_no_source": lambda: rt(sources=False).source_spectrum(),
+        "rt_focus_untraced": lambda: rt().focus_search("RMS Spot Size", 10.),
+        "rt_focus_method": lambda: rt().focus_search("Sharpest", 10.),
+        "rt_focus_outside": lambda: rt().focus_search("RMS Spot Size", 100.),
+        "rt_iter_N_zero": lambda: rt().iterative_render(0),
+        "rt_iter_no_detector": lambda: rt(detector=False).iterative_render(10000),
+        "rt_iter_no_source": lambda: rt(sources=False).iterative_render(10000),
+        "rt_iter_index_list": lambda: rt().iterative_render(10000, detector_index=[0, 0]),
+        "rt_iter_extent_len": lambda: rt().iterative_render(10000, pos=[[0, 0, 30], [0, 0, 32]], extent=[None]),
+        "rt_remove_missing": lambda: rt().remove(ot.Detector(ot.CircularSurface(r=1), pos=[0, 0, 1])),
+        "rt_current_untraced": lambda: rt().check_if_rays_are_current(),
+    })
     names, res = [], []
     with ot.global_options.no_warnings():
         for name, f in cases.items():
