@@ -463,4 +463,16 @@ def container_cases(ot) -> dict:
                                    "square_limit": ([-1, 1, -1, 1], 5.0), "point_limit": ([0, 0, 0, 0], 2.0),
                                    "tiny": ([0, 1e-12, 0, 5e-13], None)}.items():
             out[f"cont/grid_{name}"] = _image_grid(ot, ext, limit)
+        # cuts through images (base_image.py:149-186) and their pixel bookkeeping
+        rng = np.random.default_rng(5)
+        rgb = ot.RGBImage(rng.uniform(0, 1, (7, 11, 3)), extent=[-1.1, 3.3, 0.5, 2.6])
+        gray = ot.GrayscaleImage(rng.uniform(0, 1, (9, 5)), [2.5, 4.5])
+        for name, img in (("rgb", rgb), ("gray", gray)):
+            x0, x1, y0, y1 = img.extent
+            for k, (kw, tag) in enumerate([(dict(x=x0), "x_lo"), (dict(x=x1), "x_hi"), (dict(x=(x0 + x1) / 2 + 0.01), "x_mid"),
+                                           (dict(y=y0), "y_lo"), (dict(y=y1), "y_hi"), (dict(y=y0 + 0.3 * (y1 - y0)), "y_in")]):
+                edges, cuts = img.profile(**kw)
+                out[f"cont/profile_{name}_{tag}"] = np.concatenate([np.asarray(edges, dtype=np.float64)] +
+                                                                   [np.asarray(c, dtype=np.float64) for c in cuts])
+            out[f"cont/image_{name}"] = np.array([*img.s, img.Apx, *img.shape[:2], *img.extent], dtype=np.float64)
     return out
