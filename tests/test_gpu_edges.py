@@ -630,6 +630,11 @@ def test_padded_plane_stride_equals_packed_storage(monkeypatch):
                     RH.rays.w_list[:, 0].copy(), RH.rays.wl_list.copy())
             RH.trace(N, _initial_rays=init, _hurb_normals=hn, _N_list=RH.rays.N_list)
             out["hurb_p"], out["hurb_w"], out["hurb_msgs"] = RH.rays.p_list.copy(), RH.rays.w_list.copy(), RH._msgs.copy()
+            # chunked rendering with odd chunk sizes (two chunks of 1 100 003 and 1 899 998 rays), fused and hit-list paths
+            RI = scenes.double_gauss(ot, seed=23)
+            RI.ITER_RAYS_STEP = 1_100_003
+            imgs = RI.iterative_render(3_000_001, pos=[[0, 0, 160.], [0, 0, 170.]], extent=[[-40., 40., -40., 40.], None])
+            out["img_iter0"], out["img_iter1"] = imgs[0]._data.copy(), imgs[1]._data.copy()
         return out
 
     def _dirs(p):
