@@ -132,6 +132,7 @@ class Raytracer(Group):
         """The tracing snapshot plus the detectors (they matter to images, not to the rays)."""
         snap = self.tracing_snapshot()
         snap["Detectors"] = [det.crepr() for det in self.detectors]
+        snap["Markers"], snap["Volumes"] = [], []  # plot-only elements of the reference: none here, the keys for its callers
         return snap
 
     def compare_property_snapshot(self, h1: dict, h2: dict) -> dict:

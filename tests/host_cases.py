@@ -251,7 +251,7 @@ def geometry_cases(ot) -> dict:
 
 def all_cases(ot) -> dict:
     return {**surface_cases(ot), **element_cases(ot), **spectrum_cases(ot), **geometry_cases(ot), **error_cases(ot),
-            **container_cases(ot)}
+            **container_cases(ot), **snapshot_cases(ot)}
 
 
 def error_cases(ot) -> dict:
@@ -475,4 +475,46 @@ def container_cases(ot) -> dict:
                 out[f"cont/profile_{name}_{tag}"] = np.concatenate([np.asarray(edges, dtype=np.float64)] +
                                                                    [np.asarray(c, dtype=np.float64) for c in cuts])
             out[f"cont/image_{name}"] = np.array([*img.s, img.Apx, *img.shape[:2], *img.extent], dtype=np.float64)
+    return out
+
+
+def snapshot_cases(ot) -> dict:
+    """Raytracer.property_snapshot / compare_property_snapshot (raytracer.py:141-205): which groups of a scene count as
+    changed after an edit."""
+    out = {}
+    n = ot.RefractionIndex("Constant", n=1.5)
+
+    def scene():
+        RT = ot.Raytracer(outline=[-5, 5, -5, 5, -10, 60])
+        RT.add(ot.RaySource(ot.CircularSurface(r=1), pos=[0, 0, -5]))
+        RT.add(ot.Lens(ot.SphericalSurface(r=2, R=10), ot.SphericalSurface(r=2, R=-10), de=0.2, pos=[0, 0, 5], n=n))
+        RT.add(ot.Aperture(ot.RingSurface(r=2, ri=0.5), pos=[0, 0, 12]))
+        RT.add(ot.Filter(ot.CircularSurface(r=2), pos=[0, 0, 16], spectrum=ot.TransmissionSpectrum("Constant", val=0.5)))
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[4, 4]), pos=[0, 0, 30]))
+        return RT
+
+    edits = {
+        "nothing": lambda RT: None,
+        "move_lens": lambda RT: RT.lenses[0].move_to([0, 0, 6]),
+        "source_power": lambda RT: setattr(RT.ray_sources[0], "power", 2.0),
+        "source_spectrum": lambda RT: setattr(RT.ray_sources[0], "spectrum", ot.LightSpectrum("Constant")),
+        "add_detector": lambda RT: RT.add(ot.Detector(ot.CircularSurface(r=1), pos=[0, 0, 40])),
+        "move_detector": lambda RT: RT.detectors[0].move_to([0, 0, 31]),
+        "ambient": lambda RT: setattr(RT, "n0", ot.RefractionIndex("Constant", n=1.1)),
+        "lens_index": lambda RT: setattr(RT.lenses[0], "n", ot.RefractionIndex("Constant", n=1.6)),
+        "remove_aperture": lambda RT: RT.remove(RT.apertures[0]),
+        "filter_spectrum": lambda RT: setattr(RT.filters[0], "spectrum", ot.TransmissionSpectrum("Constant", val=0.6)),
+        "outline": lambda RT: setattr(RT, "outline", [-6, 6, -6, 6, -10, 60]),
+        "no_pol": lambda RT: setattr(RT, "no_pol", True),
+        "flip_lens": lambda RT: RT.lenses[0].flip(),
+    }
+    with ot.global_options.no_warnings():
+        for name, edit in edits.items():
+            RT = scene()
+            h1 = RT.property_snapshot()
+            edit(RT)
+            cmp = RT.compare_property_snapshot(h1, RT.property_snapshot())
+            keys = sorted(cmp)
+            out[f"snap/{name}_keys"] = np.array(keys)
+            out[f"snap/{name}"] = np.array([float(bool(cmp[k])) for k in keys])
     return out
