@@ -33,7 +33,9 @@ _FORMULAS = {
 class RefractionIndex(Spectrum):
 
     coeff_count = {name: count for name, (count, _) in _FORMULAS.items()}
-    n_types = sorted(["Abbe", "Constant", "Data", "Function", *_FORMULAS])
+    # the reference's order (refraction_index.py:22-26): alphabetical, with the two models added last at the end
+    n_types = sorted(["Abbe", "Constant", "Data", "Function", *(k for k in _FORMULAS if k not in ("Herzberger", "Schott"))]) \
+        + ["Herzberger", "Schott"]
     spectrum_types = n_types
     quantity = "Refraction Index n"
     unit = ""

@@ -251,7 +251,7 @@ def geometry_cases(ot) -> dict:
 
 def all_cases(ot) -> dict:
     return {**surface_cases(ot), **element_cases(ot), **spectrum_cases(ot), **geometry_cases(ot), **error_cases(ot),
-            **container_cases(ot), **snapshot_cases(ot)}
+            **container_cases(ot), **snapshot_cases(ot), **constant_cases(ot)}
 
 
 def error_cases(ot) -> dict:
@@ -517,4 +517,31 @@ def snapshot_cases(ot) -> dict:
             keys = sorted(cmp)
             out[f"snap/{name}_keys"] = np.array(keys)
             out[f"snap/{name}"] = np.array([float(bool(cmp[k])) for k in keys])
+    return out
+
+
+def constant_cases(ot) -> dict:
+    """Class constants and option lists users (and GUIs) read."""
+    S = ot.CircularSurface
+    out = {
+        "const/numbers": np.array([ot.Raytracer.N_EPS, ot.Raytracer.HURB_FACTOR, S.C_EPS, S.N_EPS, ot.RenderImage.EPS,
+                                   ot.RenderImage.K, ot.RenderImage.MAX_IMAGE_SIDE, ot.RenderImage.MAX_IMAGE_RATIO,
+                                   *ot.RenderImage.SIZES], dtype=np.float64),
+        "const/infos": np.array([f"{m.name}={int(m.value)}" for m in ot.Raytracer.INFOS]),
+        "const/focus_methods": np.array(ot.Raytracer.focus_search_methods),
+        "const/image_modes": np.array(ot.RenderImage.image_modes),
+        "const/source_options": np.array([*ot.RaySource.divergences, "|", *ot.RaySource.orientations, "|",
+                                          *ot.RaySource.polarizations]),
+        "const/abbr": np.array([getattr(ot, c).abbr for c in ("Lens", "Filter", "Aperture", "Detector", "IdealLens", "RaySource")]),
+        "const/spectrum_types": np.array([*ot.LightSpectrum.spectrum_types, "|", *ot.TransmissionSpectrum.spectrum_types]),
+        "const/n_types": np.array(ot.RefractionIndex.n_types),
+        "const/coeff_count": np.array([f"{k}={v}" for k, v in sorted(ot.RefractionIndex.coeff_count.items())]),
+        "const/projections": np.array(ot.SphericalSurface.sphere_projection_methods),
+        "const/rotational_symmetry": np.array([float(getattr(ot, c).rotational_symmetry) for c in (
+            "CircularSurface", "RingSurface", "RectangularSurface", "SlitSurface", "ConicSurface", "SphericalSurface",
+            "AsphericSurface", "TiltedSurface", "DataSurface1D", "DataSurface2D", "FunctionSurface1D", "FunctionSurface2D")]),
+    }
+    t, l = ot.TransmissionSpectrum("Constant", val=0.5), ot.LightSpectrum("Lines", lines=[500., 600.], line_vals=[1, 1])
+    c, r = ot.LightSpectrum("Constant"), ot.RefractionIndex("Constant", n=1.2)
+    out["const/units"] = np.array([t.unit, t.quantity, l.unit, l.quantity, c.unit, c.quantity, r.unit, r.quantity])
     return out
