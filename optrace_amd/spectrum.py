@@ -224,6 +224,101 @@ class LightSpectrum(Spectrum):
             return np.where(inside, heights[np.clip(bin_, 0, len(heights) - 1)], 0.)
         return super()._eval_host(wl)
 
+    # ---- figures of a spectrum (light_spectrum.py:232-400): host arithmetic on the spectrum's own description ----
+    _DENSE = 100000   # samples over the visible range where a figure has no closed form
+
+    def _dense(self):
+        grid = wavelengths(self._DENSE)
+        return grid, self._eval_host(grid)
+
+    def _integral(self, sensitivity) -> float:
+        """Integral of sensitivity(wl) * spectrum over the wavelength; sums for line spectra, bin sums for histograms."""
+        kind = self.spectrum_type
+        if kind == "Monochromatic":
+            return float(sensitivity(self.wl) * self.val)
+        if kind == "Lines":
+            return float(np.sum(sensitivity(self.lines) * self.line_vals))
+        if kind == "Histogram":
+            width = self._wls[1] - self._wls[0]
+            centres = self._wls[:-1] + width / 2
+            return float(np.sum(sensitivity(centres) * self._vals) * width)
+        grid, values = self._dense()
+        weighted = sensitivity(grid) * values
+        return float(np.sum((weighted[1:] + weighted[:-1]) / 2) * (grid[1] - grid[0]))
+
+    def power(self) -> float:
+        """Power in W."""
+        return self._integral(lambda wl: np.ones_like(wl, dtype=np.float64))
+
+    def luminous_power(self) -> float:
+        """Luminous power in lm (683 lm/W times the CIE 1931 y observer)."""
+        table = _tables["observers"]
+        return self._integral(lambda wl: 683.0 * np.interp(wl, table[:, 0], table[:, 2], left=0, right=0))
+
+    def peak(self) -> float:
+        """Highest value of the spectrum."""
+        kind = self.spectrum_type
+        if kind in ("Monochromatic", "Gaussian", "Rectangle", "Constant", "Blackbody"):
+            return float(self.val)
+        if kind == "Lines":
+            return float(np.max(self.line_vals))
+        if kind in ("Histogram", "Data"):
+            return float(np.max(self._vals))
+        return float(np.max(self._dense()[1]))
+
+    def peak_wavelength(self) -> float:
+        """Wavelength of the (first) highest value."""
+        kind = self.spectrum_type
+        if kind == "Monochromatic":
+            return float(self.wl)
+        if kind == "Lines":
+            return float(self.lines[int(np.argmax(self.line_vals))])
+        if kind == "Rectangle":
+            return float(self.wl0)
+        if kind == "Constant":
+            return float(go.wavelength_range[0])
+        if kind == "Gaussian":
+            return float(self.mu)
+        grid, values = self._dense()
+        return float(grid[int(np.argmax(values))])
+
+    def centroid_wavelength(self) -> float:
+        """Power-weighted mean wavelength."""
+        kind = self.spectrum_type
+        middle = float(np.mean(go.wavelength_range))
+        if kind == "Monochromatic":
+            return float(self.wl)
+        if kind == "Lines":
+            lines, weights = np.array(self.lines), np.array(self.line_vals)
+            return float(np.sum(weights * lines) / np.sum(weights))
+        if kind == "Rectangle":
+            return float(np.mean([self.wl0, self.wl1]))
+        if kind == "Constant":
+            return middle
+        grid, values = self._dense()
+        if not np.any(values > 0):
+            return middle
+        moment = grid * values
+        return float(np.sum((moment[1:] + moment[:-1]) / 2) / np.sum((values[1:] + values[:-1]) / 2))
+
+    def fwhm(self) -> float:
+        """Full width at half maximum around the highest peak: the nearest crossings of half its height on both sides."""
+        kind = self.spectrum_type
+        if kind in ("Monochromatic", "Lines"):
+            return 0.0
+        if kind == "Rectangle":
+            return float(self.wl1 - self.wl0)
+        if kind == "Constant":
+            return float(go.wavelength_range[1] - go.wavelength_range[0])
+        grid, values = self._dense()
+        top = int(np.argmax(values))
+        below = values < 0.5 * values[top]
+        right = np.flatnonzero(below[top:])
+        left = np.flatnonzero(below[:top][::-1])
+        hi = top + int(right[0]) if right.size else values.shape[0] - 1
+        lo = top - int(left[0]) if left.size else 0
+        return float(grid[hi] - grid[lo])
+
     @staticmethod
     def render(wl, w, **kwargs) -> "LightSpectrum":
         """Histogram spectrum (unit W/nm) of rays with wavelengths `wl` and powers `w`

@@ -175,6 +175,15 @@ def spectrum_cases(ot) -> dict:
         sl = ot.presets.spectral_lines
         out["light/spectral_lines"] = np.array([sl.h, sl.g, sl.F_, sl.F, sl.e, sl.d, sl.D, sl.C_, sl.C, sl.r, sl.A_,
                                                 *sl.FDC, *sl.FdC, *sl.FeC, *sl.F_eC_, *sl.rgb], dtype=np.float64)
+        # figures of spectra (light_spectrum.py:232-400): power, luminous power, peak, peak / centroid wavelength, width
+        hist = ot.LightSpectrum("Histogram")
+        hist._wls = np.linspace(450., 650., 41)
+        hist._vals = np.exp(-((hist._wls[:-1] + 2.5 - 560.) / 30.) ** 2)
+        figures = dict(light, mono=ot.LightSpectrum("Monochromatic", wl=532., val=1.5), hist=hist,
+                       lines=ot.LightSpectrum("Lines", lines=[450., 550., 650.], line_vals=[1., 3., 2.]))
+        for name, sp in figures.items():
+            out[f"light/figures_{name}"] = np.array([sp.power(), sp.luminous_power(), sp.peak(), sp.peak_wavelength(),
+                                                     sp.centroid_wavelength(), sp.fwhm()], dtype=np.float64)
         out["light/desc_lengths"] = np.array([len(light["constant"].get_desc()), len(light["gauss"].get_desc())], dtype=np.float64)
     return out
 
