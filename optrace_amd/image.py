@@ -26,6 +26,22 @@ def srgb_to_srgb_linear(rgb: np.ndarray) -> np.ndarray:
     return lin
 
 
+def srgb_linear_to_srgb(rgbl: np.ndarray) -> np.ndarray:
+    """Apply the sRGB gamma (color/srgb.py:357-376); odd in its argument like the inverse above."""
+    a = 0.055
+    size = np.abs(rgbl)
+    out = np.sign(rgbl) * ((1 + a) * size ** (1 / 2.4) - a)
+    toe = size <= 0.0031308
+    out[toe] = 12.92 * rgbl[toe]
+    return out
+
+
+# linear sRGB -> CIE XYZ (D65), the matrix of color/srgb.py:61-63
+_SRGB_TO_XYZ = np.array([[0.4124564, 0.3575761, 0.1804375],
+                         [0.2126729, 0.7151522, 0.0721750],
+                         [0.0193339, 0.1191920, 0.9503041]])
+
+
 def power_from_srgb_linear(rgbl: np.ndarray) -> np.ndarray:
     """Relative pixel power under the primary spectra below (color/srgb.py:556-565)."""
     f = SRGB_PRIMARY_POWER_FACTORS
@@ -173,6 +189,14 @@ class RGBImage(_BaseImage):
     """sRGB image with values in [0, 1] (rgb_image.py:12-75)."""
     _channels = 3
 
+    def to_grayscale_image(self) -> "GrayscaleImage":
+        """The luminance (CIE Y of the linear values) with the sRGB gamma again (rgb_image.py:41-56)."""
+        linear = srgb_to_srgb_linear(self._data)
+        xyz = (_SRGB_TO_XYZ @ linear.reshape(-1, 3).T).T.reshape(linear.shape)
+        gray = np.clip(srgb_linear_to_srgb(xyz[:, :, 1]), 0, 1)
+        return GrayscaleImage(gray, extent=self.extent, desc=self.desc, long_desc=self.long_desc, quantity=self.quantity,
+                              projection=self.projection, limit=self.limit)
+
     def _check_pixels(self, px):
         if px.ndim != 3 or px.shape[2] != 3:
             raise ValueError("Image needs to have three dimensions with 3 elements (RGB) in the third dimension, "
@@ -195,6 +219,11 @@ class ScalarImage(_BaseImage):
 
 class GrayscaleImage(ScalarImage):
     """sRGB-gamma grayscale image with values in [0, 1] (grayscale_image.py:10-60)."""
+
+    def to_rgb_image(self) -> RGBImage:
+        """The same values in three channels (grayscale_image.py:36-43)."""
+        return RGBImage(np.repeat(self._data[:, :, None], 3, axis=2), extent=self.extent, desc=self.desc,
+                        long_desc=self.long_desc, quantity=self.quantity, projection=self.projection, limit=self.limit)
 
     def _check_pixels(self, px):
         _at_most_one(px)

@@ -484,6 +484,10 @@ def container_cases(ot) -> dict:
                 out[f"cont/profile_{name}_{tag}"] = np.concatenate([np.asarray(edges, dtype=np.float64)] +
                                                                    [np.asarray(c, dtype=np.float64) for c in cuts])
             out[f"cont/image_{name}"] = np.array([*img.s, img.Apx, *img.shape[:2], *img.extent], dtype=np.float64)
+        g2 = rgb.to_grayscale_image()
+        out["cont/to_gray"] = np.concatenate((g2.data.ravel(), g2.extent))
+        r2 = gray.to_rgb_image()
+        out["cont/to_rgb"] = np.concatenate((r2.data.ravel(), r2.extent))
     return out
 
 
