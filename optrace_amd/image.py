@@ -37,9 +37,9 @@ def srgb_linear_to_srgb(rgbl: np.ndarray) -> np.ndarray:
 
 
 # linear sRGB -> CIE XYZ (D65), the matrix of color/srgb.py:61-63
-_SRGB_TO_XYZ = np.array([[0.4124564, 0.3575761, 0.1804375],
-                         [0.2126729, 0.7151522, 0.0721750],
-                         [0.0193339, 0.1191920, 0.9503041]])
+_SRGB_TO_XYZ = np.array([0.4124564, 0.3575761, 0.1804375,   # X
+                         0.2126729, 0.7151522, 0.0721750,   # Y: the luminance
+                         0.0193339, 0.1191920, 0.9503041]).reshape(3, 3)
 
 
 def power_from_srgb_linear(rgbl: np.ndarray) -> np.ndarray:
