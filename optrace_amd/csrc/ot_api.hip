@@ -20,12 +20,11 @@
 #include "ot_scene.hpp"
 #include "ot_spectrum.hpp"
 #include "ot_trace.hpp"
+#include "ot_trace_kernel.hpp"
 
 // ---------------------------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------------------------
-#define OT_CNT_SLOTS 1024  // counter slot tables per scene (see trace_kernel)
-
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string& msg) {
@@ -332,10 +331,19 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
                 return fail(OT_ERR_INVALID, "element: unknown kind");
         }
     }
-    bool needs_full = false, needs_numeric = false;  // anything beyond conic/flat lens surfaces and plain apertures
+    bool needs_full = false;  // anything beyond lens surfaces and plain apertures
+    int hit_level = OT_HIT_CLOSED;
     for (const StepDev& d : steps) {
         needs_full |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER || d.hurb;
-        needs_numeric |= surfs[d.surf].kind >= OT_SURF_ASPHERE && !surfs[d.surf].flat;
+        const SurfDev& sf = surfs[d.surf];
+        int lv = OT_HIT_CLOSED;
+        if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) {
+            // flat data surfaces have a closed-form hit -- unless a mask_func bitmap has to be consulted
+            if (!sf.flat || sf.mask_n != 0) lv = OT_HIT_SPLINE;
+        } else if (sf.kind >= OT_SURF_ASPHERE && !sf.flat) {
+            lv = OT_HIT_ILLINOIS;
+        }
+        hit_level = std::max(hit_level, lv);
     }
     const int nt = (int)steps.size() + 1;  // sections = tracing surfaces + 2, the end aperture being a step
 
@@ -469,7 +477,7 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     sc->needs_tables = needs_tables;
     sc->cnt_slots = (unsigned int*)(blob + o_cnt);
     sc->needs_full = needs_full;
-    sc->needs_numeric = needs_numeric;
+    sc->hit_level = hit_level;
     sc->d = (SceneDev*)(blob + o_hdr);
     sc->blob = blob;
     (void)hipGetDevice(&sc->device);
@@ -757,214 +765,6 @@ extern "C" void ot_sources_destroy(ot_sources* s) {
 
 // ---------------------------------------------------------------------------------------------------------
 // kernels
-// ---------------------------------------------------------------------------------------------------------
-#define OT_MAX_RANGES 64
-#ifndef OT_TRACE_MIN_WAVES
-#define OT_TRACE_MIN_WAVES 1
-#endif
-// Feature level 0 kernels (flat and conic surfaces only): five waves per SIMD asked for.  The discrete-spectrum variants
-// need 64-78 registers anyway; the continuous-spectrum ones (C3, C4) come down from 115-122 to 96 with a few spilled
-// values, and they wait on the dependent table loads of the generator half of the time: C4 10.5 -> 10.0 ms.
-#ifndef OT_TRACE_MIN_WAVES_F0
-#define OT_TRACE_MIN_WAVES_F0 5
-#endif
-
-struct RangeRec {  // one source range in device memory (scenes with more than OT_MAX_RANGES ranges)
-    int64_t first, count;
-    int32_t source;
-    uint32_t n2;
-    double inv_n, inv_n2;
-    float w;
-};
-
-struct RangeArgs {
-    int32_t n;
-    int32_t source[OT_MAX_RANGES];
-    int64_t first[OT_MAX_RANGES];
-    int64_t count[OT_MAX_RANGES];
-    // per-range constants of the stratified samplers, evaluated once on the host: 1 / count,
-    // floor(sqrt(count)) and its reciprocal (random.py:23-31, 62)
-    uint32_t n2[OT_MAX_RANGES];
-    double inv_n[OT_MAX_RANGES];
-    double inv_n2[OT_MAX_RANGES];
-    float w[OT_MAX_RANGES];  // power of each ray of the range
-    const RangeRec* ext;  // n > OT_MAX_RANGES: n records sorted by `first`, contiguous; the arrays above are unused
-};
-
-OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& k, int& src) {
-    if (rg.ext) {  // many ranges: binary search for the last record starting at or before this ray
-        int lo = 0, hi = rg.n - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (rg.ext[mid].first <= ray)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        const RangeRec rr = rg.ext[lo];
-        if (ray < rr.first || ray >= rr.first + rr.count) return false;
-        g.j = (uint32_t)(ray - rr.first);
-        g.n = (uint32_t)rr.count;
-        g.n2 = rr.n2;
-        g.inv_n = rr.inv_n;
-        g.inv_n2 = rr.inv_n2;
-        g.w = rr.w;
-        k = lo;
-        src = rr.source;
-        return true;
-    }
-    for (int q = 0; q < rg.n; q++) {
-        if (ray >= rg.first[q] && ray < rg.first[q] + rg.count[q]) {
-            g.j = (uint32_t)(ray - rg.first[q]);
-            g.n = (uint32_t)rg.count[q];
-            g.n2 = rg.n2[q];
-            g.inv_n = rg.inv_n[q];
-            g.inv_n2 = rg.inv_n2[q];
-            g.w = rg.w[q];
-            k = q;
-            src = rg.source[q];
-            return true;
-        }
-    }
-    return false;
-}
-
-// Generates the ray of every lane that has one.  Source ranges span millions of rays, so a wavefront nearly
-// always lies inside one range: then the range index, its ray count and its source record are WAVE-UNIFORM
-// (broadcast from the first lane) -- the source is read with scalar loads, the switches over shape / spectrum /
-// divergence / polarisation are scalar branches, permutation keys come from the scalar ALU.  A wave that
-// straddles a range boundary takes the per-lane path.  (A loop over the ranges of a wave instead of the two
-// paths made the register allocator give up: 256 VGPRs.)
-OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sources, int64_t ray, uint64_t seed,
-                          bool no_pol, NewRay& nr) {
-    GenCtx g;
-    g.seed = seed;
-    g.gidx = (uint64_t)ray;
-    // the range of the wave's first ray, found on the scalar unit: the records are sorted and contiguous
-    // (make_ranges), so it is the last one that starts at or before that ray
-    const uint64_t ray0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)ray >> 32)) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ray);
-    int lo = 0, hi = rg.n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        const int64_t f = rg.ext ? as_const(rg.ext)[mid].first : rg.first[mid];
-        if ((uint64_t)f <= ray0)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    int64_t first0, count0;
-    int src0;
-    if (rg.ext) {
-        const auto& rr = as_const(rg.ext)[lo];
-        first0 = rr.first; count0 = rr.count; src0 = rr.source;
-        g.n2 = rr.n2; g.inv_n = rr.inv_n; g.inv_n2 = rr.inv_n2; g.w = rr.w;
-    } else {
-        first0 = rg.first[lo]; count0 = rg.count[lo]; src0 = rg.source[lo];
-        g.n2 = rg.n2[lo]; g.inv_n = rg.inv_n[lo]; g.inv_n2 = rg.inv_n2[lo]; g.w = rg.w[lo];
-    }
-    const bool inside = ray >= first0 && ray < first0 + count0;
-    if (__ballot(inside) == __ballot(true)) {  // one range in this wave
-        g.j = (uint32_t)(ray - first0);
-        g.n = (uint32_t)count0;
-        g.range = (uint32_t)lo;
-        const auto& S = as_const(sources)[src0];
-        fill_dither_for(g, S);
-        nr = generate_ray(S, g, no_pol);
-        return true;
-    }
-    int k = -1, src = 0;
-    const bool have = locate_range(rg, ray, g, k, src);
-    if (have) {
-        g.range = (uint32_t)k;
-        fill_dither_for(g, sources[src]);
-        nr = generate_ray(sources[src], g, no_pol);
-    }
-    return have;
-}
-
-// Raytracer.trace: optional on-the-fly generation, then all steps.  One ray per lane, 256-thread workgroups
-// (4 wave64); template switches select a kernel that only contains what the scene needs:
-//   POL  polarisation tracked          GEN  rays generated in registers (no section-0 round trip)
-//   TAB  tabulated media/filters or injected HURB normals (per-lane global loads inside the loop)
-//   FEAT 0: conic / flat surfaces and plain apertures only (82 VGPRs)   1: + ideal lenses, filters, HURB (127)
-//        2: + surfaces that need the numeric hit search: aspheres, tilted, spline surfaces (206)
-// Event counters go wave -> LDS (per workgroup) -> one of OT_CNT_SLOTS global slot tables (blockIdx % slots) ->
-// reduce_counters_kernel, so that no two workgroups hammer the same address (see count_event).
-// The launch covers the rays [ray_base, ray_base + count) of the bundle; R's pointers are advanced to ray_base by
-// the host (R.N stays the plane stride), so lanes address their ray with a 32-bit offset (count <= 2^28).
-template <bool POL, bool GEN, int SPEC, int FEAT>
-__global__ __launch_bounds__(256, (FEAT == 0 ? OT_TRACE_MIN_WAVES_F0 : OT_TRACE_MIN_WAVES)) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
-                                                    const SourceDev* __restrict__ sources, RangeArgs rg,
-                                                    const double* __restrict__ hurb_normals, uint64_t seed,
-                                                    unsigned int* __restrict__ slots, int64_t ray_base,
-                                                    uint32_t count) {
-    extern __shared__ double lds[];  // [discrete-spectrum table (SPEC == 2)] [event counters + timeout flag]
-    auto& sc = *as_const(scp);
-    const int n_tab = (SPEC == 2) ? (3 * sc.n_steps + 2) * OT_MAX_LINES : 0;
-    double* ltab = lds;
-    unsigned int* cnt = (unsigned int*)(lds + n_tab);  // (OT_N_INFOS x nt) counters + 1 flag
-    const int n_cnt = OT_N_INFOS * sc.nt + 1;
-    for (int k = threadIdx.x; k < n_cnt; k += blockDim.x) cnt[k] = 0u;
-    if (SPEC == 2)
-        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) ltab[k] = sc.line_tab[k];
-    __syncthreads();
-
-    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ray = ray_base + (int64_t)local;
-    bool have = local < count;
-    RayState r;
-    if (have) {
-        if (GEN) {
-            NewRay nr;
-            have = generate_lane(rg, sources, ray, seed, !POL, nr);
-            if (have) {
-                r.p = nr.p;
-                r.s = nr.s;
-                r.w = nr.w;
-                r.wl = nr.wl;
-                r.polx = (float)nr.polx;
-                r.poly = (float)nr.poly;
-                r.polz = (float)nr.polz;
-                __builtin_nontemporal_store(r.wl, &R.wl[local]);  // written once, streamed (see OT_STORE_HINT)
-            }
-        } else {
-            const int64_t N = R.N, nt = R.nt;
-            r.p.x = R.p[local];
-            r.p.y = R.p[local + N * nt];
-            r.p.z = R.p[local + N * 2 * nt];
-            r.s.x = R.s[local];
-            r.s.y = R.s[local + N];
-            r.s.z = R.s[local + 2 * N];
-            r.w = R.w[local];
-            r.wl = R.wl[local];
-            r.polx = r.poly = r.polz = 0.f;
-            if (POL) {
-                r.polx = R.pol[local];
-                r.poly = R.pol[local + N * nt];
-                r.polz = R.pol[local + N * 2 * nt];
-            }
-        }
-    }
-    // RaySource.create_rays raises if any generated direction has s_z <= 0 (ray_source.py:353).  Reported as
-    // counter (HURB_NEG_DIR, section 0), a cell no tracing event can touch; the host turns it into that error.
-    if (GEN) count_event(cnt, sc.nt, OT_INFO_HURB_NEG_DIR, 0, have && !(r.s.z > 0));
-    if (have) {
-        int lj = 0;  // discrete spectra: which line this ray carries
-        if (SPEC == 2) {
-            for (int j = 1; j < sc.n_lines; j++)
-                if ((float)ltab[j] == r.wl) lj = j;
-        }
-        // feature level 2: 25 doubles per lane behind the counters for the spline patch cache
-        double* patch = (FEAT >= 2) ? lds + n_tab + (n_cnt + 2) / 2 : nullptr;
-        bool ok = trace_ray<POL, SPEC, FEAT>(sc, R, local, (uint64_t)ray, r, hurb_normals, seed, cnt, ltab, lj, patch);
-        if (!ok) cnt[n_cnt - 1] = 1u;  // numeric hit search timed out (surface.py:403)
-    }
-    __syncthreads();
-    unsigned int* slot = slots + (size_t)(blockIdx.x % OT_CNT_SLOTS) * n_cnt;
-    for (int k = threadIdx.x; k < n_cnt; k += blockDim.x)
-        if (cnt[k]) atomicAdd(&slot[k], cnt[k]);
-}
 
 // sums the slot tables into the caller's int64 counters (ADD) and clears them for the next launch:
 // one workgroup per counter, one lane per 4 slots, wave shuffle + LDS reduction
@@ -1237,19 +1037,20 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
     const SourceDev* sd = src ? src->d : nullptr;
     unsigned long long* m = (unsigned long long*)msgs;
     if (!msgs) HIP_TRY(hipHostGetDevicePointer((void**)&m, sc->pin_msgs, 0));
-    dim3 block(256);
     // kernel variant: polarisation x on-device generation x spectrum handling x feature set
     const bool tab = sc->needs_tables || hurb_normals != nullptr;
-    const int feat = sc->needs_numeric ? 2 : (sc->needs_full ? 1 : 0);
+    // spline scenes always take the full variant: at ~250 VGPRs the ideal-lens / filter / HURB code costs them nothing
+    const int feat = OT_FEAT(sc->hit_level, sc->needs_full || sc->hit_level == OT_HIT_SPLINE);
     bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr;  // generated rays only
     // dynamic LDS: the counter table, and with discrete spectra the per-line tables (3 rows per step).  Very long
     // stacks do not fit the 64 KB a kernel gets without asking: the formula kernels (SPEC 0 / 1) trace those.
     const size_t lds_cnt = sizeof(unsigned int) * (size_t)n_cnt + 8;
     const size_t lds_lines = sizeof(double) * (size_t)(3 * sc->h.n_steps + 2) * OT_MAX_LINES;
-    if (lds_cnt > 60000) return fail(OT_ERR_UNSUPPORTED, "ot_trace: more than ~3000 tracing surfaces in one scene");
-    if (lines && lds_cnt + lds_lines > 60000) lines = false;
-    // numeric surfaces: a 5 x 5 coefficient patch per lane (spline surfaces, ot_spline.hpp::PatchCache)
-    const size_t lds_patch = (feat == 2) ? 256 * 25 * sizeof(double) + 16 : 0;
+    // spline surfaces: a 5 x 5 coefficient patch per lane (ot_spline.hpp::PatchCache)
+    const size_t lds_patch = (sc->hit_level == OT_HIT_SPLINE) ? 256 * 25 * sizeof(double) + 16 : 0;
+    if (lds_cnt + lds_patch > 65000)
+        return fail(OT_ERR_UNSUPPORTED, lds_patch ? "ot_trace: more than ~650 tracing surfaces in a scene with spline surfaces"
+                                                  : "ot_trace: more than ~3000 tracing surfaces in one scene");
     if (lines && lds_cnt + lds_lines + lds_patch > 65000) lines = false;
     const size_t lds = ((lds_cnt + (lines ? lds_lines : 0) + 7) / 8) * 8 + lds_patch;
     unsigned int* slots = sc->cnt_slots;
@@ -1257,24 +1058,31 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
     // lanes address their ray with 32-bit byte offsets: launches of at most 2^28 rays, base pointers advanced
     const int64_t chunk = 1ll << 28;
     for (int64_t base = 0; base < rays->N; base += chunk) {
-    const uint32_t count = (uint32_t)std::min<int64_t>(chunk, rays->N - base);
-    const dim3 grid = grid_for(count);
-    ot_rays part = *rays;
-    part.p += base; part.s += base; part.w += base; part.n += base; part.wl += base;
-    if (part.pol) part.pol += base;
-#define OT_LAUNCH(P, G, S, F) \
-    hipLaunchKernelGGL((trace_kernel<P, G, S, F>), grid, block, lds, st, sc->d, part, sd, r, hurb_normals, seed, slots, base, count)
-#define OT_LAUNCH_F(P, G, S) do { if (feat == 2) OT_LAUNCH(P, G, S, 2); else if (feat == 1) OT_LAUNCH(P, G, S, 1); else OT_LAUNCH(P, G, S, 0); } while (0)
-    if (src) {
-        if (lines)    { if (pol) OT_LAUNCH_F(true, true, 2); else OT_LAUNCH_F(false, true, 2); }
-        else if (tab) { if (pol) OT_LAUNCH_F(true, true, 1); else OT_LAUNCH_F(false, true, 1); }
-        else          { if (pol) OT_LAUNCH_F(true, true, 0); else OT_LAUNCH_F(false, true, 0); }
-    } else {
-        if (tab)      { if (pol) OT_LAUNCH_F(true, false, 1); else OT_LAUNCH_F(false, false, 1); }
-        else          { if (pol) OT_LAUNCH_F(true, false, 0); else OT_LAUNCH_F(false, false, 0); }
-    }
-#undef OT_LAUNCH_F
-#undef OT_LAUNCH
+        TraceLaunch L;
+        L.count = (uint32_t)std::min<int64_t>(chunk, rays->N - base);
+        L.grid = grid_for(L.count);
+        L.lds = lds;
+        L.st = st;
+        L.sc = sc->d;
+        L.part = *rays;
+        L.part.p += base; L.part.s += base; L.part.w += base; L.part.n += base; L.part.wl += base;
+        if (L.part.pol) L.part.pol += base;
+        L.sd = sd;
+        L.rg = &r;
+        L.hurb_normals = hurb_normals;
+        L.seed = seed;
+        L.slots = slots;
+        L.base = base;
+        L.pol = pol;
+        L.gen = src != nullptr;
+        L.spec = (src && lines) ? 2 : (tab ? 1 : 0);
+        switch (feat) {
+            case OT_FEAT(OT_HIT_CLOSED, 0): launch_trace_feat<OT_FEAT(OT_HIT_CLOSED, 0)>(L); break;
+            case OT_FEAT(OT_HIT_CLOSED, 1): launch_trace_feat<OT_FEAT(OT_HIT_CLOSED, 1)>(L); break;
+            case OT_FEAT(OT_HIT_ILLINOIS, 0): launch_trace_feat<OT_FEAT(OT_HIT_ILLINOIS, 0)>(L); break;
+            case OT_FEAT(OT_HIT_ILLINOIS, 1): launch_trace_feat<OT_FEAT(OT_HIT_ILLINOIS, 1)>(L); break;
+            default: launch_trace_feat<OT_FEAT(OT_HIT_SPLINE, 1)>(L); break;
+        }
     }
     HIP_TRY(hipGetLastError());
     if (sc->timing) {

@@ -175,7 +175,7 @@ OT_DEV bool detector_hit_last(DET& D, int nt, bool active, const SectionPair& sp
     if (!(det.flat && nt >= 2 && reaches && !(sp.zq >= det.z_min))) return false;
     const V3 p = {sp.xq, sp.yq, sp.zq};
     bool ish, ill;
-    find_hit<false>(det, p, sdir, ph, ish, ill);
+    find_hit<OT_HIT_CLOSED>(det, p, sdir, ph, ish, ill);
     w = (ph.z > sp.zl + OT_C_EPS) ? 0.f : sp.wq;  // a hit behind the end of the ray is none (raytracer.py:985)
     valid = ish && (w > 0);
     if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
@@ -258,7 +258,7 @@ OT_DEV void detector_hit(const ot_rays& R, int64_t r, bool active, DET& D, const
                     break;
                 }
                 bool ill;
-                if (!find_hit<NUMERIC>(det, p, s, ph, ish, ill)) timeout = true;
+                if (!find_hit<(NUMERIC ? OT_HIT_SPLINE : OT_HIT_CLOSED)>(det, p, s, ph, ish, ill)) timeout = true;
                 any_ill = any_ill || ill;
                 double p2z = (k == nt - 1) ? zl : zp[N * (int64_t)k];
                 if (!(ph.z > p2z + OT_C_EPS)) break;  // hit lies inside this section (raytracer.py:985)

@@ -92,6 +92,15 @@ OT_DEV V3 along(const V3& p, const V3& s, double t) {
 
 #include "ot_spline.hpp"
 
+// Hit levels: which surface kinds a piece of device code has to handle.  Kernels are compiled per level so that a scene
+// only carries the code (registers, LDS, instruction cache) of what it contains:
+//   OT_HIT_CLOSED    flat and conic surfaces: closed-form hit, no loop
+//   OT_HIT_ILLINOIS  + aspheres and tilted surfaces: the numeric hit search (surface.py:329-414) on a closed-form sag
+//   OT_HIT_SPLINE    + data / function surfaces: spline tables, coefficient patch cache, mask_func bitmaps
+#define OT_HIT_CLOSED 0
+#define OT_HIT_ILLINOIS 1
+#define OT_HIT_SPLINE 2
+
 // ---- spline surfaces: DataSurface2D._call / ._values / .normals data_surface_2d.py:126-196 -----------------
 // table layout (include/optrace_amd.h): DATA1D t[n] | c[n] | dc[n];  DATA2D t[n] | c[(n-5)^2] | cx[(n-6)(n-5)] | cy
 template <class SF>
@@ -235,10 +244,10 @@ OT_DEV double asph_poly_deriv(SF& sf, double r) {  // polyval(polyder(..)) asphe
 }
 
 // Surface._values relative to the centre: conic_surface.py:57, aspheric_surface.py:51
-template <class SF>
+template <int LEVEL = OT_HIT_SPLINE, class SF>
 OT_DEV double surf_values_rel(SF& sf, double x, double y, PatchCache* pc = nullptr) {
     if (sf.kind == OT_SURF_TILTED) return x * sf.mx + y * sf.my;  // tilted_surface.py:60-73
-    if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) return data_values_rel(sf, x, y, pc);
+    if (LEVEL >= OT_HIT_SPLINE && (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D)) return data_values_rel(sf, x, y, pc);
     if (sf.kind == OT_SURF_CONIC) {
         double r2 = x * x + y * y;
         return ot_div(sf.rho * r2, 1 + sqrt(1 - sf.k1rho2 * r2));
@@ -251,17 +260,17 @@ OT_DEV double surf_values_rel(SF& sf, double x, double y, PatchCache* pc = nullp
 }
 
 // Surface.values surface.py:137-164
-template <class SF>
+template <int LEVEL = OT_HIT_SPLINE, class SF>
 OT_DEV double surf_values(SF& sf, double x, double y, PatchCache* pc = nullptr) {
     if (sf.flat) return sf.z_max;
-    if (surf_mask(sf, x, y)) return sf.pz + surf_values_rel(sf, x - sf.px, y - sf.py, pc);
-    if (sf.kind == OT_SURF_TILTED || sf.kind == OT_SURF_DATA2D) {
+    if (surf_mask<(LEVEL >= OT_HIT_SPLINE)>(sf, x, y)) return sf.pz + surf_values_rel<LEVEL>(sf, x - sf.px, y - sf.py, pc);
+    if (sf.kind == OT_SURF_TILTED || (LEVEL >= OT_HIT_SPLINE && sf.kind == OT_SURF_DATA2D)) {
         // no rotational symmetry: edge value along the direction of (x, y), surface.py:156-159;
         // cos / sin of arctan2 formed as dx / rr, dy / rr like in surf_normal
         double dx = x - sf.px, dy = y - sf.py;
         double rr = sqrt(dx * dx + dy * dy);
         double c = (rr > 0.0) ? dx / rr : 1.0, sn = (rr > 0.0) ? dy / rr : 0.0;
-        return sf.pz + surf_values_rel(sf, sf.r_edge * c, sf.r_edge * sn, pc);
+        return sf.pz + surf_values_rel<LEVEL>(sf, sf.r_edge * c, sf.r_edge * sn, pc);
     }
     return sf.edge_val;
 }
@@ -270,20 +279,22 @@ OT_DEV double surf_values(SF& sf, double x, double y, PatchCache* pc = nullptr) 
 // FunctionSurface2D.normals (1D branch) function_surface_2d.py:216-251 + AsphericSurface._deriv :67-82.
 // cos(atan2(dy,dx)) and sin(atan2(dy,dx)) are formed as dx/r, dy/r: same value to 1-2 ulp without three
 // transcendental calls per ray (normals never feed a mask directly; tolerance 1e-6).
-template <bool INSIDE = false, bool ALL_KINDS = true, class SF>
+template <bool INSIDE = false, int LEVEL = OT_HIT_SPLINE, class SF>
 OT_DEV V3 surf_normal(SF& sf, double x, double y, PatchCache* pc = nullptr) {
+    constexpr bool TABLES = LEVEL >= OT_HIT_SPLINE;
     V3 n = {0.0, 0.0, 1.0};
     if (sf.kind < OT_SURF_CONIC) return n;
-    if (!ALL_KINDS && sf.kind != OT_SURF_CONIC) return n;  // kernel variant for scenes of flat and conic surfaces
+    if (LEVEL == OT_HIT_CLOSED && sf.kind != OT_SURF_CONIC) return n;  // kernel variant for scenes of flat and conic surfaces
     if (sf.kind == OT_SURF_TILTED) {  // tilted_surface.py:75-89: constant, also when the plane happens to be flat
-        if (!INSIDE && !surf_mask(sf, x, y)) return n;
+        if (!INSIDE && !surf_mask<TABLES>(sf, x, y)) return n;
         V3 m = {sf.nx, sf.ny, sf.nz};
         return m;
     }
     if (sf.flat) return n;
-    if (!INSIDE && !surf_mask(sf, x, y)) return n;  // INSIDE: caller already knows mask(x, y) is true
+    if (!INSIDE && !surf_mask<TABLES>(sf, x, y)) return n;  // INSIDE: caller already knows mask(x, y) is true
     double dx = x - sf.px, dy = y - sf.py;
     if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) {  // data_surface_2d.py:153-196
+        if (LEVEL < OT_HIT_SPLINE) return n;  // (unreachable: such scenes run the spline level)
         double gx, gy;
         data_gradient(sf, dx, dy, gx, gy, pc);
         V3 m = {-gx, -gy, 1.0};
@@ -319,9 +330,9 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y, PatchCache* pc = nullptr) {
 // Surface._find_hit_handle_abnormal surface.py:436-479
 template <class SF>
 OT_DEV void handle_abnormal_f(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, double f);
-template <class SF>
+template <int LEVEL = OT_HIT_SPLINE, class SF>
 OT_DEV void handle_abnormal(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, PatchCache* pc = nullptr) {
-    double zs = surf_values(sf, ph.x, ph.y, pc);
+    double zs = surf_values<LEVEL>(sf, ph.x, ph.y, pc);
     handle_abnormal_f(sf, p, s, ph, hit, ph.z - zs);
 }
 
@@ -393,8 +404,9 @@ OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) 
 // loop below runs while the 64-bit ballot of unconverged lanes is non-zero (one scalar branch per iteration)
 // and converged lanes idle, so a wave pays max(iterations) of its own 64 rays only.
 // Returns false if a lane hit the 200-iteration timeout (surface.py:403).
-template <bool NUMERIC = true, class SF>
+template <int LEVEL = OT_HIT_SPLINE, class SF>
 OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& ill, PatchCache* pc = nullptr) {
+    constexpr bool TABLES = LEVEL >= OT_HIT_SPLINE;
     ill = false;
     if (sf.kind == OT_SURF_CONIC) {
         find_hit_conic(sf, p, s, ph, hit);
@@ -403,11 +415,13 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
     if (sf.flat) {
         double t = ot_div(sf.pz - p.z, s.z);
         ph = along(p, s, t);
-        hit = surf_mask<NUMERIC>(sf, ph.x, ph.y);
-        handle_abnormal(sf, p, s, ph, hit);
+        // a flat function surface may still carry a mask_func bitmap (the custom apertures of
+        // docs/source/usage/surfaces.rst:360-369); the scene compiler sends such scenes to the spline level
+        hit = surf_mask<TABLES>(sf, ph.x, ph.y);
+        handle_abnormal<LEVEL>(sf, p, s, ph, hit);
         return true;
     }
-    if (!NUMERIC) {  // kernel variant without numeric surfaces: unreachable, keeps the Illinois loop out of it
+    if (LEVEL == OT_HIT_CLOSED) {  // kernel variant without numeric surfaces: unreachable, keeps the Illinois loop out of it
         ph = p;
         hit = false;
         return true;
@@ -421,7 +435,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         bool nz0 = td != 0;
         double t = ((sf.px - p.x) * sf.nx + (sf.py - p.y) * sf.ny + (sf.pz - p.z) * sf.nz) / (nz0 ? td : 1e-12);
         ph_pre = along(p, s, t);
-        pre = surf_mask(sf, ph_pre.x, ph_pre.y) && nz0;
+        pre = surf_mask<TABLES>(sf, ph_pre.x, ph_pre.y) && nz0;
     }
     const double isz = ot_rcp3(s.z);
     double t1 = ot_div_r(sf.zt1 - p.z, s.z, isz);
@@ -430,8 +444,8 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
     V3 p1 = along(p, s, t1), p2 = along(p, s, t2);
     double f1 = 0.0, f2 = 0.0;
     if (!pre) {
-        f1 = p1.z - surf_values(sf, p1.x, p1.y, pc);
-        f2 = p2.z - surf_values(sf, p2.x, p2.y, pc);
+        f1 = p1.z - surf_values<LEVEL>(sf, p1.x, p1.y, pc);
+        f2 = p2.z - surf_values<LEVEL>(sf, p2.x, p2.y, pc);
     }
     bool w = !pre && isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
     ph.x = ph.y = ph.z = 0.0;
@@ -445,7 +459,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         if (w) {
             double ts = t1 - ot_div(f1, f2 - f1) * (t2 - t1);
             V3 pl = along(p, s, ts);
-            double fts = pl.z - surf_values(sf, pl.x, pl.y, pc);
+            double fts = pl.z - surf_values<LEVEL>(sf, pl.x, pl.y, pc);
             double prod = fts * f2;
             if (prod < 0) {
                 t1 = t2;
@@ -475,7 +489,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         it++;
     }
     if (!pre) {
-        hit = surf_mask(sf, ph.x, ph.y);
+        hit = surf_mask<TABLES>(sf, ph.x, ph.y);
         handle_abnormal_f(sf, p, s, ph, hit, f_ph);
     }
     if (sf.kind == OT_SURF_TILTED) {  // tilted_surface.py:119-120: abnormal handling once more, for all rays
@@ -483,7 +497,7 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
             ph = ph_pre;
             hit = true;
         }
-        handle_abnormal(sf, p, s, ph, hit, pc);
+        handle_abnormal<LEVEL>(sf, p, s, ph, hit, pc);
     }
     return ok;
 }

@@ -155,10 +155,10 @@ OT_DEV double fresnel_T2(double n1, double n2, double ns, double W, double A_ts2
 // Raytracer.__refraction raytracer.py:761-829 for a lane that has power and hit the surface.
 // The new direction s' is computed in the reference's exact operation order (it feeds the next hit mask).
 // Returns true on total internal reflection.
-template <bool POL, bool NUMERIC, class SF>
+template <bool POL, int LEVEL, class SF>
 OT_DEV bool refract(SF& sf, RayState& r, const V3& pn, float& wn, float& npx, float& npy, float& npz,
                     double n1, double n2, double N, PatchCache* pc = nullptr) {  // N = n1 / n2 (raytracer.py:799)
-    V3 n = surf_normal<true, NUMERIC>(sf, pn.x, pn.y, pc);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
+    V3 n = surf_normal<true, LEVEL>(sf, pn.x, pn.y, pc);  // pn is a hit point: is_hit implies mask(pn) (surface.py:409)
     V3 s = r.s;
     double ns = dot3(n, s);
     double W = ot_sqrt(1 - N * N * (1 - ns * ns));
@@ -313,14 +313,16 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
                       const double* __restrict__ hurb_normals, uint64_t seed, unsigned int* msgs, const double* ltab,
                       int lj, double* patch_lds) {
     constexpr bool TAB = (SPEC == 1);
-    constexpr bool FULL = FEAT >= 1;     // ideal lenses, filters, HURB
-    constexpr bool NUMERIC = FEAT >= 2;  // surfaces that need the Illinois search (aspheres, tilted, spline)
+    constexpr bool FULL = (FEAT & 1) != 0;  // ideal lenses, filters, HURB
+    constexpr int LEVEL = FEAT / 2;         // hit level (ot_device.hpp): closed form / + Illinois search / + spline surfaces
+    constexpr bool NUMERIC = LEVEL >= OT_HIT_ILLINOIS;
+    constexpr bool SPLINE = LEVEL >= OT_HIT_SPLINE;
     // lj = line index of this ray (SPEC == 2), straight from the generator
     const double* lrow = ltab + OT_MAX_LINES + lj;  // row 0 of this lane's column
     const uint32_t o8 = local * 8u, o4 = local * 4u;
     // numeric surfaces: this lane's coefficient patch in LDS (ot_spline.hpp::PatchCache)
-    PatchCache pcache = {patch_lds + threadIdx.x, 256, nullptr};  // (feature level 2 launches always carry the buffer)
-    PatchCache* const pc = NUMERIC ? &pcache : nullptr;
+    PatchCache pcache = {patch_lds + threadIdx.x, 256, nullptr};  // (spline-level launches always carry the buffer)
+    PatchCache* const pc = SPLINE ? &pcache : nullptr;
     const int nt = sc.nt;
     const auto surfaces = as_const(sc.surfaces);
     const auto steps = as_const(sc.steps);
@@ -341,11 +343,11 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
         const bool hw = r.w > 0;
         V3 ph;
         bool hit = false, ill = false;
-        if (NUMERIC) {  // another surface, another table: the cached patch and cell belong to the previous one
+        if (SPLINE) {  // another surface, another table: the cached patch and cell belong to the previous one
             pcache.key = nullptr;
         }
         if (hw) {
-            ok &= find_hit<NUMERIC>(sf, r.p, r.s, ph, hit, ill, pc);
+            ok &= find_hit<LEVEL>(sf, r.p, r.s, ph, hit, ill, pc);
             pn = ph;
         }
         if (NUMERIC) count_event(msgs, nt, OT_INFO_ILL_COND, i + 1, hw && ill);
@@ -370,7 +372,7 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
                 if (FULL && kind == OT_STEP_IDEAL)
                     refract_ideal<POL>(sf, st, r, pn, npx, npy, npz);
                 else
-                    tir = refract<POL, NUMERIC>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq, pc);
+                    tir = refract<POL, LEVEL>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq, pc);
             }
         } else if (FULL && kind == OT_STEP_FILTER) {  // raytracer.py:379-380
             if (hwh) {

@@ -20,9 +20,12 @@ def c1_single_lens(ot, **rt_args):
     return RT
 
 
-def double_gauss(ot, spectrum=None, **rt_args):
+def double_gauss(ot, spectrum=None, aspheric=False, **rt_args):
     """BASELINE.json configs[1] / C2: Nikkor-Wakamiya 100 mm f/1.4 double Gauss, geometry of
-    examples/double_gauss.py:34-102 (US patent 4448497), 5 point sources, FDC line spectrum."""
+    examples/double_gauss.py:34-102 (US patent 4448497), 5 point sources, FDC line spectrum.
+    aspheric=True: every lens FRONT becomes an AsphericSurface of the same vertex radius (k = -0.3, small even
+    polynomial) -- the synthetic asphere scene SURVEY 8(a6) asks for: 7 of the 15 surfaces go through the numeric
+    (Illinois) hit search, the rest stay closed-form."""
     RT = ot.Raytracer(outline=[-2000, 2000, -22000, 2000, -50000, 180], **rt_args)
     g = 50000
     spectrum = spectrum or ot.LightSpectrum("Lines", lines=[486.1327, 589.2938, 656.272], line_vals=[1, 1, 1])
@@ -32,7 +35,12 @@ def double_gauss(ot, spectrum=None, **rt_args):
                             div_angle=0.03, pos=[0, -xp, -g], spectrum=spectrum, desc=f"{deg} deg"))
 
     def lens(r1, R1, r2, R2, n, V, z, d2):
-        L = ot.Lens(ot.SphericalSurface(r=r1, R=R1), ot.SphericalSurface(r=r2, R=R2),
+        if aspheric:
+            with ot.global_options.no_warnings():
+                front = ot.AsphericSurface(r=r1, R=R1, k=-0.3, coeff=[-1e-6 * np.sign(R1), 2e-10 * np.sign(R1)])
+        else:
+            front = ot.SphericalSurface(r=r1, R=R1)
+        L = ot.Lens(front, ot.SphericalSurface(r=r2, R=R2),
                     n=ot.RefractionIndex("Abbe", n=n, V=V), pos=[0, 0, z], d1=0, d2=d2)
         RT.add(L)
         return L
@@ -237,7 +245,45 @@ def masked_scene(ot, **rt_args):
     return RT
 
 
-SCENES3 = {"masked": (masked_scene, 3000)}
+def _zeros(x, y):
+    return np.zeros_like(x)
+
+
+def _lower_part(x, y):
+    return y <= -0.625
+
+
+def _quadrant_gap(x, y):
+    """everything but the quadrant x > 0.625, y > 0 (borders on cell borders of the bitmap)"""
+    return ~((x > 0.625) & (y > 0))
+
+
+def masked_flat_scene(ot, **rt_args):
+    """FLAT function surfaces with a mask_func and nothing else numeric in the scene -- the custom apertures of the
+    reference's documentation (docs/source/usage/surfaces.rst:360-369: FunctionSurface2D(func=zeros, mask_func=...)):
+    as Aperture (the part y <= -0.625 blocks), as Filter (window attenuates) and as the front face of a plate (rays outside the
+    mask miss the lens and are absorbed).  Such a scene needs no numeric hit search, yet every hit test has to consult
+    the mask bitmap."""
+    RT = ot.Raytracer(outline=[-12, 12, -12, 12, 0, 60], **rt_args)
+    RT.add(ot.RaySource(ot.CircularSurface(r=3.2), divergence="Isotropic", div_angle=1.5, s=[0, 0, 1], pos=[0, 0, 0],
+                        spectrum=ot.LightSpectrum("Rectangle", wl0=480., wl1=620.)))
+    ap = ot.FunctionSurface2D(func=_zeros, mask_func=_lower_part, r=5)
+    RT.add(ot.Aperture(ap, pos=[0, 0, 8]))
+    win = ot.FunctionSurface2D(func=_zeros, mask_func=_window, r=5)
+    win.rotate(90)
+    RT.add(ot.Filter(win, pos=[0, 0, 14], spectrum=ot.TransmissionSpectrum("Constant", val=0.5)))
+    face = ot.FunctionSurface2D(func=_zeros, mask_func=_quadrant_gap, r=5)
+    RT.add(ot.Lens(face, ot.SphericalSurface(r=5, R=-30), d=1.0, pos=[0, 0, 22], n=ot.RefractionIndex("Constant", n=1.55)))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[12, 12]), pos=[0, 0, 40]))
+    return RT
+
+
+def double_gauss_aspheric(ot, **rt_args):
+    return double_gauss(ot, aspheric=True, **rt_args)
+
+
+SCENES3 = {"masked": (masked_scene, 3000), "masked_flat": (masked_flat_scene, 3000),
+           "double_gauss_aspheric": (double_gauss_aspheric, 2000)}
 
 
 # ---- random scenes (tests/test_gpu_random_scenes.py, golden trace_random*.npz) -------------------------------------

@@ -44,6 +44,10 @@ CONFIGS = {
     "C3 arizona eye RGB": (c3, 50_000_000),
     "C4 image render no_pol": (c4, 200_000_000),
     "C5 HURB slit+lens": (lambda o: scenes.hurb_slit_lens(o, seed=51), 100_000_000),
+    # numeric hit search: the C2 stack with aspheric lens fronts (7 of 15 surfaces), and the mixed test scene
+    "A1 double gauss aspheric fronts": (lambda o: scenes.double_gauss(o, seed=1, aspheric=True), 10_000_000),
+    "A1n double gauss aspheric no_pol": (lambda o: scenes.double_gauss(o, seed=1, aspheric=True, no_pol=True), 10_000_000),
+    "A2 asphere test scene": (lambda o: scenes.asphere_scene(o, seed=3), 10_000_000),
     "freeform (spline surfaces)": (lambda o: scenes.freeform_scene(o, seed=5), 10_000_000),
 }
 
