@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 4
+#define OT_ABI_VERSION 5
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -412,8 +412,8 @@ typedef struct ot_detector_req {
     int32_t projection;   /* OT_PROJ_*                                              */
     int32_t xy_only;      /* 1: ph is (count,2), the z plane is not written         */
     const double* crop4;  /* HOST f64[4] user extent or NULL                        */
-    double* ph;           /* device (count,3) F-order, (count,2) with xy_only       */
-    float* hw;            /* device (count)                                         */
+    double* ph;           /* device (count,3) F-order, (count,2) with xy_only; ph and hw both NULL (extent4 given):  */
+    float* hw;            /* device (count)      extent-only request, nothing but extent4 and ill_count is written   */
     double* extent4;      /* device f64[4] or NULL, initialised by the caller       */
     int64_t* ill_count;   /* device int64[2], added to                              */
 } ot_detector_req;
@@ -524,6 +524,22 @@ int ot_focus_prepare(const ot_rays* rays, int64_t first, int64_t count, double z
 int ot_focus_cost(int64_t count, const double* pasb, const float* w, int32_t mode, const double* z, int32_t nz,
                   int32_t n_px, double* workspace, double* cost, void* stream);
 int ot_focus_moments(int64_t count, const double* pasb, const float* w, double b0, double b1, double* sums, void* stream);
+
+/* ---- diagnostics ------------------------------------------------------------------------------------------
+ * The tracing loop issues f64 division and square root as their bare cores (reciprocal / reciprocal-square-root seed +
+ * the refinement steps of the IEEE sequence, without its range scaling and special-value fix-up; csrc/ot_device.hpp).
+ * Bit-exact hit masks need those cores to return the bits of IEEE `/` and sqrt on every operand the path produces.
+ * ot_selftest_arith draws n random operand sets of a class ON THE DEVICE, evaluates core and IEEE operator side by side
+ * and counts sets whose result bits differ (two NaNs count as equal); first_bad4 (HOST f64[4]) receives the operands
+ * a, b, c and the core's first result of one differing set.  mismatches is a HOST int64.
+ *   op:    0 ot_div(a, b) | 1 ot_sqrt(|a|) | 2 normalize3(a, b, c) | 3 two quotients a / c, b / c sharing one reciprocal
+ *   class: 0 uniform mantissas, exponents +-500 (sqrt: 2^-760 .. 2^1020, normalize3: +-250) | 1 mm geometry 2^-20 .. 2^14
+ *          | 2 refractive indices [1, 2.5] | 3 direction cosines near 0 and near 1
+ * ot_selftest_eval evaluates both on caller-supplied DEVICE operands (special values); outputs are (n, 3) F-order. */
+int ot_selftest_arith(int32_t op, int32_t operand_class, int64_t n, uint64_t seed, int64_t* mismatches,
+                      double* first_bad4, void* stream);
+int ot_selftest_eval(int32_t op, int64_t n, const double* a, const double* b, const double* c, double* core_out,
+                     double* ieee_out, void* stream);
 
 #ifdef __cplusplus
 }

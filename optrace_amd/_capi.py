@@ -156,10 +156,12 @@ SIGNATURES = {
     "ot_focus_prepare": (C.c_int, [C.POINTER(Rays), i64, i64, C.c_double, vp, vp, vp, vp]),
     "ot_focus_cost": (C.c_int, [i64, vp, vp, i32, C.POINTER(C.c_double), i32, i32, vp, vp, vp]),
     "ot_focus_moments": (C.c_int, [i64, vp, vp, C.c_double, C.c_double, vp, vp]),
+    "ot_selftest_arith": (C.c_int, [i32, i32, i64, u64, C.POINTER(i64), C.POINTER(C.c_double), vp]),
+    "ot_selftest_eval": (C.c_int, [i32, i64, vp, vp, vp, vp, vp, vp]),
 }
 
 FOCUS_WS = 16  # OT_FOCUS_WS
-ABI_VERSION = 4  # OT_ABI_VERSION
+ABI_VERSION = 5  # OT_ABI_VERSION
 
 _lib = None
 

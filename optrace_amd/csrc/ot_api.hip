@@ -18,6 +18,7 @@
 #include "ot_image.hpp"
 #include "ot_render_tiles.hpp"
 #include "ot_scene.hpp"
+#include "ot_selftest.hpp"
 #include "ot_spectrum.hpp"
 #include "ot_trace.hpp"
 #include "ot_trace_kernel.hpp"
@@ -1217,7 +1218,10 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
     if (first < 0 || count < 0 || first + count > rays->N) return fail(OT_ERR_INVALID, "ot_detector_hits: range outside the storage");
     for (int k = 0; k < n_reqs; k++) {
         const ot_detector_req& q = reqs[k];
-        if (!q.detector || !q.ph || !q.hw || !q.ill_count) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
+        if (!q.detector || !q.ill_count) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
+        // ph and hw both NULL: extent-only request (no hit list is written)
+        if ((!q.ph || !q.hw) && (q.ph || q.hw || !q.extent4))
+            return fail(OT_ERR_INVALID, "ot_detector_hits: ph and hw may only be NULL together, and only with extent4");
         if (q.projection < OT_PROJ_NONE || q.projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
     }
     if (int rc = require_device()) return rc;
@@ -1851,6 +1855,48 @@ extern "C" int ot_focus_moments(int64_t count, const double* pasb, const float* 
     const unsigned gs = stream_blocks(count, 256, 8);
     hipLaunchKernelGGL(focus_moments1_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, sums);
     hipLaunchKernelGGL(focus_moments2_kernel, dim3(gs), dim3(256), 0, st, count, pasb, w, b0, b1, sums);
+    HIP_TRY(hipGetLastError());
+    return OT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// diagnostics: exactness of the division / square-root cores (ot_selftest.hpp)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int ot_selftest_arith(int32_t op, int32_t operand_class, int64_t n, uint64_t seed, int64_t* mismatches,
+                                 double* first_bad4, void* stream) {
+    if (!mismatches || !first_bad4 || n < 0) return fail(OT_ERR_INVALID, "ot_selftest_arith: bad argument");
+    if (op < OT_ST_DIV || op > OT_ST_DIV_SHARED || operand_class < OT_CLS_WIDE || operand_class > OT_CLS_COSINE)
+        return fail(OT_ERR_INVALID, "ot_selftest_arith: unknown operation or operand class");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    char* scratch = nullptr;
+    HIP_TRY(hipMalloc((void**)&scratch, 64));
+    hipError_t e = hipMemsetAsync(scratch, 0, 64, st);
+    unsigned long long host[2] = {0, 0};
+    double bad[4] = {0, 0, 0, 0};
+    if (e == hipSuccess && n > 0) {
+        hipLaunchKernelGGL(selftest_arith_kernel, dim3((unsigned)(cu_count() * 8)), dim3(256), 0, st, (int)op,
+                           (int)operand_class, n, seed, (unsigned long long*)scratch, (double*)(scratch + 16));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(bad, scratch + 16, 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(scratch);
+    HIP_TRY(e);
+    *mismatches = (int64_t)host[0];
+    std::memcpy(first_bad4, bad, sizeof(bad));
+    return OT_OK;
+}
+
+extern "C" int ot_selftest_eval(int32_t op, int64_t n, const double* a, const double* b, const double* c, double* core_out,
+                                double* ieee_out, void* stream) {
+    if (n < 0 || (n && (!a || !core_out || !ieee_out))) return fail(OT_ERR_INVALID, "ot_selftest_eval: bad argument");
+    if (op < OT_ST_DIV || op > OT_ST_DIV_SHARED) return fail(OT_ERR_INVALID, "ot_selftest_eval: unknown operation");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return OT_OK;
+    hipLaunchKernelGGL(selftest_eval_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, (int)op, n, a, b, c, core_out,
+                       ieee_out);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

@@ -291,7 +291,7 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
     if (__ballot(!settled) != 0ull) {
         if (!settled) detector_hit<NUMERIC>(R, r, active, D, sp, sdir, ph, w, valid, any_ill, timeout);
     }
-    if (active) {
+    if (active && D.ph) {  // (no hit list wanted: the extent-only pass of images with an automatic extent)
         D.ph[q] = valid ? ph.x : 0.0;
         D.ph[q + count] = valid ? ph.y : 0.0;
         if (!D.xy_only) D.ph[q + 2 * count] = valid ? ph.z : 0.0;

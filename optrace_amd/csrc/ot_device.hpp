@@ -317,8 +317,8 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y, PatchCache* pc = nullptr) {
         n.z = ot_sqrt(1 - n_r * n_r);
         return n;
     }
-    double rm = sqrt(dx * dx + dy * dy);
-    double fr = ot_div(rm * sf.rho, sqrt(1 - sf.k1rho2 * (rm * rm)));
+    double rm = ot_sqrt(dx * dx + dy * dy);
+    double fr = ot_div(rm * sf.rho, ot_sqrt(1 - sf.k1rho2 * (rm * rm)));
     fr += asph_poly_deriv(sf, rm);
     const double irm = ot_rcp3(rm);
     double c = (rm > 0.0) ? ot_div_r(dx, rm, irm) : 1.0;
@@ -399,6 +399,112 @@ OT_DEV void find_hit_conic(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit) 
     }
 }
 
+// Surface.values of an AsphericSurface (surface.py:137-164 with aspheric_surface.py:51-65), the cost function of its hit
+// search.  The generic surf_values spends most of an evaluation on what an asphere does not need: the mask switch
+// over every surface kind, the edge continuation of non-symmetric surfaces, a dynamic loop that fetches one
+// coefficient per scalar-memory round trip, IEEE sqrt with its range scaling.  Here: disc mask and sag share r^2, the
+// two roots go through ot_sqrt (same bits), and the Horner steps are unrolled behind wave-uniform tests `j < ncoeff`, so
+// the coefficients are scalar registers loaded once per surface instead of once per evaluation.
+// polyval over [a_2n, 0, ..., a_2, 0, 0] is y = (y r + a) r per coefficient and one more `y r`; the reference's `+ 0`
+// steps only turn -0 into +0, which no later sum can see.
+// NC > 0: the surface has exactly NC coefficients (compile-time chain; find_hit picks the instance with one wave-uniform
+// switch outside the search loop).  NC = 0: any count, one jump into the unrolled chain per evaluation.
+template <int NC, class SF>
+struct AsphereSag {
+    SF& sf;
+    OT_DEV double operator()(double x, double y) const {
+        const double dx = x - sf.px, dy = y - sf.py;
+        const double r2 = dx * dx + dy * dy;
+        const double r = ot_sqrt(r2);
+        const double rr = r * r;
+        double z = ot_div(sf.rho * rr, 1 + ot_sqrt(1 - sf.k1rho2 * rr));
+        double y_ = 0.0;
+        if (NC > 0) {
+            y_ = sf.coeff[NC - 1] * r;  // the first step 0 r + a is a itself (a NaN or infinite r ends as NaN either way)
+#pragma unroll
+            for (int j = NC - 2; j >= 0; j--) {
+                y_ = y_ * r + sf.coeff[j];
+                y_ = y_ * r;
+            }
+        } else {
+            // Horner from the highest coefficient the surface has: one wave-uniform jump into the unrolled chain.  (The
+            // empty asm statements keep the steps from being turned into twelve always-executed select pairs.)
+#define OT_ASPH_STEP(J)               \
+    case J + 1:                       \
+        asm volatile("");             \
+        y_ = y_ * r + sf.coeff[J];    \
+        y_ = y_ * r;                  \
+        [[fallthrough]];
+            static_assert(OT_MAX_ASPH == 12, "AsphereSag unrolls twelve coefficients");
+            switch (sf.ncoeff) {
+                OT_ASPH_STEP(11) OT_ASPH_STEP(10) OT_ASPH_STEP(9) OT_ASPH_STEP(8) OT_ASPH_STEP(7) OT_ASPH_STEP(6)
+                OT_ASPH_STEP(5) OT_ASPH_STEP(4) OT_ASPH_STEP(3) OT_ASPH_STEP(2) OT_ASPH_STEP(1) OT_ASPH_STEP(0)
+                default: break;
+            }
+#undef OT_ASPH_STEP
+        }
+        y_ = y_ * r;
+        z += y_;
+        return (r2 <= sf.r_eps2) ? sf.pz + z : sf.edge_val;
+    }
+};
+
+// The Illinois iteration of Surface.find_hit (surface.py:363-405) on f(t) = z_ray(t) - values(x(t), y(t)).  The
+// reference shrinks its active set with boolean masks every iteration; here that is the wavefront's EXEC mask: the loop
+// runs while the 64-bit ballot of unconverged lanes is non-zero (one scalar branch per iteration) and converged lanes
+// idle, so a wave pays max(iterations) of its own 64 rays only.  The three cases of the update are selects inside one
+// masked block (no nested divergence), and a converged lane keeps its parameter and cost value (t_out, f_out) instead
+// of the point: the caller forms p + s t again, the same bits.
+// Returns false if a lane hit the 200-iteration timeout (surface.py:403).
+template <class EVAL>
+OT_DEV bool illinois_search(const V3& p, const V3& s, double t1, double t2, double f1, double f2, bool w, EVAL&& values,
+                            double& t_out, double& f_out) {
+    bool ok = true;
+    int it = 1;
+    while (__ballot(w) != 0ull) {
+        if (w) {
+            const double ts = t1 - ot_div(f1, f2 - f1) * (t2 - t1);
+            const double fts = (p.z + s.z * ts) - values(p.x + s.x * ts, p.y + s.y * ts);
+            const double prod = fts * f2;
+            const bool neg = prod < 0, pos = prod > 0, zero = prod == 0;  // none of them for a NaN
+            const double t1n = neg ? t2 : (zero ? ts : t1);
+            const double f1n = neg ? f2 : (pos ? 0.5 * f1 : (zero ? fts : f1));
+            const bool any = neg || pos || zero;
+            t1 = t1n;
+            f1 = f1n;
+            t2 = any ? ts : t2;
+            f2 = any ? fts : f2;
+            if (fabs(t2 - t1) < OT_C_EPS / 10) {
+                t_out = ts;
+                f_out = fts;
+                w = false;
+            }
+        }
+        if (it == OT_MAX_HIT_ITER) {  // every wave reaches this exit: the loop is bounded
+            ok = !w;
+            w = false;
+        }
+        it++;
+    }
+    return ok;
+}
+
+// the numeric branch of Surface.find_hit for an asphere with NC coefficients (0: any number); t1, t2 = the bracket
+template <int NC, class SF>
+OT_DEV bool find_hit_asphere(SF& sf, const V3& p, const V3& s, double t1, double t2, bool w0, V3& ph, bool& hit, bool& ill) {
+    const AsphereSag<NC, SF> sag = {sf};
+    const V3 p1 = along(p, s, t1), p2 = along(p, s, t2);
+    const double f1 = p1.z - sag(p1.x, p1.y), f2 = p2.z - sag(p2.x, p2.y);
+    ill = f1 * f2 > 0;
+    double tf = t1, ff = f1;  // lanes without a search end at p1 (surface.py:353-354)
+    const bool ok = illinois_search(p, s, t1, t2, f1, f2, w0, sag, tf, ff);
+    ph = along(p, s, tf);
+    const double dx = ph.x - sf.px, dy = ph.y - sf.py;
+    hit = dx * dx + dy * dy <= sf.r_eps2;
+    handle_abnormal_f(sf, p, s, ph, hit, ff);
+    return ok;
+}
+
 // Surface.find_hit surface.py:307-414.  Numeric branch = Illinois regula falsi.  The reference shrinks its
 // active set with boolean masks every iteration; on the GPU the same thing is the wavefront's EXEC mask: the
 // loop below runs while the 64-bit ballot of unconverged lanes is non-zero (one scalar branch per iteration)
@@ -426,6 +532,20 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         hit = false;
         return true;
     }
+    const double isz = ot_rcp3(s.z);
+    double t1 = ot_div_r(sf.zt1 - p.z, s.z, isz);
+    double t2 = ot_div_r(sf.zt2 - p.z, s.z, isz);
+    if (t1 < 0) t1 = -OT_C_EPS;
+    const bool w0 = isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
+    if (sf.kind == OT_SURF_ASPHERE) {  // its own copies of the search: see AsphereSag
+        switch (sf.ncoeff) {
+            case 1: return find_hit_asphere<1>(sf, p, s, t1, t2, w0, ph, hit, ill);
+            case 2: return find_hit_asphere<2>(sf, p, s, t1, t2, w0, ph, hit, ill);
+            case 3: return find_hit_asphere<3>(sf, p, s, t1, t2, w0, ph, hit, ill);
+            case 4: return find_hit_asphere<4>(sf, p, s, t1, t2, w0, ph, hit, ill);
+            default: return find_hit_asphere<0>(sf, p, s, t1, t2, w0, ph, hit, ill);
+        }
+    }
     // TiltedSurface.find_hit tilted_surface.py:91-123: closed-form plane hit first; rays that miss the disc go
     // through the generic search below (the edge is continued radially), the others sit it out
     bool pre = false;
@@ -437,60 +557,20 @@ OT_DEV bool find_hit(SF& sf, const V3& p, const V3& s, V3& ph, bool& hit, bool& 
         ph_pre = along(p, s, t);
         pre = surf_mask<TABLES>(sf, ph_pre.x, ph_pre.y) && nz0;
     }
-    const double isz = ot_rcp3(s.z);
-    double t1 = ot_div_r(sf.zt1 - p.z, s.z, isz);
-    double t2 = ot_div_r(sf.zt2 - p.z, s.z, isz);
-    if (t1 < 0) t1 = -OT_C_EPS;
-    V3 p1 = along(p, s, t1), p2 = along(p, s, t2);
+    const V3 p1 = along(p, s, t1), p2 = along(p, s, t2);
     double f1 = 0.0, f2 = 0.0;
+    auto values = [&](double x, double y) { return surf_values<LEVEL>(sf, x, y, pc); };
     if (!pre) {
-        f1 = p1.z - surf_values<LEVEL>(sf, p1.x, p1.y, pc);
-        f2 = p2.z - surf_values<LEVEL>(sf, p2.x, p2.y, pc);
+        f1 = p1.z - values(p1.x, p1.y);
+        f2 = p2.z - values(p2.x, p2.y);
     }
-    bool w = !pre && isfinite(t1) && isfinite(t2) && !((t2 - t1) < OT_C_EPS);
-    ph.x = ph.y = ph.z = 0.0;
-    if (!w) ph = p1;
-    double f_ph = f1;  // cost function at ph: at p1 for lanes without a search, re-set when a lane converges (a lane
-                       // that runs into the iteration limit fails the whole trace, surface.py:403)
     ill = !pre && f1 * f2 > 0;
-    bool ok = true;
-    int it = 1;
-    while (__ballot(w) != 0ull) {
-        if (w) {
-            double ts = t1 - ot_div(f1, f2 - f1) * (t2 - t1);
-            V3 pl = along(p, s, ts);
-            double fts = pl.z - surf_values<LEVEL>(sf, pl.x, pl.y, pc);
-            double prod = fts * f2;
-            if (prod < 0) {
-                t1 = t2;
-                t2 = ts;
-                f1 = f2;
-                f2 = fts;
-            } else if (prod > 0) {
-                t2 = ts;
-                f1 = 0.5 * f1;
-                f2 = fts;
-            } else if (prod == 0) {
-                t1 = ts;
-                t2 = ts;
-                f1 = fts;
-                f2 = fts;
-            }
-            if (fabs(t2 - t1) < OT_C_EPS / 10) {
-                ph = pl;
-                f_ph = fts;
-                w = false;
-            }
-        }
-        if (it == OT_MAX_HIT_ITER) {  // every wave reaches this exit: the loop is bounded
-            ok = !w;
-            w = false;
-        }
-        it++;
-    }
+    double tf = t1, ff = f1;
+    const bool ok = illinois_search(p, s, t1, t2, f1, f2, !pre && w0, values, tf, ff);
+    ph = along(p, s, tf);
     if (!pre) {
         hit = surf_mask<TABLES>(sf, ph.x, ph.y);
-        handle_abnormal_f(sf, p, s, ph, hit, f_ph);
+        handle_abnormal_f(sf, p, s, ph, hit, ff);
     }
     if (sf.kind == OT_SURF_TILTED) {  // tilted_surface.py:119-120: abnormal handling once more, for all rays
         if (pre) {

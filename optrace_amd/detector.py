@@ -59,6 +59,41 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
     return res
 
 
+def detector_extents(rays, first: int, count: int, requests: list) -> list:
+    """Extent of the valid hits of up to 8 detectors in one pass over the ray sections, without hit lists
+    (`ot_detector_hits_multi` with ph = hw = NULL): 52 B read per ray, nothing written.  The first half of an image with
+    an automatic extent (raytracer.py:1042-1046); the second is `detector_images` with that extent.
+    requests: dicts with surf_desc, projection.  -> list of (extent4 numpy [x0, x1, y0, y1], +-inf without a hit;
+    ill_count)."""
+    lib = _capi.load_library()
+    dev = require_device()
+    n = len(requests)
+    reqs = (_capi.DetectorReq * n)()
+    keep = []
+    ill = torch.zeros(2 * n, dtype=torch.int64, device=dev)
+    ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf] * n, dtype=torch.float64, device=dev)
+    any_numeric = False
+    for k, rq in enumerate(requests):
+        sd = rq["surf_desc"]
+        keep.append(sd)
+        r = reqs[k]
+        r.detector = C.addressof(sd)
+        r.projection = int(rq["projection"])
+        r.xy_only = 1
+        r.crop4 = None
+        r.ph, r.hw = None, None
+        r.extent4 = ext.data_ptr() + 32 * k
+        r.ill_count = ill.data_ptr() + 16 * k
+        any_numeric = any_numeric or (sd.kind >= _capi.SURF_ASPHERE and sd.z_min != sd.z_max)
+    rs = rays._rays_struct()
+    _capi.check(lib.ot_detector_hits_multi(C.byref(rs), int(first), int(count), reqs, n, stream_ptr()))
+    ext_h = ext.cpu().numpy().reshape(n, 4)
+    ill_h = ill.cpu().numpy() if any_numeric else np.zeros(2 * n, dtype=np.int64)
+    if ill_h[1::2].any():
+        raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
+    return [(ext_h[k].copy(), int(ill_h[2 * k])) for k in range(n)]
+
+
 def detector_images(rays, first: int, count: int, requests: list) -> list:
     """Hit search and binning fused (`ot_detector_images`) for detector images whose extent is known beforehand.
 

@@ -132,18 +132,75 @@ def sharded_detector_image(RT, N: int, detector_index: int = 0, extent=None, pro
     finally:
         RT.seed = seed0
     dev = RT.rays._dev["p"].device
-    det = RT.detectors[detector_index]
+    spec = dict(detector_index=detector_index, source_index=None, extent=extent, projection_method=projection_method)
     if extent is None:
-        # agree on the automatic extent first (two-pass: hit search, min/max exchange, then binning)
-        ph, hw, wl, ext, proj, ill = RT._hit_detector("Detector Image", detector_index, None, None, projection_method)
-        has = bool((hw > 0).any().item())
-        e = ext if has else np.array([np.inf, -np.inf, np.inf, -np.inf])
-        ext = allreduce_extent(np.asarray(e, dtype=np.float64), device=dev)
-        extent = list(ext) if np.all(np.isfinite(ext)) else list(det.pos[:2].repeat(2))
+        # agree on the automatic extent first: extent-only pass over the sections, min / max exchange, then the binning
+        spec = RT._auto_extents([spec], agree=lambda raw: allreduce_extents(raw, device=dev))[0]
     with global_options.no_warnings():
-        img = RT.detector_image(detector_index=detector_index, extent=extent, projection_method=projection_method,
-                                _keep_on_device=True)
+        img = RT._render_detectors([spec], [None])[0]
     allreduce_image(img._dev)
     img._sync_host()
     RT._msgs = allreduce_counters(RT._msgs, device=dev)
     return img
+
+
+def allreduce_extents(raw: np.ndarray, device=None) -> np.ndarray:
+    """Common automatic extents of all ranks for K images at once: rows [xmin, xmax, ymin, ymax], +-inf where a rank has
+    no hit.  One MIN and one MAX all-reduce of 2 K doubles each."""
+    raw = np.asarray(raw, dtype=np.float64).reshape(-1, 4)
+    if world()[1] == 1:
+        return raw
+    device = device if _device_collectives() else None
+    lo = torch.tensor(raw[:, [0, 2]].ravel(), dtype=torch.float64, device=device)
+    hi = torch.tensor(raw[:, [1, 3]].ravel(), dtype=torch.float64, device=device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    lo, hi = lo.cpu().numpy().reshape(-1, 2), hi.cpu().numpy().reshape(-1, 2)
+    return np.stack([lo[:, 0], hi[:, 0], lo[:, 1], hi[:, 1]], axis=1)
+
+
+def sharded_iterative_render(RT, N: int, detector_index=0, limit=None, projection_method="Equidistant", pos=None,
+                             extent=None, base_seed: int = 0) -> list:
+    """`Raytracer.iterative_render` (raytracer.py:1134-1279) with the N rays sharded over the ranks -- BASELINE config 4
+    as stated: every rank traces its shard ONCE (in chunks sized by its storage) and bins each chunk into all K detector
+    positions in one pass over the sections; the ranks exchange
+      * the automatic extents of the first chunk (one MIN and one MAX all-reduce of 2 K doubles; nothing with user
+        extents), so that all ranks bin into the same pixel grids -- the reference fixes the extents with its first
+        chunk in the same way (raytracer.py:1262),
+      * the K histograms, summed once at the end (one all-reduce of the stacked images when their shapes agree),
+      * the event counters.
+    The rank's rays carry its share of the source powers (ray_storage.py:160) and the seed `base_seed + rank`
+    (chunks advance it by 1000003 like the single-process form, so rank and chunk streams do not meet).
+    Returns the K images, identical on every rank; `RT._msgs` becomes the sum over all ranks."""
+    rank, ws = world()
+    first, end = shard_range(int(N), rank, ws)
+    n_local = end - first
+    if n_local <= 0:
+        raise ValueError("fewer rays than ranks")
+    seed0 = RT.seed
+    RT.seed = base_seed + rank
+    dev = None
+    try:
+        images = RT.iterative_render(n_local, detector_index=detector_index, limit=limit,
+                                     projection_method=projection_method, pos=pos, extent=extent,
+                                     _power_scale=n_local / N, _finish=False,
+                                     _agree_extents=lambda raw: allreduce_extents(raw, device=RT.rays._dev["p"].device))
+    finally:
+        RT.seed = seed0
+    dev = RT.rays._dev["p"].device
+    if ws > 1:
+        shapes = {tuple(img._dev.shape) for img in images}
+        if len(shapes) == 1 and len(images) > 1:  # the usual case: one exchange for all positions
+            stack = torch.stack([img._dev for img in images])
+            allreduce_image(stack)
+            for k, img in enumerate(images):
+                img._dev.copy_(stack[k])
+        else:
+            for img in images:
+                allreduce_image(img._dev)
+    RT._msgs = allreduce_counters(RT._msgs, device=dev)
+    for img in images:
+        img._sync_host()
+        if img._limit is not None:
+            img._apply_rayleigh_filter()
+    return images

@@ -465,7 +465,8 @@ class Raytracer(Group):
         return out
 
     def _render_detectors(self, specs: list, limits: list, into: list = None, **kwargs) -> list:
-        """Detector images whose extents are known beforehand (every spec carries a user extent): hit search and
+        """Detector images whose extents are known beforehand (every spec carries a user extent, or the automatic
+        one of `_auto_extents` as "auto_extent"): hit search and
         binning in ONE pass over the ray sections (`ot_detector_images`), up to 8 images per pass; the hit positions
         are never written to memory.  into: per spec a (Ny, Nx, 4) device histogram to add to, or None.
         -> RenderImages (raytracer.py:1053-1098 for each spec)."""
@@ -476,7 +477,9 @@ class Raytracer(Group):
             label = rq["desc"]
             if sp.get("source_index") is not None:
                 label = f"Rays from RS{sp['source_index']} at {label}"
-            img = RenderImage(extent=rq["crop"], projection=rq["projection"], long_desc=label)
+            # the image extent: the user extent hits are cropped to, or an automatic one (`_auto_extents`: no crop)
+            img = RenderImage(extent=rq["crop"] if rq["crop"] is not None else sp["auto_extent"],
+                              projection=rq["projection"], long_desc=label)
             img._limit = limit
             img._fix_extent()
             Nx, Ny = img._pixel_counts()
@@ -505,6 +508,34 @@ class Raytracer(Group):
                     img._apply_rayleigh_filter()
         return images
 
+    def _auto_extents(self, specs: list, agree=None) -> list:
+        """Automatic extents (raytracer.py:1042-1049) of the specs without a user extent, from an extent-only pass over
+        the ray sections (no hit list: `detector.detector_extents`, up to 8 detectors per pass).  `agree`: callable
+        mapping the (n, 4) array of raw extents (+-inf where no ray hits) to the one every rank uses
+        (distributed.py); an extent no ray reaches collapses to the detector centre.  -> specs with "auto_extent" set."""
+        todo = [n for n, sp in enumerate(specs) if sp.get("extent") is None]
+        if not todo:
+            return specs
+        reqs = self._detector_requests(specs)
+        raw = np.empty((len(todo), 4), dtype=np.float64)
+        groups: dict = {}
+        for m, n in enumerate(todo):
+            groups.setdefault((reqs[n]["Ns"], reqs[n]["Ne"]), []).append(m)
+        for (Ns, Ne), ms in groups.items():
+            for b in range(0, len(ms), 8):
+                part = ms[b:b + 8]
+                res = _detector.detector_extents(self.rays, Ns, Ne - Ns, [
+                    dict(surf_desc=reqs[todo[m]]["surf_desc"], projection=_capi.PROJECTIONS[reqs[todo[m]]["projection"]])
+                    for m in part])
+                for m, (ext4, _) in zip(part, res):
+                    raw[m] = ext4
+        if agree is not None:
+            raw = np.asarray(agree(raw), dtype=np.float64).reshape(len(todo), 4)
+        out = [dict(sp) for sp in specs]
+        for m, n in enumerate(todo):
+            out[n]["auto_extent"] = raw[m].copy() if np.all(np.isfinite(raw[m])) else reqs[n]["centre"]
+        return out
+
     def _hit_detector(self, info: str, detector_index: int = 0, source_index: int = None, extent=None,
                       projection_method: str = "Equidistant"):
         """One detector: (ph, hw, wl, extent_out, projection, ill_count), see `_hit_detectors`."""
@@ -530,7 +561,11 @@ class Raytracer(Group):
                     " are not included in the convolution calculation.")
         spec = dict(detector_index=detector_index, source_index=source_index, extent=extent,
                     projection_method=projection_method)
-        if extent is not None and not kwargs.get("_unfused", False):  # extent known: one pass, no hit positions in memory
+        if not kwargs.get("_unfused", False):
+            # extent known: hit search and binning in one pass, no hit positions in memory; an automatic extent comes
+            # from an extent-only pass first (52 B read per ray, nothing written) instead of a hit list
+            if extent is None:
+                spec = self._auto_extents([spec])[0]
             return self._render_detectors([spec], [limit], **kwargs)[0]
         kwargs.pop("_unfused", None)
         hits = self._hit_detectors("Detector Image", [spec])[0]
@@ -707,7 +742,7 @@ class Raytracer(Group):
 
     # ---- iterative rendering (raytracer.py:1134-1279) -------------------------------------------------------
     def iterative_render(self, N, detector_index=0, limit=None, projection_method="Equidistant", pos=None,
-                         extent=None) -> list:
+                         extent=None, _power_scale: float = 1.0, _agree_extents=None, _finish: bool = True) -> list:
         """Render detector images from N rays traced in chunks of ITER_RAYS_STEP; images of all chunks
         are summed (the extent of the first chunk fixes later ones)."""
         if not self.ray_sources:
@@ -768,7 +803,7 @@ class Raytracer(Group):
             if i == iterations - 1:
                 rays_step += int(N - iterations * rays_step)
             with global_options.no_warnings():
-                self.trace(N=rays_step, _chunk=i)
+                self.trace(N=rays_step, _chunk=i, _power_scale=_power_scale)
                 msgs_cum += self._msgs
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
@@ -785,15 +820,9 @@ class Raytracer(Group):
                     # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
                     direct = 0 < i and rays_step == step0
                     into = [images[j]._dev if direct else None for j in group]
-                    if all(extentc[j] is not None for j in group):
-                        imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, _dont_filter=True)
-                    else:
-                        hits = self._hit_detectors("Detector Image", specs)
-                        imgs = []
-                        for g, j in enumerate(group):
-                            imgs.append(self._image_from_hits(hits[g], detector_index[j], None, limit[j],
-                                                              _dont_filter=True, _into=into[g]))
-                            hits[g] = None
+                    if not all(extentc[j] is not None for j in group):  # first chunk: extents from their own pass
+                        specs = self._auto_extents(specs, agree=_agree_extents)
+                    imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, _dont_filter=True)
                     for g, j in enumerate(group):
                         img = imgs[g]
                         if i == 0:
@@ -810,11 +839,13 @@ class Raytracer(Group):
             for img in images:
                 img._dev *= scale0
 
+        self._msgs = msgs_cum
+        if not _finish:  # distributed.sharded_iterative_render: histograms still on the device, summed over the ranks first
+            return images
         for i, img in enumerate(images):
             img._sync_host()
             if limit[i] is not None:
                 img._apply_rayleigh_filter()
 
-        self._msgs = msgs_cum
         self._show_messages(N)
         return images

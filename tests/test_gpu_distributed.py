@@ -126,6 +126,104 @@ def test_sharded_detector_image_equals_single_process_composition(tmp_path, worl
         assert abs(got["empty_extent"][:2].mean() - 1500) < 1.0  # collapsed onto the detector centre, then widened
 
 
+# ---- sharded iterative render: BASELINE config 4 as stated (trace once per rank, K positions, one histogram exchange) ----
+_WORKER_ITER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+root, backend, out, extent, N, base_seed = sys.argv[1:7]
+sys.path[:0] = [root, root + "/tests"]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group(backend)
+import optrace_amd as ot
+from optrace_amd import distributed as D
+import scenes
+with ot.global_options.no_warnings():
+    RT = scenes.double_gauss(ot)
+    RT.ITER_RAYS_STEP = 30_000  # several chunks per rank
+    z0 = RT.detectors[0].pos[2]
+    pos = [[0, 0, z0 - 3], [0, 0, z0], [0, 0, z0 + 3]]
+    ext = None if extent == "auto" else [-45., 45., -45., 45.]
+    traces = []
+    trace0 = RT.trace
+    def counting_trace(*a, **k):
+        traces.append(k.get("N", a[0] if a else None))
+        return trace0(*a, **k)
+    RT.__dict__["trace"] = counting_trace  # (instance attribute, no tracked assignment)
+    imgs = D.sharded_iterative_render(RT, int(N), pos=pos, extent=ext, base_seed=int(base_seed))
+    n_local = D.shard_range(int(N), rank, world)
+    n_local = n_local[1] - n_local[0]
+    assert sum(traces) == n_local, "every rank traces its shard exactly once, whatever the number of positions"
+if rank == 0:
+    np.savez(out, data=np.stack([im._data for im in imgs]), extent=np.stack([np.asarray(im.extent) for im in imgs]),
+             msgs=RT._msgs)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _single_process_iter(world, extent):
+    """The shards rendered one after the other in this process (same seeds, same chunks), images added.  The common
+    automatic extents come from the two-step hit lists of every shard's first chunk."""
+    import optrace_amd as ot
+    from optrace_amd import distributed as D
+    import scenes
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot)
+        RT.ITER_RAYS_STEP = 30_000
+        z0 = RT.detectors[0].pos[2]
+        pos = [[0, 0, z0 - 3], [0, 0, z0], [0, 0, z0 + 3]]
+        shards = [D.shard_range(N_RAYS, r, world) for r in range(world)]
+        agreed = None
+        if extent is None:
+            lo = np.full((3, 2), np.inf)
+            hi = -lo
+            for r, (a, b) in enumerate(shards):
+                RT.seed = BASE_SEED + r
+                RT.trace(30_000, _chunk=0, _power_scale=(b - a) / N_RAYS)
+                for k, p in enumerate(pos):
+                    e = RT._hit_detectors("Detector Image", [dict(detector_index=0, extent=None, pos=p,
+                                                                  projection_method="Equidistant")])[0][3]
+                    lo[k], hi[k] = np.minimum(lo[k], e[[0, 2]]), np.maximum(hi[k], e[[1, 3]])
+            agreed = np.stack([lo[:, 0], hi[:, 0], lo[:, 1], hi[:, 1]], axis=1)
+        total, msgs, exts = None, 0, None
+        for r, (a, b) in enumerate(shards):
+            RT.seed = BASE_SEED + r
+            imgs = RT.iterative_render(b - a, pos=pos, extent=extent, _power_scale=(b - a) / N_RAYS,
+                                       _agree_extents=None if agreed is None else (lambda raw: agreed))
+            d = np.stack([im._data for im in imgs])
+            total = d if total is None else total + d
+            msgs = msgs + RT._msgs
+            exts = np.stack([np.asarray(im.extent) for im in imgs])
+    return total, exts, msgs
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,backend,extent", [(2, "gloo", "user"), (2, "gloo", "auto"), (1, "nccl", "auto")])
+def test_sharded_iterative_render_equals_single_process_composition(tmp_path, world, backend, extent):
+    """K = 3 detector positions, several chunks per rank, user and automatic extents (raytracer.py:1134-1279)."""
+    script = tmp_path / "worker_iter.py"
+    script.write_text(_WORKER_ITER)
+    out = tmp_path / f"iter_{world}_{backend}_{extent}.npz"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script),
+           str(ROOT), backend, str(out), extent, str(N_RAYS), str(BASE_SEED)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = np.load(out)
+    ref, ref_ext, ref_msgs = _single_process_iter(world, None if extent == "auto" else [-45., 45., -45., 45.])
+    assert np.array_equal(got["msgs"], ref_msgs), "summed counters of the ranks = counters of the shards"
+    np.testing.assert_allclose(got["extent"], ref_ext, rtol=1e-12, atol=1e-12)
+    assert got["data"].shape == ref.shape and got["data"].shape[0] == 3
+    assert np.array_equal(got["data"][..., 3] > 0, ref[..., 3] > 0), "same pixels lit"
+    np.testing.assert_allclose(got["data"], ref, rtol=1e-9, atol=1e-12 * ref.max())
+    for k in range(3):  # every position sees the full source power minus what the system absorbs
+        assert 0.3 < got["data"][k, ..., 3].sum() <= 5.0
+
+
 @pytest.mark.timeout(900)
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a torch.distributed environment starts two ranks itself (they share the

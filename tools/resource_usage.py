@@ -19,7 +19,7 @@ KEYS = [("VGPRs", r"\bVGPRs: (\d+)"), ("AGPRs", r"AGPRs: (\d+)"), ("sgpr_spill",
 
 
 def demangle(names):
-    r = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True)
+    r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
     out = r.stdout.split("\n")
     return [re.sub(r"\(.*$", "", o) for o in out[:len(names)]]
 
