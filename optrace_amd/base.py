@@ -38,6 +38,8 @@ def check_in(key: str, val, choices) -> None:
 
 _EPOCH = [0]
 _SAW_WRITEABLE = [False]  # set by crepr when it meets a large array that can still be edited in place
+_WATCH = [None]           # [list or None]: while a list, crepr adds the small arrays it meets that can still be edited in
+                          # place (RaySource.s, conv_pos, the outline); Raytracer.trace collects them for its shortcut
 
 
 def mutation_epoch() -> int:
@@ -82,7 +84,11 @@ class BaseClass:
             if isinstance(v, BaseClass):
                 return v.crepr()
             if isinstance(v, np.ndarray):
-                return tuple(v.ravel().tolist()) if v.size < 20 else _array_token(v)
+                if v.size >= 20:
+                    return _array_token(v)
+                if v.flags.writeable and _WATCH[0] is not None:  # the reference re-reads such arrays at every trace
+                    _WATCH[0].append(v)
+                return tuple(v.ravel().tolist())
             if isinstance(v, list):
                 return tuple(v)
             return id(v) if callable(v) else v

@@ -582,6 +582,8 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
             guides.push_back((int32_t)j);
         }
     };
+    struct PickRef { size_t off; int src; };
+    std::vector<PickRef> pick_refs;
     bool any_rgb = false;
     for (int i = 0; i < n_sources; i++) {
         const ot_source& s = sources[i];
@@ -658,38 +660,52 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
         if (s.shape == OT_SRC_IMAGE_RGB || s.shape == OT_SRC_IMAGE_GRAY) {
             size_t npx = (size_t)s.img_w * (size_t)s.img_h;
             if (!s.img_pdf || npx < 1) return fail(OT_ERR_INVALID, "image source: pixel pdf missing");
-            std::vector<double> cdf(npx);
+            if (s.shape == OT_SRC_IMAGE_RGB && !s.img_rgb) return fail(OT_ERR_INVALID, "RGB image source: pixel colours missing");
+            std::vector<double> rec(4 * npx, 0.0);
             double acc = 0.0;  // np.cumsum of the pixel pdf (random.py:133 on f_ = f[f > 0]; zero-weight pixels
+            const double fr = 0.885651229244, fb = 0.775993481741;  // srgb.py:24-26
             for (size_t j = 0; j < npx; j++) {  // keep the running sum and can never be selected by "next")
                 acc += s.img_pdf[j];
-                cdf[j] = acc;
-            }
-            offs[i][3] = push(cdf.data(), npx);
-            add_guide(cdf.data(), npx, 0.0, &d.g_img);
-            if (s.shape == OT_SRC_IMAGE_RGB) {
-                if (!s.img_rgb) return fail(OT_ERR_INVALID, "RGB image source: pixel colours missing");
-                std::vector<double> mix(2 * npx);
-                const double fr = 0.885651229244, fb = 0.775993481741;  // srgb.py:24-26
-                for (size_t j = 0; j < npx; j++) {
+                rec[4 * j] = acc;
+                if (s.shape == OT_SRC_IMAGE_RGB) {  // color.random_wavelengths_from_srgb srgb.py:522-541
                     double r = srgb_to_linear(s.img_rgb[3 * j]) * fr;
                     double g = srgb_to_linear(s.img_rgb[3 * j + 1]);
                     double b = srgb_to_linear(s.img_rgb[3 * j + 2]) * fb;
                     double c0 = r, c1 = r + g, c2 = r + g + b;
                     double den = (c2 != 0.0) ? c2 : 1.0;
-                    mix[2 * j] = c0 / den;
-                    mix[2 * j + 1] = c1 / den;
+                    rec[4 * j + 1] = c0 / den;
+                    rec[4 * j + 2] = c1 / den;
                 }
-                offs[i][4] = push(mix.data(), 2 * npx);
-                any_rgb = true;
             }
+            if (tabs.size() & 1) tabs.push_back(0.0);  // PixRec is read with 16-byte loads
+            offs[i][3] = push(rec.data(), rec.size());
+            // bucket table of the pixel pick: K ~ 4 buckets per pixel; pick_lo[b] = pixels whose own bucket lies before b.
+            // The bucket of a value is the DEVICE's expression (pixel_bucket, monotone in X), so for X in bucket b every
+            // pixel before pick_lo[b] has F < X and every pixel from pick_lo[b + 1] on has F > X.
+            size_t K = 16;
+            while (K < 4 * npx && K < ((size_t)1 << 22)) K <<= 1;
+            d.pick_K = (int32_t)K;
+            d.pix_total = acc;
+            d.pick_scale = (acc > 0.0) ? (double)K / acc : 0.0;
+            pick_refs.push_back({guides.size(), i});
+            size_t j = 0;
+            for (size_t b = 0; b <= K; b++) {
+                while (j < npx && (size_t)pixel_bucket(rec[4 * j], d.pick_scale, (int)K) < b) j++;
+                guides.push_back((int32_t)j);
+            }
+            any_rgb = any_rgb || s.shape == OT_SRC_IMAGE_RGB;
         }
     }
-    size_t prim_off = (size_t)-1, prim_pairs_off = (size_t)-1;
-    if (any_rgb) {  // inverse-CDF tables of the three primaries over wavelengths(5000) (srgb.py:528, 549-551)
-        std::vector<double> prim(3 * 2 * OT_PRIM_N);
+    size_t prim_off = (size_t)-1;
+    if (any_rgb) {
+        // The three primaries over wavelengths(5000) (srgb.py:528, 549-551): cumulative trapezoid F_j, and the inverse
+        // x(F) the reference interpolates linearly between its nodes (random.py:150-157) sampled at OT_PRIM_M + 1
+        // equidistant values of the uniform variable.  Between two samples the device interpolates linearly as well:
+        // exact where no node lies between them, elsewhere off by less than the spacing of the reference's own
+        // wavelength grid (0.08 nm) except in the few buckets of the far tails (1.5e-5 of the rays each).
+        std::vector<double> inv(3 * (size_t)(OT_PRIM_M + 1));
+        std::vector<double> x(OT_PRIM_N), F(OT_PRIM_N);
         for (int c = 0; c < 3; c++) {
-            double* x = prim.data() + (size_t)c * 2 * OT_PRIM_N;
-            double* F = x + OT_PRIM_N;
             double prev = 0.0;
             for (int j = 0; j < OT_PRIM_N; j++) {
                 x[j] = 380.0 + (780.0 - 380.0) * (double)j / (double)(OT_PRIM_N - 1);
@@ -697,16 +713,16 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
                 F[j] = (j == 0) ? 0.0 : F[j - 1] + (f + prev) / 2;
                 prev = f;
             }
+            double* o = inv.data() + (size_t)c * (OT_PRIM_M + 1);
+            int lo = 0;
+            for (int m = 0; m <= OT_PRIM_M; m++) {
+                const double X = F[0] + ((double)m / (double)OT_PRIM_M) * (F[OT_PRIM_N - 1] - F[0]);
+                while (lo < OT_PRIM_N - 2 && F[lo + 1] <= X) lo++;
+                const double dF = F[lo + 1] - F[lo];
+                o[m] = (dF > 0) ? x[lo] + (X - F[lo]) / dF * (x[lo + 1] - x[lo]) : x[lo];
+            }
         }
-        prim_off = push(prim.data(), prim.size());
-        prim_pairs_off = tabs.size();
-        for (int c = 0; c < 3; c++) push_pairs(prim.data() + (size_t)c * 2 * OT_PRIM_N, OT_PRIM_N);
-        for (int i = 0; i < n_sources; i++)
-            if (sources[i].shape == OT_SRC_IMAGE_RGB)
-                for (int c = 0; c < 3; c++) {
-                    const double* F = prim.data() + (size_t)c * 2 * OT_PRIM_N + OT_PRIM_N;
-                    add_guide(F, OT_PRIM_N, F[0], &devs[i].g_prim[c]);
-                }
+        prim_off = push(inv.data(), inv.size());
     }
 
     size_t o_tab = align_up(sizeof(SourceDev) * n_sources);
@@ -716,15 +732,14 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
     HIP_TRY(hipMalloc((void**)&blob, total));
     const double* dtab = (const double*)(blob + o_tab);
     for (const GuideRef& r : grefs) r.dst->g = (const int32_t*)(blob + o_guide) + r.off;
+    for (const PickRef& r : pick_refs) devs[r.src].pick_lo = (const int32_t*)(blob + o_guide) + r.off;
     for (int i = 0; i < n_sources; i++) {
         SourceDev& d = devs[i];
         if (offs[i][0] != (size_t)-1) d.spec_tab = dtab + offs[i][0];
         if (offs[i][1] != (size_t)-1) d.pol_tab = dtab + offs[i][1];
         if (offs[i][2] != (size_t)-1) d.div_tab = dtab + offs[i][2];
-        if (offs[i][3] != (size_t)-1) d.img_cdf = dtab + offs[i][3];
-        if (offs[i][4] != (size_t)-1) d.img_rgb = dtab + offs[i][4];
-        if (prim_off != (size_t)-1) d.prim_tab = dtab + prim_off;
-        if (prim_pairs_off != (size_t)-1) d.prim_pairs = dtab + prim_pairs_off;
+        if (offs[i][3] != (size_t)-1) d.pix_rec = dtab + offs[i][3];
+        if (prim_off != (size_t)-1) d.prim_inv = dtab + prim_off;
         if (offs[i][6] != (size_t)-1) d.spec_pairs = dtab + offs[i][6];
         if (offs[i][7] != (size_t)-1) d.pol_pairs = dtab + offs[i][7];
         if (offs[i][8] != (size_t)-1) d.div_pairs = dtab + offs[i][8];
@@ -742,6 +757,8 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
     so->d = (SourceDev*)blob;
     so->n = n_sources;
     so->blob = blob;
+    so->has_image = false;
+    for (int i = 0; i < n_sources; i++) so->has_image = so->has_image || sources[i].shape >= OT_SRC_IMAGE_RGB;
     so->n_or = new int64_t[n_sources];
     so->power = new double[n_sources];
     for (int i = 0; i < n_sources; i++) {
@@ -1042,7 +1059,8 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
     const bool tab = sc->needs_tables || hurb_normals != nullptr;
     // spline scenes always take the full variant: at ~250 VGPRs the ideal-lens / filter / HURB code costs them nothing
     const int feat = OT_FEAT(sc->hit_level, sc->needs_full || sc->hit_level == OT_HIT_SPLINE);
-    bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr;  // generated rays only
+    // discrete-spectrum kernels: generated rays only, and no image source (their variant of the generator has none)
+    bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr && !src->has_image;
     // dynamic LDS: the counter table, and with discrete spectra the per-line tables (3 rows per step).  Very long
     // stacks do not fit the 64 KB a kernel gets without asking: the formula kernels (SPEC 0 / 1) trace those.
     const size_t lds_cnt = sizeof(unsigned int) * (size_t)n_cnt + 8;

@@ -162,9 +162,9 @@ OT_DEV void fill_dither(GenCtx& g, bool need_b, bool image) {
 }
 
 // which Philox blocks a source needs (see dither_slot)
-template <class SRC>
+template <bool IMAGES = true, class SRC>
 OT_DEV void fill_dither_for(GenCtx& g, SRC& src) {
-    const bool image = src.shape >= OT_SRC_IMAGE_RGB;
+    const bool image = IMAGES && src.shape >= OT_SRC_IMAGE_RGB;
     const bool extended = src.shape != OT_SRC_POINT && !image;
     fill_dither(g, extended || (src.divergence != OT_DIV_NONE && src.div_2d), image);
 }
@@ -285,15 +285,75 @@ struct NewRay {
     float w, wl;
 };
 
-// RaySource.create_rays ray_source.py:204-437 for ray j of a range of n rays of source `src`
+// ---- image sources: pixel by inverse CDF in two memory round trips ------------------------------------------------
+// bucket of a value of the cumulative pixel pdf; the host builds SourceDev::pick_lo with this very expression
+OT_HD int pixel_bucket(double X, double scale, int K) {
+    const double t = X * scale;
+    return (t > 0.0) ? ((t < (double)(K - 1)) ? (int)t : K - 1) : 0;
+}
+
+struct alignas(16) PixRec {  // SourceDev::pix_rec
+    double F, c_r, c_rg, pad;
+};
+
+// random.inverse_transform_sampling random.py:113-159, kind="discrete", for the pixel of an image source: the first
+// pixel whose cumulative weight reaches X (scipy interp1d kind="next").  Round trip 1 fetches the bucket's pixel range
+// [lo, hi]; round trip 2 the records of pixels lo and lo + 1 -- cumulative weight AND colours, so whichever of the two
+// it is (four buckets per pixel: nearly always) nothing more has to be fetched.  (Before: bucket hint, then a walk over
+// the cumulative table in dependent loads, then the colours of the pixel found: four and more round trips, and the
+// few-surface kernels are bound by exactly this latency chain -- profiles/r2/sq_configs.txt.)
+struct PixelPick {
+    double X;
+    int lo, hi;
+};
+
 template <class SRC>
+OT_DEV PixelPick pixel_pick_issue(SRC& src, const GenCtx& g, double X) {
+    PixelPick pk;
+    pk.X = X;
+    const int b = pixel_bucket(X, src.pick_scale, src.pick_K);
+    pk.lo = src.pick_lo[b];
+    pk.hi = src.pick_lo[b + 1];
+    return pk;
+}
+
+template <class SRC>
+OT_DEV uint32_t pixel_pick_finish(SRC& src, const PixelPick& pk, int npx, const PixRec& r0, const PixRec& r1, PixRec& rec) {
+    int P = pk.lo;
+    rec = r0;
+    const int hi = pk.hi < npx - 1 ? pk.hi : npx - 1;
+    if (P < hi && rec.F < pk.X) {
+        P++;
+        rec = r1;
+        const PixRec* recs = (const PixRec*)src.pix_rec;
+        while (P < hi && rec.F < pk.X) {  // more than one pixel inside one bucket: dark pixels
+            P++;
+            rec = recs[P];
+        }
+    }
+    return (uint32_t)P;
+}
+
+// RaySource.create_rays ray_source.py:204-437 for ray j of a range of n rays of source `src`.
+// Image sources need three dependent memory round trips (pixel range, pixel records, wavelength of the primary); the
+// function is laid out so that everything that does not depend on them -- in-pixel jitter, the divergence sample, the
+// polarisation angle, later the frames and the direction -- is computed while they are in flight.
+// IMAGES = false: a variant without the image sources (the discrete-spectrum kernels: the host sends scenes with an
+// image source to the formula kernels, and the bench kernel keeps the 76 registers it needs without that path).
+template <bool IMAGES = true, class SRC>
 OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
     NewRay o;
     o.w = g.w;  // power / N, ray_source.py:220
+    const bool image = IMAGES && src.shape >= OT_SRC_IMAGE_RGB;
+    const uint32_t npx = image ? (uint32_t)src.img_w * (uint32_t)src.img_h : 0u;
+
+    // ---- image sources, round trip 1: the pixel range of this ray's stratified uniform variable (ray_source.py:243-245)
+    PixelPick pk = {0.0, 0, 0};
+    if (image && npx > 1) pk = pixel_pick_issue(src, g, strat_interval(g, ST_PIXEL, 0.0, src.pix_total));
 
     // ---- wavelength (light_spectrum.py:81-138) ----
     double wl = 0.0;
-    if (src.shape != OT_SRC_IMAGE_RGB) {
+    if (!IMAGES || src.shape != OT_SRC_IMAGE_RGB) {
         switch (src.spectrum) {
             case OT_SPEC_MONO: wl = (double)(float)src.wl; break;
             case OT_SPEC_UNIFORM: wl = strat_interval(g, ST_WL, src.wl0, src.wl1); break;
@@ -316,93 +376,27 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         }
     }
 
-    // ---- start position (ray_source.py:229-255) ----
-    V3 p = {src.pos[0], src.pos[1], src.pos[2]};
-    switch (src.shape) {
-        case OT_SRC_POINT: break;
-        case OT_SRC_LINE: {
-            double t = strat_interval(g, ST_POS, -src.r, src.r);
-            p.x += src.ca * t;
-            p.y += src.sa * t;
-            break;
-        }
-        case OT_SRC_CIRCLE:
-        case OT_SRC_RING: {
-            double x, y;
-            strat_ring(g, ST_POS, src.shape == OT_SRC_RING ? src.ri : 0.0, src.r, false, x, y);
-            p.x += x;
-            p.y += y;
-            break;
-        }
-        case OT_SRC_RECT: {
-            double x, y;
-            strat_rect(g, ST_POS, -src.dim[0] / 2, src.dim[0] / 2, -src.dim[1] / 2, src.dim[1] / 2, x, y);
-            p.x += x * src.ca - y * src.sa;
-            p.y += x * src.sa + y * src.ca;
-            break;
-        }
-        default: {  // image sources: pixel by inverse CDF, uniform inside the pixel
-            uint32_t npx = (uint32_t)src.img_w * (uint32_t)src.img_h;
-            uint32_t P = 0;
-            if (npx > 1) {
-                double X = strat_interval(g, ST_PIXEL, 0.0, src.img_cdf[npx - 1]);
-                P = (uint32_t)cdf_index_discrete(src.img_cdf, (int)npx, X, src.g_img);
-            }
-            uint32_t PY = P / (uint32_t)src.img_w, PX = P - PY * (uint32_t)src.img_w;
-            double rx, ry;
-            strat_rect(g, ST_PIX_JITTER, 0.0, 1.0, 0.0, 1.0, rx, ry);
-            double xs = src.pos[0] - src.dim[0] / 2, ys = src.pos[1] - src.dim[1] / 2;
-            p.x = src.px_w * ((double)PX + rx) + xs;
-            p.y = src.px_h * ((double)PY + ry) + ys;
-            if (src.shape == OT_SRC_IMAGE_RGB) {  // color.random_wavelengths_from_srgb srgb.py:513-553
-                double choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
-                double c_r = src.img_rgb[2 * (size_t)P], c_rg = src.img_rgb[2 * (size_t)P + 1];
-                int prim = (choice < c_r) ? 0 : ((choice > c_rg) ? 2 : 1);
-                const double* tab = src.prim_tab + (size_t)prim * 2 * OT_PRIM_N;
-                const double* F = tab + OT_PRIM_N;
-                // The reference stratifies the wavelengths of each primary over exactly the rays that got that primary
-                // (srgb.py:549-551), which keeps the colour noise of an image far below 1 / sqrt(rays per primary).  The
-                // stratified choice variable carries that for free: inside the sub-interval that selected the primary it is
-                // itself a stratified uniform variable over that primary's rays (exactly so for equal pixel colours).
-                const double lo = (prim == 0) ? 0.0 : ((prim == 1) ? c_r : c_rg);
-                const double hi = (prim == 0) ? c_r : ((prim == 1) ? c_rg : 1.0);
-                const double t = (hi > lo) ? ot_div(choice - lo, hi - lo) : 0.5;
-                double X = F[0] + t * (F[OT_PRIM_N - 1] - F[0]);
-                wl = inv_cdf_linear(src.prim_pairs + (size_t)prim * 2 * OT_PRIM_N, OT_PRIM_N, X, src.g_prim[prim]);
-            }
-        }
+    // ---- image sources: in-pixel position and the choice of the primary (no memory involved) ----
+    double rx = 0.0, ry = 0.0, choice = 0.0;
+    if (image) {
+        strat_rect(g, ST_PIX_JITTER, 0.0, 1.0, 0.0, 1.0, rx, ry);
+        if (src.shape == OT_SRC_IMAGE_RGB) choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
     }
-    o.p = p;
-    o.wl = (float)wl;
-
-    // ---- orientation (ray_source.py:264-277) ----
-    V3 s_or;
-    if (src.frame_uniform) {  // one base orientation for the whole source (host): constant, or a point source converging
-        s_or.x = src.s[0];
-        s_or.y = src.s[1];
-        s_or.z = src.s[2];
-    } else if (src.orientation == OT_OR_CONVERGING) {
-        V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
-        const double il = ot_rcp3(ot_sqrt(d.x * d.x + d.y * d.y + d.z * d.z));
-        s_or.x = d.x * il;
-        s_or.y = d.y * il;
-        s_or.z = d.z * il;
-    } else if (src.orientation == OT_OR_ARRAY && src.s_or) {  // or_func(x, y) evaluated by the caller (:272-274)
-        s_or.x = src.s_or[g.j];
-        s_or.y = src.s_or[g.j + src.n_or];
-        s_or.z = src.s_or[g.j + 2 * src.n_or];
-    } else {
-        s_or.x = src.s[0];
-        s_or.y = src.s[1];
-        s_or.z = src.s[2];
+    // ---- image sources, round trip 2: the records of the first two pixels of the range ----
+    PixRec r0 = {0.0, 0.0, 0.0, 0.0}, r1 = r0;
+    if (image && npx > 1) {
+        const PixRec* recs = (const PixRec*)src.pix_rec;
+        r0 = recs[pk.lo];
+        r1 = recs[pk.lo + 1 < (int)npx ? pk.lo + 1 : pk.lo];
+    } else if (image) {
+        r0 = ((const PixRec*)src.pix_rec)[0];
     }
 
-    // ---- divergence (ray_source.py:290-351) ----
-    V3 s = s_or;
-    if (src.divergence != OT_DIV_NONE) {
-        // sin / cos of the polar angle theta and of the azimuth alpha; where the reference goes through
-        // asin / acos and back (ray_source.py:303-320, 343-351) the pair is formed algebraically
-        double st, ct, sa, ca;
+    // ---- divergence sample (ray_source.py:290-351): sin / cos of the polar angle theta and of the azimuth alpha; where
+    // the reference goes through asin / acos and back (ray_source.py:303-320, 343-351) the pair is formed algebraically
+    double st = 0.0, ct = 1.0, sa = 0.0, ca = 1.0;
+    auto divergence_sample = [&]() {
+        if (src.divergence == OT_DIV_NONE) return;
         if (src.div_2d) {
             double X = strat_interval(g, ST_DIV_ALPHA, 0.0, 2.0);
             const double sgn = (X <= 1.0) ? 1.0 : -1.0;  // alpha = div_axis or div_axis + pi
@@ -447,7 +441,123 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 }
             }
         }
-        V3 sx, sy;  // the frame around s_or (ray_source.py:339-341): sy = [1, 0, 0] x s_or, sx = s_or x sy
+    };
+
+    // ---- polarisation angle (ray_source.py:359-385) ----
+    double psn = 0.0, pcs = 1.0;
+    auto polarization_angle = [&]() {
+        if (no_pol) return;
+        switch (src.polarization) {
+            case OT_POL_CONSTANT:
+                pcs = src.pol_cos;
+                psn = src.pol_sin;
+                break;
+            case OT_POL_UNIFORM: sincospi_small(strat_interval(g, ST_POL, 0.0, 2.0), &psn, &pcs); break;  // angle in [0, 2 pi)
+            case OT_POL_LIST: {
+                const double* F = src.pol_tab + src.n_pol;
+                double ang = inv_cdf_discrete(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, 0.0, F[src.n_pol - 1]), src.g_pol);
+                sincos(ang, &psn, &pcs);
+                break;
+            }
+            default: {
+                const double* F = src.pol_tab + src.n_pol;
+                double ang = inv_cdf_linear(src.pol_pairs, (int)src.n_pol, strat_interval(g, ST_POL, F[0], F[src.n_pol - 1]), src.g_pol);
+                sincos(ang, &psn, &pcs);
+            }
+        }
+    };
+    // Image sources sample both while their pixel records are on the way; every other source where the values are used
+    // (the samples would only occupy registers in between: 86 instead of 76 for the point sources of the bench scene).
+    if (image) {
+        divergence_sample();
+        polarization_angle();
+    }
+
+    // ---- start position (ray_source.py:229-255) ----
+    V3 p = {src.pos[0], src.pos[1], src.pos[2]};
+    double wl_x0 = 0.0, wl_x1 = 0.0, wl_f = 0.0;  // RGB images: two samples of the primary's inverse table and the weight
+    switch (src.shape) {
+        case OT_SRC_POINT: break;
+        case OT_SRC_LINE: {
+            double t = strat_interval(g, ST_POS, -src.r, src.r);
+            p.x += src.ca * t;
+            p.y += src.sa * t;
+            break;
+        }
+        case OT_SRC_CIRCLE:
+        case OT_SRC_RING: {
+            double x, y;
+            strat_ring(g, ST_POS, src.shape == OT_SRC_RING ? src.ri : 0.0, src.r, false, x, y);
+            p.x += x;
+            p.y += y;
+            break;
+        }
+        case OT_SRC_RECT: {
+            double x, y;
+            strat_rect(g, ST_POS, -src.dim[0] / 2, src.dim[0] / 2, -src.dim[1] / 2, src.dim[1] / 2, x, y);
+            p.x += x * src.ca - y * src.sa;
+            p.y += x * src.sa + y * src.ca;
+            break;
+        }
+        default: {  // image sources: pixel by inverse CDF, uniform inside the pixel
+            if (!IMAGES) break;
+            PixRec rec = r0;
+            uint32_t P = 0;
+            if (npx > 1) P = pixel_pick_finish(src, pk, (int)npx, r0, r1, rec);
+            if (src.shape == OT_SRC_IMAGE_RGB) {  // color.random_wavelengths_from_srgb srgb.py:513-553
+                const double c_r = rec.c_r, c_rg = rec.c_rg;
+                const int prim = (choice < c_r) ? 0 : ((choice > c_rg) ? 2 : 1);
+                // The reference stratifies the wavelengths of each primary over exactly the rays that got that primary
+                // (srgb.py:549-551), which keeps the colour noise of an image far below 1 / sqrt(rays per primary).  The
+                // stratified choice variable carries that for free: inside the sub-interval that selected the primary it is
+                // itself a stratified uniform variable over that primary's rays (exactly so for equal pixel colours).
+                const double lo = (prim == 0) ? 0.0 : ((prim == 1) ? c_r : c_rg);
+                const double hi = (prim == 0) ? c_r : ((prim == 1) ? c_rg : 1.0);
+                const double t = (hi > lo) ? ot_div(choice - lo, hi - lo) : 0.5;
+                // round trip 3: the inverse cumulative spectrum of the primary around t (SourceDev::prim_inv)
+                const double tm = t * (double)OT_PRIM_M;
+                int m = (int)tm;
+                m = m < 0 ? 0 : (m > OT_PRIM_M - 1 ? OT_PRIM_M - 1 : m);
+                const double* inv = src.prim_inv + (size_t)prim * (OT_PRIM_M + 1) + m;
+                wl_x0 = inv[0];
+                wl_x1 = inv[1];
+                wl_f = tm - (double)m;
+            }
+            uint32_t PY = P / (uint32_t)src.img_w, PX = P - PY * (uint32_t)src.img_w;
+            double xs = src.pos[0] - src.dim[0] / 2, ys = src.pos[1] - src.dim[1] / 2;
+            p.x = src.px_w * ((double)PX + rx) + xs;
+            p.y = src.px_h * ((double)PY + ry) + ys;
+        }
+    }
+    o.p = p;
+
+    // ---- orientation (ray_source.py:264-277) ----
+    V3 s_or;
+    if (src.frame_uniform) {  // one base orientation for the whole source (host): constant, or a point source converging
+        s_or.x = src.s[0];
+        s_or.y = src.s[1];
+        s_or.z = src.s[2];
+    } else if (src.orientation == OT_OR_CONVERGING) {
+        V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
+        const double il = ot_rcp3(ot_sqrt(d.x * d.x + d.y * d.y + d.z * d.z));
+        s_or.x = d.x * il;
+        s_or.y = d.y * il;
+        s_or.z = d.z * il;
+    } else if (src.orientation == OT_OR_ARRAY && src.s_or) {  // or_func(x, y) evaluated by the caller (:272-274)
+        s_or.x = src.s_or[g.j];
+        s_or.y = src.s_or[g.j + src.n_or];
+        s_or.z = src.s_or[g.j + 2 * src.n_or];
+    } else {
+        s_or.x = src.s[0];
+        s_or.y = src.s[1];
+        s_or.z = src.s[2];
+    }
+
+    // ---- direction: the divergence sample in the frame around s_or (ray_source.py:339-351) ----
+    V3 s = s_or;
+    if (!image) divergence_sample();
+    if (src.divergence != OT_DIV_NONE) {
+        V3 sx, sy;  // sy = [1, 0, 0] x s_or, sx = s_or x sy
         if (src.frame_uniform) {
             sx = {src.fx[0], src.fx[1], src.fx[2]};
             sy = {src.fy[0], src.fy[1], src.fy[2]};
@@ -462,29 +572,11 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
     }
     o.s = s;
 
-    // ---- polarisation (ray_source.py:359-433) ----
+    // ---- polarisation vector (ray_source.py:387-433) ----
     o.polx = o.poly = o.polz = 0.0;
+    if (!image) polarization_angle();
     if (!no_pol) {
-        double sn, cs;
-        switch (src.polarization) {
-            case OT_POL_CONSTANT:
-                cs = src.pol_cos;
-                sn = src.pol_sin;
-                break;
-            case OT_POL_UNIFORM: sincospi_small(strat_interval(g, ST_POL, 0.0, 2.0), &sn, &cs); break;  // angle in [0, 2 pi)
-            case OT_POL_LIST: {
-                const double* F = src.pol_tab + src.n_pol;
-                double ang = inv_cdf_discrete(src.pol_tab, (int)src.n_pol, strat_interval(g, ST_POL, 0.0, F[src.n_pol - 1]), src.g_pol);
-                sincos(ang, &sn, &cs);
-                break;
-            }
-            default: {
-                const double* F = src.pol_tab + src.n_pol;
-                double ang = inv_cdf_linear(src.pol_pairs, (int)src.n_pol, strat_interval(g, ST_POL, F[0], F[src.n_pol - 1]), src.g_pol);
-                sincos(ang, &sn, &cs);
-            }
-        }
-        double px = cs, py = sn, pz = 0.0;
+        double px = pcs, py = psn, pz = 0.0;
         if (s.z != 1) {
             double fa = ot_rcp3(ot_sqrt(1 - s.z * s.z) + 1e-16);
             V3 ps = {s.y * fa, -s.x * fa, 0.0};
@@ -499,5 +591,7 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         o.poly = py;
         o.polz = pz;
     }
+    if (IMAGES && src.shape == OT_SRC_IMAGE_RGB) wl = wl_x0 + wl_f * (wl_x1 - wl_x0);
+    o.wl = (float)wl;
     return o;
 }

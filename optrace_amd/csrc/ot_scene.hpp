@@ -139,13 +139,21 @@ struct SourceDev {
     const double* spec_tab; int64_t n_spec;
     const double* pol_tab;  int64_t n_pol;
     const double* div_tab;  int64_t n_div;
-    const double* img_cdf;      // cumulative pixel pdf (img_w*img_h)
-    const double* img_rgb;      // per pixel cumulative primary mix: (r, r+g) / (r+g+b), 2 per pixel
-    const double* prim_tab;     // inverse-CDF tables of the three sRGB primaries: 3 x (PRIM_N wl, PRIM_N cdf)
-    CdfGuide g_spec, g_pol, g_div, g_img, g_prim[3];
+    // image sources (ot_generate.hpp::pixel_pick): one 32-byte record per pixel {cumulative pdf F_j, cumulative primary
+    // mix r / (r+g+b), (r+g) / (r+g+b), 0}, and per bucket b of [0, F_total) the number of pixels whose bucket lies
+    // before b (pick_lo[0 .. pick_K], buckets by the device's own expression (int)(X * pick_scale)): a pixel is found
+    // with two memory round trips, the second one already carrying its colours
+    const double* pix_rec;
+    const int32_t* pick_lo;
+    int32_t pick_K, _pad3;
+    double pick_scale, pix_total;
+    // wavelength of an sRGB primary as a function of the uniform variable: OT_PRIM_M + 1 samples of the inverse cumulative
+    // spectrum per primary (3 tables), linear in between -- one round trip, no search
+    const double* prim_inv;
+    CdfGuide g_spec, g_pol, g_div;
     // the continuous inverse-CDF tables once more as (F_j, x_j) pairs: the two nodes an interpolation needs sit in
     // one 32-byte load, which also decides whether the search has to step (see inv_cdf_linear)
-    const double *spec_pairs, *pol_pairs, *div_pairs, *prim_pairs;
+    const double *spec_pairs, *pol_pairs, *div_pairs;
     const double* s_or; int64_t n_or;  // OR_ARRAY: caller-owned base orientations x[n_or] | y[n_or] | z[n_or]
     // the same base orientation for every ray (constant orientation; point source converging onto conv_pos): it is in
     // `s` and its divergence frame in fx, fy, all evaluated once on the host instead of once per ray
@@ -160,7 +168,9 @@ struct ot_sources {
     int device;
     int64_t* n_or;  // host, per source: rays a range of this source must hold (OR_ARRAY with an array), else -1
     double* power;  // host, per source
+    bool has_image = false;  // some source is an image (those scenes take the formula kernels, see generate_ray<IMAGES>)
     struct RangeCache* rcache = nullptr;  // the last range list seen by make_ranges and what was derived from it
 };
 
-#define OT_PRIM_N 5000
+#define OT_PRIM_N 5000    // wavelengths the reference tabulates the primaries on (srgb.py:528)
+#define OT_PRIM_M 65536   // buckets of the inverse tables (SourceDev::prim_inv)

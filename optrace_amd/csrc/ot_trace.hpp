@@ -262,13 +262,18 @@ OT_DEV bool hurb_bend(SC& sc, SF& sf, RayState& r, const V3& pn, float& wn, floa
 // profiles/r2/store_hints.txt: kernel 1.671 -> 1.622 ms with " nt"; " sc0 sc1" alone 1.667; " sc0 sc1 nt" 1.619, shipped).
 #define OT_STORE_HINT " sc0 sc1 nt"
 #endif
+// The statements clobber "memory": they write it, and without the clobber the compiler may move its own loads and stores
+// of the same planes across them (the kernel variant that loads section 0 from the planes it then overwrites).
+#ifndef OT_STORE_CLOBBER
+#define OT_STORE_CLOBBER : "memory"
+#endif
 OT_DEV void store_f64(const void* base, uint32_t off, double v) {
     const void* b;
-    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0" OT_STORE_HINT : "=&s"(b) : "v"(off), "v"(v), "s"(base));
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0" OT_STORE_HINT : "=&s"(b) : "v"(off), "v"(v), "s"(base) OT_STORE_CLOBBER);
 }
 OT_DEV void store_f32(const void* base, uint32_t off, float v) {
     const void* b;
-    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" OT_STORE_HINT : "=&s"(b) : "v"(off), "v"(v), "s"(base));
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" OT_STORE_HINT : "=&s"(b) : "v"(off), "v"(v), "s"(base) OT_STORE_CLOBBER);
 }
 
 // One section of one ray.  The plane base addresses (array + N * plane) are wave-uniform and stay in SGPRs; the
@@ -296,6 +301,44 @@ OT_DEV void store_section(const ot_rays& R, uint32_t o8, uint32_t o4, int sec, c
         store_f32(R.pol + N * (sec + 2 * nt), o4, pz);
     }
 }
+
+// The same with running plane bases: eight wave-uniform 64-bit pointers that advance by one plane per section (two
+// scalar adds each) instead of eight `array + N * (section + k * nt)` products per section.
+struct PlaneBases {
+    const double *px, *py, *pz, *n;
+    const float *w, *qx, *qy, *qz;
+    int64_t N;
+};
+template <bool POL>
+OT_DEV PlaneBases plane_bases(const ot_rays& R) {
+    const int64_t N = R.N, nt = R.nt;
+    PlaneBases b = {R.p, R.p + N * nt, R.p + N * 2 * nt, R.n, R.w, nullptr, nullptr, nullptr, N};
+    if (POL) {
+        b.qx = R.pol;
+        b.qy = R.pol + N * nt;
+        b.qz = R.pol + N * 2 * nt;
+    }
+    return b;
+}
+template <bool POL>
+OT_DEV void store_section_next(PlaneBases& b, uint32_t o8, uint32_t o4, const V3& p, float w, double n, float px, float py,
+                               float pz) {
+    store_f64(b.px, o8, p.x);
+    store_f64(b.py, o8, p.y);
+    store_f64(b.pz, o8, p.z);
+    store_f32(b.w, o4, w);
+    store_f64(b.n, o8, n);
+    b.px += b.N, b.py += b.N, b.pz += b.N, b.n += b.N, b.w += b.N;
+    if (POL) {
+        store_f32(b.qx, o4, px);
+        store_f32(b.qy, o4, py);
+        store_f32(b.qz, o4, pz);
+        b.qx += b.N, b.qy += b.N, b.qz += b.N;
+    }
+}
+#ifndef OT_RUNNING_BASES
+#define OT_RUNNING_BASES 1
+#endif
 
 // sub_trace raytracer.py:297-397 for one ray whose section 0 state is in `r`.
 // The element list is flattened on the host into one STEP per tracing surface (lens front, lens back, ideal
@@ -331,7 +374,12 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
     const auto pool = as_const(sc.pool);
     bool ok = true;
     r.n_cur = (SPEC == 2) ? lrow[(3 * sc.n_steps) * OT_MAX_LINES] : medium_n<TAB>(media[sc.n0], pool, r.wl);
+#if OT_RUNNING_BASES
+    PlaneBases planes = plane_bases<POL>(R);
+    store_section_next<POL>(planes, o8, o4, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+#else
     store_section<POL>(R, o8, o4, 0, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+#endif
 
     for (int i = 0; i < sc.n_steps; i++) {  // i = index of the section the ray starts this step in
         auto& st = steps[i];
@@ -411,7 +459,14 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
         r.poly = npy;
         r.polz = npz;
         r.n_cur = n_next;
+#ifdef OT_NO_SECTION_STORES  // experiment (tools/power_clock.py): the same arithmetic, only the last section is stored
+        if (i + 1 == sc.n_steps)
+#endif
+#if OT_RUNNING_BASES
+        store_section_next<POL>(planes, o8, o4, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+#else
         store_section<POL>(R, o8, o4, i + 1, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+#endif
     }
     const int64_t N = R.N;
     store_f64(R.s, o8, r.s.x);

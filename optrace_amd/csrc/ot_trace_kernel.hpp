@@ -20,7 +20,13 @@
 #define OT_TRACE_MIN_WAVES_F0 5
 #endif
 // waves per SIMD asked of the register allocator, per feature level (see OT_FEAT below)
-#define OT_TRACE_WAVES(FEAT) ((FEAT) == 0 ? OT_TRACE_MIN_WAVES_F0 : OT_TRACE_MIN_WAVES)
+// (discrete-spectrum kernels of level 0 -- the bench scene -- fit six: asked for explicitly, the allocator otherwise
+// spreads out over whatever five waves leave it)
+#ifndef OT_TRACE_MIN_WAVES_F0_LINES
+#define OT_TRACE_MIN_WAVES_F0_LINES 6
+#endif
+#define OT_TRACE_WAVES(FEAT, SPEC) \
+    ((FEAT) == 0 ? ((SPEC) == 2 ? OT_TRACE_MIN_WAVES_F0_LINES : OT_TRACE_MIN_WAVES_F0) : OT_TRACE_MIN_WAVES)
 
 struct RangeRec {  // one source range in device memory (scenes with more than OT_MAX_RANGES ranges)
     int64_t first, count;
@@ -88,6 +94,7 @@ OT_DEV bool locate_range(const RangeArgs& rg, int64_t ray, GenCtx& g, int& k, in
 // divergence / polarisation are scalar branches, permutation keys come from the scalar ALU.  A wave that
 // straddles a range boundary takes the per-lane path.  (A loop over the ranges of a wave instead of the two
 // paths made the register allocator give up: 256 VGPRs.)
+template <bool IMAGES = true>
 OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sources, int64_t ray, uint64_t seed,
                           bool no_pol, NewRay& nr) {
     GenCtx g;
@@ -122,16 +129,16 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
         g.n = (uint32_t)count0;
         g.range = (uint32_t)lo;
         const auto& S = as_const(sources)[src0];
-        fill_dither_for(g, S);
-        nr = generate_ray(S, g, no_pol);
+        fill_dither_for<IMAGES>(g, S);
+        nr = generate_ray<IMAGES>(S, g, no_pol);
         return true;
     }
     int k = -1, src = 0;
     const bool have = locate_range(rg, ray, g, k, src);
     if (have) {
         g.range = (uint32_t)k;
-        fill_dither_for(g, sources[src]);
-        nr = generate_ray(sources[src], g, no_pol);
+        fill_dither_for<IMAGES>(g, sources[src]);
+        nr = generate_ray<IMAGES>(sources[src], g, no_pol);
     }
     return have;
 }
@@ -147,7 +154,7 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
 // The launch covers the rays [ray_base, ray_base + count) of the bundle; R's pointers are advanced to ray_base by
 // the host (R.N stays the plane stride), so lanes address their ray with a 32-bit offset (count <= 2^28).
 template <bool POL, bool GEN, int SPEC, int FEAT>
-__global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT)) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
+__global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT, SPEC)) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
                                                     const SourceDev* __restrict__ sources, RangeArgs rg,
                                                     const double* __restrict__ hurb_normals, uint64_t seed,
                                                     unsigned int* __restrict__ slots, int64_t ray_base,
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT)) void trace_kernel(const 
     if (have) {
         if (GEN) {
             NewRay nr;
-            have = generate_lane(rg, sources, ray, seed, !POL, nr);
+            have = generate_lane<(SPEC != 2)>(rg, sources, ray, seed, !POL, nr);  // no image sources with SPEC 2 (launch_trace)
             if (have) {
                 r.p = nr.p;
                 r.s = nr.s;

@@ -278,22 +278,28 @@ class Raytracer(Group):
         The reference re-reads the whole object graph on every call (raytracer.py:246-278).  Here everything
         derived from it -- geometry checks, the compiled scene, the source table, the snapshot -- is kept while
         nothing changed: every tracked object reports assignments to a global counter (base.mutation_epoch), so
-        an unchanged scene is recognised by one integer comparison plus the identities of the list members.
+        an unchanged scene is recognised by one integer comparison, the identities of the list members and the bytes of
+        the few small arrays that are still writeable (large ones are read-only or switch the shortcut off).
         """
         fast = self._fast
         if (fast is not None and fast[0] == _base.mutation_epoch() and fast[1] == self._structure()
-                and not self.geometry_error):
+                and not self.geometry_error and all(a.tobytes() == b for a, b in fast[5])):
             check_type("N", N, int)
             if N < 1:
                 raise ValueError(f"Ray number N needs to be at least 1, but is {N}.")
-            _, _, snap, scene, splits = fast
+            _, _, snap, scene, splits, _ = fast
             snap = dict(snap)
             writeable = False
         else:
             self._fast = fast = None
             _base._SAW_WRITEABLE[0] = False
+            _base._WATCH[0] = [self.outline] if self.outline.flags.writeable else []
             snap = self.tracing_snapshot()  # taken once: geometry-check key, scene key and the post-trace record
             writeable = _base._SAW_WRITEABLE[0]  # large arrays that can still change in place: no shortcut next time
+            # small arrays that can: their bytes are compared before every shortcut (assignments move the counter, an
+            # edit in place like `RT.outline[5] += 1` or `RS.s[0] = 0.1` does not)
+            watch = [(a, a.tobytes()) for a in _base._WATCH[0]]
+            _base._WATCH[0] = None
             if self._pretrace_check(N, snap):
                 return
             scene = self._compile(snap)
@@ -363,7 +369,7 @@ class Raytracer(Group):
         self._last_trace_snapshot = snap
         if fast is None and not writeable and _initial_rays is None and not rays_obj._has_function_orientation:
             # read the counter last: objects this call created itself (the end aperture of the element list) count too
-            self._fast = (_base.mutation_epoch(), self._structure(), snap, scene, splits)
+            self._fast = (_base.mutation_epoch(), self._structure(), snap, scene, splits, watch)
 
     # ---- detector (raytracer.py:881-1098) ----------------------------------------------------------------
     # ---- shared argument checks of the post-processing entry points ------------------------------------------
@@ -561,12 +567,14 @@ class Raytracer(Group):
                     " are not included in the convolution calculation.")
         spec = dict(detector_index=detector_index, source_index=source_index, extent=extent,
                     projection_method=projection_method)
-        if not kwargs.get("_unfused", False):
-            # extent known: hit search and binning in one pass, no hit positions in memory; an automatic extent comes
-            # from an extent-only pass first (52 B read per ray, nothing written) instead of a hit list
-            if extent is None:
-                spec = self._auto_extents([spec])[0]
+        if extent is not None and not kwargs.get("_unfused", False):  # extent known: one pass, no hit positions in memory
             return self._render_detectors([spec], [limit], **kwargs)[0]
+        # Automatic extent: hit list first, then the binning.  (Measured against an extent-only pass followed by the
+        # fused kernels, `_auto_extents` + `_render_detectors`, profiles/r3/detector_full_size.txt: C4 5.7 against 5.8 ms,
+        # C5 3.7 / 3.6, and slower where the fused entry point falls back to this chain anyway -- spherical detectors, C3
+        # 3.0 against 1.9 ms -- or the image is point-like, C2 1.3 against 0.9 ms: the sections are read twice either
+        # way.  The extent-only pass serves where hit lists would have to be kept or exchanged: the first chunk of
+        # `iterative_render` and the sharded forms in distributed.py.)
         kwargs.pop("_unfused", None)
         hits = self._hit_detectors("Detector Image", [spec])[0]
         return self._image_from_hits(hits, detector_index, source_index, limit, **kwargs)

@@ -428,6 +428,37 @@ def test_stale_rays_are_refused():
         RT.detector_image(limit=4, extent=[-0.01, 0.01, -0.01, 0.01])  # limit together with an extent only warns
 
 
+def test_arrays_edited_in_place_between_traces_are_seen():
+    """The unchanged-scene shortcut of `trace` counts assignments; the few small arrays that stay writeable (the outline,
+    RaySource.s, conv_pos) can also be edited in place, which the reference picks up because it re-reads the object graph
+    at every trace (raytracer.py:246-278).  Their bytes are therefore compared before every shortcut."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-5, 5, -5, 5, -10, 30], seed=3)
+        RS = ot.RaySource(ot.Point(), divergence="None", s=[0, 0, 1], pos=[0, 0, -5],
+                          spectrum=ot.LightSpectrum("Monochromatic", wl=550.))
+        RT.add(RS)
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[4, 4]), pos=[0, 0, 20]))
+        RT.trace(1000)
+        RT.trace(1000)  # second call: the shortcut
+        assert RT.rays.p_list[0, -1, 2] == 30 and abs(RT.rays.p_list[0, -1, 0]) < 1e-12
+        o = RT.outline
+        assert o.flags.writeable, "the case only exists while the outline can be edited in place"
+        o[5] += 7.0
+        RT.trace(1000)
+        assert RT.rays.p_list[0, -1, 2] == 37, "the new outline ends the rays"
+        RT.detector_image()  # rays are current: no 'retrace first'
+        assert RS.s.flags.writeable
+        RS.s[0], RS.s[2] = 0.1 / np.hypot(0.1, 1), 1 / np.hypot(0.1, 1)
+        RT.trace(1000)
+        x_end = RT.rays.p_list[0, -1, 0]
+        assert abs(x_end - 0.1 * 42) < 1e-9, "the tilted direction is used"
+        RT.detector_image()
+        # and an edit after the last trace makes the rays stale, like any other change
+        o[5] -= 1.0
+        with pytest.raises(RuntimeError):
+            RT.detector_image()
+
+
 def test_meniscus_lenses_whose_surfaces_embrace_each_other():
     """After the reference's test_non_sequental_surface_extent (tests/test_tracer_special.py:366-417): near-hemispherical
     meniscus lenses, one surface reaching past the other in z -- no geometry error, a beam through the middle passes
