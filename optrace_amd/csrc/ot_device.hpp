@@ -307,14 +307,17 @@ OT_DEV V3 surf_normal(SF& sf, double x, double y, PatchCache* pc = nullptr) {
             n.z = ot_sqrt(1 - sf.rho2 * (dx * dx) - sf.rho2 * (dy * dy));
             return n;
         }
-        double r = ot_sqrt(dx * dx + dy * dy);
-        double n_r = ot_div(sf.nrho * r, ot_sqrt(1 - sf.krho2 * (r * r)));
-        const double ir = ot_rcp3(r);
-        double c = (r > 0.0) ? ot_div_r(dx, r, ir) : 1.0;
-        double s = (r > 0.0) ? ot_div_r(dy, r, ir) : 0.0;
-        n.x = n_r * c;
-        n.y = n_r * s;
-        n.z = ot_sqrt(1 - n_r * n_r);
+        // n_r = -rho r / sqrt(1 - k rho^2 r^2), (n_x, n_y) = n_r (cos phi, sin phi), n_z = sqrt(1 - n_r^2)
+        // (conic_surface.py:101-118) with cos phi = dx / r, sin phi = dy / r: the radius cancels, so
+        // n_x = -rho dx / sqrt(1 - k rho^2 r^2), likewise n_y, and n_r^2 = n_x^2 + n_y^2 -- one square root, one
+        // reciprocal and a third of the instructions less than going through r and n_r, the same values to 1-2 ulp
+        // (the deviation class of dx / r for cos(atan2) itself, see above)
+        const double r2 = dx * dx + dy * dy;
+        const double q = ot_sqrt(1 - sf.krho2 * r2);
+        const double iq = ot_rcp3(q);
+        n.x = ot_div_r(sf.nrho * dx, q, iq);
+        n.y = ot_div_r(sf.nrho * dy, q, iq);
+        n.z = ot_sqrt(1 - (n.x * n.x + n.y * n.y));
         return n;
     }
     double rm = ot_sqrt(dx * dx + dy * dy);
@@ -646,6 +649,32 @@ OT_HD double interp_tab(double x, PL xp, PL fp, int n) {
 // model -- five pow() calls among them -- in front of the loop and evaluates them for every ray whatever the scene's
 // media are (measured: 570 of the 1345 vector instructions per wave of C4's kernel before any surface was reached).
 // Behind the barrier only the model the (wave-uniform) switch selects is evaluated, where it is needed.
+// x**k for the whole-number exponents 3 .. 6 of the dispersion formulas (NumPy calls libm's pow for them,
+// refraction_index.py:102-148).  On the device: repeated multiplication, within 3 ulp of pow -- the device library's pow
+// is not correctly rounded either, and its code needs ~40 vector registers that every formula kernel then carried
+// (122 instead of ~100 with polarisation).  The host (tables of discrete spectra) keeps libm's pow like the reference.
+OT_HD double ot_powi(double x, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double x2 = x * x;
+    switch (k) {
+        case 3: return x2 * x;
+        case 4: return x2 * x2;
+        case 5: return x2 * x2 * x;
+        default: return x2 * x2 * x2;
+    }
+#else
+    return pow(x, (double)k);
+#endif
+}
+
+OT_HD double ot_pow35(double x) {  // x**3.5 (Conrady): x^3 sqrt(x) on the device, see ot_powi
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x * x * x * sqrt(x);
+#else
+    return pow(x, 3.5);
+#endif
+}
+
 template <bool TAB = true, class MD, class PL>
 OT_HD double medium_n(MD& md, PL pool, float wl32) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -658,8 +687,8 @@ OT_HD double medium_n(MD& md, PL pool, float wl32) {
     switch (md.model) {
         case OT_N_CONSTANT: return c[0];
         case OT_N_ABBE: return c[0] + ot_div(c[1], wl2 - c[2]);
-        case OT_N_CONRADY: return c[0] + c[1] / um + c[2] / pow(um, 3.5);
-        case OT_N_CAUCHY: return c[0] + ot_div(c[1], wl2) + ot_div(c[2], wl2 * wl2) + ot_div(c[3], pow(wl2, 3.0));
+        case OT_N_CONRADY: return c[0] + c[1] / um + c[2] / ot_pow35(um);
+        case OT_N_CAUCHY: return c[0] + ot_div(c[1], wl2) + ot_div(c[2], wl2 * wl2) + ot_div(c[3], ot_powi(wl2, 3));
         case OT_N_SELLMEIER1:
             return sqrt(1 + ot_div(c[0] * wl2, wl2 - c[1]) + ot_div(c[2] * wl2, wl2 - c[3]) + ot_div(c[4] * wl2, wl2 - c[5]));
         case OT_N_SELLMEIER2:
@@ -672,23 +701,23 @@ OT_HD double medium_n(MD& md, PL pool, float wl32) {
             return sqrt(1 + c[0] * wl2 / (wl2 - c[1]) + c[2] * wl2 / (wl2 - c[3]) + c[4] * wl2 / (wl2 - c[5]) +
                         c[6] * wl2 / (wl2 - c[7]) + c[8] * wl2 / (wl2 - c[9]));
         case OT_N_SCHOTT:
-            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / pow(wl2, 3.0) +
-                        c[5] / pow(wl2, 4.0));
+            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / ot_powi(wl2, 3) +
+                        c[5] / ot_powi(wl2, 4));
         case OT_N_HERZBERGER: {
             double L = 1 / (wl2 - 0.028);
-            return c[0] + c[1] * L + c[2] * (L * L) + c[3] * wl2 + c[4] * (wl2 * wl2) + c[5] * pow(wl2, 3.0);
+            return c[0] + c[1] * L + c[2] * (L * L) + c[3] * wl2 + c[4] * (wl2 * wl2) + c[5] * ot_powi(wl2, 3);
         }
         case OT_N_HOO1: return sqrt(c[0] + c[1] / (wl2 - c[2]) - c[3] * wl2);
         case OT_N_HOO2: return sqrt(c[0] + c[1] * wl2 / (wl2 - c[2]) - c[3] * wl2);
         case OT_N_EXTENDED:
-            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / pow(wl2, 3.0) +
-                        c[5] / pow(wl2, 4.0) + c[6] / pow(wl2, 5.0) + c[7] / pow(wl2, 6.0));
+            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / ot_powi(wl2, 3) +
+                        c[5] / ot_powi(wl2, 4) + c[6] / ot_powi(wl2, 5) + c[7] / ot_powi(wl2, 6));
         case OT_N_EXTENDED2:
-            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / pow(wl2, 3.0) +
-                        c[5] / pow(wl2, 4.0) + c[6] * (wl2 * wl2) + c[7] * pow(wl2, 3.0));
+            return sqrt(c[0] + c[1] * wl2 + c[2] / wl2 + c[3] / (wl2 * wl2) + c[4] / ot_powi(wl2, 3) +
+                        c[5] / ot_powi(wl2, 4) + c[6] * (wl2 * wl2) + c[7] * ot_powi(wl2, 3));
         case OT_N_EXTENDED3:
             return sqrt(c[0] + c[1] * wl2 + c[2] * (wl2 * wl2) + c[3] / wl2 + c[4] / (wl2 * wl2) +
-                        c[5] / pow(wl2, 3.0) + c[6] * pow(wl2, 4.0) + c[7] * pow(wl2, 5.0) + c[8] / pow(wl2, 6.0));
+                        c[5] / ot_powi(wl2, 3) + c[6] * ot_powi(wl2, 4) + c[7] * ot_powi(wl2, 5) + c[8] / ot_powi(wl2, 6));
         case OT_N_DATA: {
             if (!TAB) break;
             auto xp = pool + md.tab_off;

@@ -379,7 +379,12 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
     // ---- image sources: in-pixel position and the choice of the primary (no memory involved) ----
     double rx = 0.0, ry = 0.0, choice = 0.0;
     if (image) {
-        strat_rect(g, ST_PIX_JITTER, 0.0, 1.0, 0.0, 1.0, rx, ry);
+        // Position inside the pixel: uniform.  The reference draws it from a grid stratified over ALL rays of the source
+        // and shuffled independently of the pixel choice (ray_source.py:247), so the rays that share a pixel carry a
+        // random subset of that grid -- indistinguishable from independent uniform values.  The dithers serve directly;
+        // a permutation and the grid arithmetic (~45 vector instructions per ray) bought nothing.
+        rx = g.u[dither_slot(ST_PIX_JITTER)];
+        ry = g.u[dither_slot(ST_PIX_JITTER) + 1];
         if (src.shape == OT_SRC_IMAGE_RGB) choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
     }
     // ---- image sources, round trip 2: the records of the first two pixels of the range ----

@@ -13,9 +13,9 @@
 #ifndef OT_TRACE_MIN_WAVES
 #define OT_TRACE_MIN_WAVES 1
 #endif
-// Feature level 0 kernels (flat and conic surfaces only): five waves per SIMD asked for.  The discrete-spectrum variants
-// need 64-78 registers anyway; the continuous-spectrum ones (C3, C4) come down from 115-122 to 96 with a few spilled
-// values, and they wait on the dependent table loads of the generator half of the time: C4 10.5 -> 10.0 ms.
+// Feature level 0 kernels (flat and conic surfaces only): five waves per SIMD asked for.  The continuous-spectrum
+// variants (C3, C4) need 90-92 registers since the dispersion formulas no longer pull in the device library's pow
+// (ot_device.hpp::ot_powi; 109-122 before, i.e. four waves or spills): no scratch in any of them.
 #ifndef OT_TRACE_MIN_WAVES_F0
 #define OT_TRACE_MIN_WAVES_F0 5
 #endif
@@ -25,7 +25,7 @@
 #ifndef OT_TRACE_MIN_WAVES_F0_LINES
 #define OT_TRACE_MIN_WAVES_F0_LINES 6
 #endif
-#define OT_TRACE_WAVES(FEAT, SPEC) \
+#define OT_TRACE_WAVES(FEAT, SPEC, POL) \
     ((FEAT) == 0 ? ((SPEC) == 2 ? OT_TRACE_MIN_WAVES_F0_LINES : OT_TRACE_MIN_WAVES_F0) : OT_TRACE_MIN_WAVES)
 
 struct RangeRec {  // one source range in device memory (scenes with more than OT_MAX_RANGES ranges)
@@ -154,7 +154,7 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
 // The launch covers the rays [ray_base, ray_base + count) of the bundle; R's pointers are advanced to ray_base by
 // the host (R.N stays the plane stride), so lanes address their ray with a 32-bit offset (count <= 2^28).
 template <bool POL, bool GEN, int SPEC, int FEAT>
-__global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT, SPEC)) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
+__global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT, SPEC, POL)) void trace_kernel(const SceneDev* __restrict__ scp, ot_rays R,
                                                     const SourceDev* __restrict__ sources, RangeArgs rg,
                                                     const double* __restrict__ hurb_normals, uint64_t seed,
                                                     unsigned int* __restrict__ slots, int64_t ray_base,
