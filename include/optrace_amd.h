@@ -416,7 +416,18 @@ typedef struct ot_detector_req {
     float* hw;            /* device (count)      extent-only request, nothing but extent4 and ill_count is written   */
     double* extent4;      /* device f64[4] or NULL, initialised by the caller       */
     int64_t* ill_count;   /* device int64[2], added to                              */
+    /* Compact hit list (fill != NULL; needs xy_only): only the VALID hits are written, into a list of OT_HIT_PIECES
+     * pieces of L = ot_hit_piece_len(count) entries each -- CAPACITY = OT_HIT_PIECES * L entries, which the caller
+     * allocates: ph = x plane [CAPACITY] then y plane [CAPACITY], hw [CAPACITY], wl_out [CAPACITY] (the hit's
+     * wavelength: the list no longer lines up with the rays).  Piece k holds fill[k] hits at its front, [k * L,
+     * k * L + fill[k]); which piece a hit lands in and its place there are arbitrary.  fill (device
+     * uint32[OT_HIT_PIECES]) must be zero on entry.  Consumed by ot_render_accumulate_compact. */
+    float* wl_out;        /* device (CAPACITY) or NULL                              */
+    uint32_t* fill;       /* device uint32[OT_HIT_PIECES] or NULL = dense list      */
 } ot_detector_req;
+#define OT_HIT_PIECES 1024
+int64_t ot_hit_piece_len(int64_t count); /* entries per piece of a compact hit list of capacity count: the power of
+                                          * two at or above count / 1024, at least 1024 (the last pieces stay empty) */
 int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_req* reqs,
                            int32_t n_reqs, void* stream);
 
@@ -459,6 +470,12 @@ int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, 
 int ot_render_accumulate(int64_t n, const double* px, const double* py, const float* w,
                          const float* wl, const double extent[4], int32_t Nx, int32_t Ny,
                          double* hist, void* stream);
+/* The same for the compact hit list of a bundle of n rays (see ot_detector_req.fill; px, py, w, wl hold
+ * OT_HIT_PIECES * ot_hit_piece_len(n) entries): piece k contributes its first fill[k] entries.  With an automatic extent the hit search writes a third of the bytes (valid hits only) and the binning
+ * reads only those. */
+int ot_render_accumulate_compact(int64_t n, const uint32_t* fill, const double* px, const double* py, const float* w,
+                                 const float* wl, const double extent[4], int32_t Nx, int32_t Ny, double* hist,
+                                 void* stream);
 
 /* ---- image conversion (next row) -------------------------------------------------- */
 #define OT_IMG_IRRADIANCE 0       /* render_image.py:180 */

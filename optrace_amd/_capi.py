@@ -96,7 +96,7 @@ class Source(C.Structure):
 class DetectorReq(C.Structure):
     _fields_ = [("detector", C.c_void_p), ("projection", C.c_int32), ("xy_only", C.c_int32),
                 ("crop4", C.c_void_p), ("ph", C.c_void_p), ("hw", C.c_void_p), ("extent4", C.c_void_p),
-                ("ill_count", C.c_void_p)]
+                ("ill_count", C.c_void_p), ("wl_out", C.c_void_p), ("fill", C.c_void_p)]
 
 
 class DetectorImageReq(C.Structure):
@@ -151,6 +151,8 @@ SIGNATURES = {
     "ot_image_convert": (C.c_int, [vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]),
     "ot_image_convolve": (C.c_int, [vp, i32, i32, vp, i32, vp, vp]),
     "ot_render_accumulate": (C.c_int, [i64, vp, vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp]),
+    "ot_render_accumulate_compact": (C.c_int, [i64, vp, vp, vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp]),
+    "ot_hit_piece_len": (i64, [i64]),
     "ot_spectrum_range": (C.c_int, [i64, vp, vp, vp, vp, vp]),
     "ot_spectrum_histogram": (C.c_int, [i64, vp, vp, vp, i32, vp, vp]),
     "ot_focus_prepare": (C.c_int, [C.POINTER(Rays), i64, i64, C.c_double, vp, vp, vp, vp]),
@@ -161,6 +163,7 @@ SIGNATURES = {
 }
 
 FOCUS_WS = 16  # OT_FOCUS_WS
+HIT_PIECES = 1024  # OT_HIT_PIECES
 ABI_VERSION = 5  # OT_ABI_VERSION
 
 _lib = None

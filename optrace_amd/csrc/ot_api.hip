@@ -1240,6 +1240,8 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
         // ph and hw both NULL: extent-only request (no hit list is written)
         if ((!q.ph || !q.hw) && (q.ph || q.hw || !q.extent4))
             return fail(OT_ERR_INVALID, "ot_detector_hits: ph and hw may only be NULL together, and only with extent4");
+        if (q.fill && (!q.ph || !q.hw || !q.wl_out || !q.xy_only || !rays->wl))
+            return fail(OT_ERR_INVALID, "ot_detector_hits: a compact hit list needs ph, hw, wl_out and xy_only");
         if (q.projection < OT_PROJ_NONE || q.projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
     }
     if (int rc = require_device()) return rc;
@@ -1271,6 +1273,9 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
         d.ill = (unsigned long long*)reqs[k].ill_count;
         d.projection = reqs[k].projection;
         d.xy_only = reqs[k].xy_only != 0;
+        d.wl_out = reqs[k].wl_out;
+        d.fill = reqs[k].fill;
+        d.piece_shift = hit_piece_shift(count);
         if (reqs[k].extent4) d.ext_slots = slots + (size_t)4 * OT_EXT_SLOTS * e++;
         numeric = numeric || !(d.det.kind == OT_SURF_CONIC || d.det.flat);
     }
@@ -1307,10 +1312,14 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
     return OT_OK;
 }
 
+extern "C" int64_t ot_hit_piece_len(int64_t count) { return hit_piece_len(count); }
+
 extern "C" int ot_detector_hits(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
                                 int32_t projection, const double* crop4, double* ph, float* hw, double* extent4,
                                 int64_t* ill_count, void* stream) {
     ot_detector_req q;
+    q.wl_out = nullptr;
+    q.fill = nullptr;
     q.detector = detector;
     q.projection = projection;
     q.xy_only = 0;
@@ -1365,8 +1374,23 @@ extern "C" int ot_scratch_trim(void) {
 
 #define OT_TILE_MIN_HITS (1ll << 21)  // shorter lists: the direct kernel alone
 
+static int render_accumulate(int64_t n, const unsigned int* fill, const double* px, const double* py, const float* w,
+                             const float* wl, const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream);
+
 extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* py, const float* w, const float* wl,
                                     const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream) {
+    return render_accumulate(n, nullptr, px, py, w, wl, extent, Nx, Ny, hist, stream);
+}
+
+extern "C" int ot_render_accumulate_compact(int64_t n, const uint32_t* fill, const double* px, const double* py,
+                                            const float* w, const float* wl, const double extent[4], int32_t Nx,
+                                            int32_t Ny, double* hist, void* stream) {
+    if (!fill) return fail(OT_ERR_INVALID, "ot_render_accumulate_compact: fill counts missing");
+    return render_accumulate(n, fill, px, py, w, wl, extent, Nx, Ny, hist, stream);
+}
+
+static int render_accumulate(int64_t n, const unsigned int* fill, const double* px, const double* py, const float* w,
+                             const float* wl, const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream) {
     if (n < 0 || !extent || !hist || Nx < 1 || Ny < 1 || (n && (!px || !py || !w || !wl)))
         return fail(OT_ERR_INVALID, "ot_render_accumulate: bad argument");
     if (int rc = require_device()) return rc;
@@ -1394,7 +1418,7 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     const char* pin = std::getenv("OT_RENDER_PATH");
     const bool pin_direct = pin && !std::strcmp(pin, "direct"), pin_tiles = pin && !std::strcmp(pin, "tiles");
     if (pin_direct || (n < OT_TILE_MIN_HITS && !pin_tiles)) {
-        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr);
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr, fill);
         HIP_TRY(hipGetLastError());
         return OT_OK;
     }
@@ -1406,12 +1430,12 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     t.ty = (Ny + OT_TILE_W - 1) / OT_TILE_W;
     t.K = t.tx * t.ty;
     if (t.K > OT_TILE_MAX) {  // no image of RenderImage is this large; stay on the direct path
-        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr);
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr, fill);
         HIP_TRY(hipGetLastError());
         return OT_OK;
     }
     t.n = n;
-    t.piece = ((n + OT_TILE_PIECES - 1) / OT_TILE_PIECES + 1023) / 1024 * 1024;
+    t.piece = fill ? hit_piece_len(n) : ((n + OT_TILE_PIECES - 1) / OT_TILE_PIECES + 1023) / 1024 * 1024;
     t.chunk = ((n + 1023) / 1024 + 1023) / 1024 * 1024;
     if (t.chunk < 16384) t.chunk = 16384;
     t.max_chunks = (int32_t)(n / t.chunk + t.K + 1);
@@ -1433,11 +1457,12 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     if (hipMallocAsync((void**)&ws, off, st) != hipSuccess || !ws) {
         // no room for the hit records (12 B per hit): the direct kernel needs no scratch
         (void)hipGetLastError();
-        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr);
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr, fill);
         HIP_TRY(hipGetLastError());
         return OT_OK;
     }
     TileWork wk;
+    wk.fill = fill;
     wk.spread = (int*)(ws + o_spread);
     wk.counts = (unsigned int*)(ws + o_counts);
     wk.tot = (unsigned long long*)(ws + o_tot);
@@ -1456,8 +1481,8 @@ extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* p
     if (pin_tiles)
         HIP_TRY(hipMemsetAsync(wk.spread, 1, sizeof(int), st));
     else
-        hipLaunchKernelGGL(tile_probe_kernel, dim3(1), dim3(1024), lds_probe, st, t, px, py, w, wk.spread);
-    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)wk.spread);
+        hipLaunchKernelGGL(tile_probe_kernel, dim3(1), dim3(1024), lds_probe, st, t, px, py, w, wk.spread, fill);
+    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)wk.spread, fill);
     hipLaunchKernelGGL(tile_count_kernel, dim3(OT_TILE_PIECES), dim3(1024), 0, st, t, px, py, w, wk);
     hipLaunchKernelGGL(tile_cursor_kernel, dim3((unsigned)((t.K + 3) / 4)), dim3(256), 0, st, t, wk, wk.tot);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, t, wk, (const unsigned long long*)wk.tot);
@@ -1512,6 +1537,8 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         dq.ph = (double*)tmp;
         dq.hw = (float*)(tmp + o_hw);
         dq.extent4 = nullptr;
+        dq.wl_out = nullptr;
+        dq.fill = nullptr;
         dq.ill_count = q.ill_count;
         int rc = ot_detector_hits_multi(rays, first, count, &dq, 1, stream);
         if (!rc) rc = ot_render_accumulate(count, dq.ph, dq.ph + count, dq.hw, rays->wl + first, q.extent, q.Nx, q.Ny, q.hist, stream);

@@ -141,7 +141,21 @@ struct DetOne {
     unsigned long long* ill;        // [2] ill-conditioned, timed out
     int projection;
     int xy_only;  // the z plane of ph is not wanted (binning and spectra use x, y only)
+    // compact hit list (ot_detector_req.fill): valid hits only, gathered at the front of the list's pieces
+    float* wl_out;
+    unsigned int* fill;
+    int piece_shift;
 };
+
+#define OT_HIT_PIECES_N 1024
+// entries per piece of a compact hit list of capacity n: the power of two at or above n / 1024 (at least 1024), so that a
+// ray's piece is a shift of its index; the last pieces of the 1024 stay empty
+__host__ __device__ static inline int hit_piece_shift(int64_t n) {
+    int s = 10;
+    while (((int64_t)OT_HIT_PIECES_N << s) < n) s++;
+    return s;
+}
+__host__ __device__ static inline int64_t hit_piece_len(int64_t n) { return (int64_t)1 << hit_piece_shift(n); }
 
 // Raytracer._hit_detector raytracer.py:922-1051, one lane per ray of [first, first+count), n_det detectors.
 // ill[0] += ill-conditioned rays, ill[1] += rays whose numeric hit search timed out.
@@ -195,7 +209,7 @@ OT_DEV void detector_hit(const ot_rays& R, int64_t r, bool active, DET& D, const
     const double* __restrict__ xp = R.p + r;
     const double* __restrict__ yp = R.p + r + N * (int64_t)nt;
     const int kq = nt >= 2 ? nt - 2 : 0;
-    const double zl = sp.zl, zq = sp.zq, xl = sp.xl, xq = sp.xq, yl = sp.yl, yq = sp.yq;
+    const double zl = sp.zl, zq = sp.zq, xq = sp.xq, yq = sp.yq;
     const float wq = sp.wq;
     const auto& det = D.det;
     ph = {0.0, 0.0, 0.0};
@@ -291,7 +305,29 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
     if (__ballot(!settled) != 0ull) {
         if (!settled) detector_hit<NUMERIC>(R, r, active, D, sp, sdir, ph, w, valid, any_ill, timeout);
     }
-    if (active && D.ph) {  // (no hit list wanted: the extent-only pass of images with an automatic extent)
+    if (D.fill) {
+        // Compact list: the wave's valid hits go, in any order, to the next free entries of a piece.  Ranks inside the
+        // wave from the ballot, the wave's base from ONE returning atomic on the piece's fill count; no barrier -- the
+        // other waves of the SIMD cover the round trip.  Wave k fills piece k mod 1024: the ~7000 waves in flight at any
+        // moment then spread their atomics over all 1024 counters.  (With contiguous pieces they all sat in the same two
+        // or three pieces and the atomics on those counters serialised: 11.8 ms for the hit kernel of C4 instead of 2.7;
+        // one atomic per workgroup behind an LDS count and three barriers: 3.8 ms.)  A piece receives at most
+        // ceil(waves / 1024) * 64 <= piece_len hits; the list's capacity is 1024 * piece_len entries, whatever the count.
+        const unsigned long long m = __ballot(valid);
+        if (m) {
+            const int64_t piece = (q >> 6) & (OT_HIT_PIECES_N - 1);
+            unsigned int base = 0u;
+            if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&D.fill[piece], (unsigned int)__popcll(m));
+            base = (unsigned int)__shfl((int)base, (int)__ffsll((long long)m) - 1);
+            if (valid) {
+                const int64_t i = (piece << D.piece_shift) + base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+                D.ph[i] = ph.x;
+                D.ph[i + ((int64_t)OT_HIT_PIECES_N << D.piece_shift)] = ph.y;  // the y plane follows the x plane's capacity
+                D.hw[i] = w;
+                D.wl_out[i] = R.wl[r];
+            }
+        }
+    } else if (active && D.ph) {  // (no hit list wanted: the extent-only pass of images with an automatic extent)
         D.ph[q] = valid ? ph.x : 0.0;
         D.ph[q + count] = valid ? ph.y : 0.0;
         if (!D.xy_only) D.ph[q + 2 * count] = valid ? ph.z : 0.0;
@@ -453,7 +489,7 @@ OT_DEV void observer_xyz_at(const double* obs, double l, double& xo, double& yo,
 __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* __restrict__ px, const double* __restrict__ py,
                                                       const float* __restrict__ w, const float* __restrict__ wl, RenderArgs a,
                                                       const double* __restrict__ table, double* __restrict__ hist,
-                                                      const int* __restrict__ spread) {
+                                                      const int* __restrict__ spread, const unsigned int* __restrict__ fill) {
     if (spread && spread[0]) return;  // the hits cover many pixels: the tile path bins them (ot_render_tiles.hpp)
     __shared__ double obs[OT_OBS_N * 3];
     __shared__ double hval[OT_HASH_N * 4];
@@ -465,9 +501,13 @@ __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* _
     // every workgroup takes one contiguous piece of the ray range: rays of one source are neighbours in the
     // storage and land in the same part of the image, so the LDS table of a workgroup sees fewer distinct pixels
     // and fewer workgroups fight over the same global addresses than with an interleaved assignment
-    const int64_t chunk = ((n + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
-    const int64_t i_end = ((int64_t)(blockIdx.x + 1) * chunk < n) ? (int64_t)(blockIdx.x + 1) * chunk : n;
-    for (int64_t i = (int64_t)blockIdx.x * chunk + threadIdx.x; i < i_end; i += blockDim.x) {
+    // (compact lists, `fill`: the workgroup walks whole pieces, each up to its fill count)
+    const int64_t plen = hit_piece_len(n);
+    const int64_t chunk = fill ? plen : ((n + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+    for (int64_t c = blockIdx.x; fill ? c < OT_HIT_PIECES_N : c * chunk < n; c += fill ? gridDim.x : n) {
+    int64_t i_end = ((c + 1) * chunk < n) ? (c + 1) * chunk : n;
+    if (fill) i_end = c * chunk + (int64_t)fill[c];
+    for (int64_t i = c * chunk + threadIdx.x; i < i_end; i += blockDim.x) {
         float wi = w[i];
         if (!(wi > 0.f || wi < 0.f)) continue;  // w == 0: adds nothing (and NaN weights are dropped)
         int32_t ix, iy;
@@ -502,6 +542,7 @@ __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* _
             unsafeAtomicAdd(hg + 2, zo * wm);
             unsafeAtomicAdd(hg + 3, 1.0 * wm);
         }
+    }
     }
     __syncthreads();
     for (int sidx = threadIdx.x; sidx < OT_HASH_N; sidx += blockDim.x) {

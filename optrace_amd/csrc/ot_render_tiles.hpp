@@ -46,6 +46,7 @@ struct TileRec {
 
 // everything the kernels exchange, carved out of one allocation
 struct TileWork {
+    const unsigned int* fill;    // compact hit list: entries of each piece that are filled (null: dense list)
     int* spread;                 // [1] probe verdict
     unsigned int* counts;        // [PIECES][K] hits of piece g in tile t, later the piece's write cursor
     unsigned long long* tot;     // [K] hits of each tile
@@ -61,7 +62,8 @@ OT_DEV int tile_of(const TileArgs& t, int32_t ix, int32_t iy, int& local) {
 }
 
 __global__ __launch_bounds__(1024) void tile_probe_kernel(TileArgs t, const double* __restrict__ px, const double* __restrict__ py,
-                                                          const float* __restrict__ w, int* __restrict__ spread) {
+                                                          const float* __restrict__ w, int* __restrict__ spread,
+                                                          const unsigned int* __restrict__ fill) {
     extern __shared__ int pset[];  // OT_TILE_PROBE_SET keys
     __shared__ int distinct;
     for (int i = threadIdx.x; i < OT_TILE_PROBE_SET; i += blockDim.x) pset[i] = -1;
@@ -70,7 +72,13 @@ __global__ __launch_bounds__(1024) void tile_probe_kernel(TileArgs t, const doub
     const int64_t S = t.n < OT_TILE_PROBE ? t.n : OT_TILE_PROBE;
     const int64_t stride = t.n / S;
     for (int64_t k = threadIdx.x; k < S; k += blockDim.x) {
-        const int64_t i = k * stride;
+        int64_t i = k * stride;
+        if (fill) {  // compact list: sample k from piece k mod 1024, spread over what the piece holds
+            const int64_t pc = k % OT_TILE_PIECES;
+            const unsigned int f = fill[pc];
+            if (!f) continue;
+            i = pc * t.piece + (int64_t)(((unsigned long long)(k / OT_TILE_PIECES) * 2654435761ull) % f);
+        }
         const float wi = w[i];
         if (!(wi > 0.f || wi < 0.f)) continue;
         int32_t ix, iy;
@@ -101,7 +109,8 @@ __global__ __launch_bounds__(1024) void tile_count_kernel(TileArgs t, const doub
     for (int i = threadIdx.x; i < t.K; i += blockDim.x) cnt[i] = 0u;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * t.piece;
-    const int64_t i1 = (i0 + t.piece < t.n) ? i0 + t.piece : t.n;
+    int64_t i1 = (i0 + t.piece < t.n) ? i0 + t.piece : t.n;
+    if (wk.fill) i1 = i0 + (int64_t)wk.fill[blockIdx.x];
     for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const float wi = w[i];
         if (!(wi > 0.f || wi < 0.f)) continue;
@@ -176,7 +185,8 @@ __global__ __launch_bounds__(1024) void tile_scatter_kernel(TileArgs t, const do
     for (int i = threadIdx.x; i < t.K; i += blockDim.x) cur[i] = wk.counts[(size_t)blockIdx.x * t.K + i];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * t.piece;
-    const int64_t i1 = (i0 + t.piece < t.n) ? i0 + t.piece : t.n;
+    int64_t i1 = (i0 + t.piece < t.n) ? i0 + t.piece : t.n;
+    if (wk.fill) i1 = i0 + (int64_t)wk.fill[blockIdx.x];
     for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const float wi = w[i];
         if (!(wi > 0.f || wi < 0.f)) continue;

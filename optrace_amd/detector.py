@@ -17,7 +17,9 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
     """Hit search for several detectors in one pass over the ray sections (`ot_detector_hits_multi`).
 
     requests: dicts with surf_desc (_capi.Surface), projection (int), want_extent (bool), crop ([x0, x1, y0, y1] or
-    None: hits outside come back with weight 0, raytracer.py:1036-1040).
+    None: hits outside come back with weight 0, raytracer.py:1036-1040); compact (bool): only the valid hits are written,
+    gathered at the front of the list's 1024 pieces (`ot_detector_req.fill`) -- the tuple then carries (wl, fill) in
+    fifth place, the hit wavelengths and the fill counts as device tensors.
     -> list of (ph flat f64 device tensor: x plane, y plane and, with want_z, z plane of count entries each, hw (count)
     f32 device tensor, extent4 or None, ill_count).  Binning and spectra use x and y only."""
     lib = _capi.load_library()
@@ -30,8 +32,12 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
     for k, rq in enumerate(requests):
         sd = rq["surf_desc"]
         want_z = bool(rq.get("want_z", False))
-        ph = torch.empty((3 if want_z else 2) * count, dtype=torch.float64, device=dev)
-        hw = torch.empty(count, dtype=torch.float32, device=dev)
+        compact = bool(rq.get("compact", False)) and not want_z
+        cap = _capi.HIT_PIECES * int(lib.ot_hit_piece_len(int(count))) if compact else count  # entries per plane
+        ph = torch.empty((3 if want_z else 2) * cap, dtype=torch.float64, device=dev)
+        hw = torch.empty(cap, dtype=torch.float32, device=dev)
+        wl_c = torch.empty(cap, dtype=torch.float32, device=dev) if compact else None
+        fill = torch.zeros(_capi.HIT_PIECES, dtype=torch.int32, device=dev) if compact else None
         ext = None
         if rq["want_extent"]:
             ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float64, device=dev)
@@ -43,19 +49,21 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         r.xy_only = 0 if want_z else 1
         r.crop4 = None if crop4 is None else C.addressof(crop4)
         r.ph, r.hw, r.extent4 = ph.data_ptr(), hw.data_ptr(), (ext.data_ptr() if ext is not None else None)
+        r.wl_out, r.fill = (wl_c.data_ptr(), fill.data_ptr()) if compact else (None, None)
         r.ill_count = ill.data_ptr() + 16 * k
         # closed-form hits (flat / conic detectors) can neither be ill-conditioned nor time out
         numeric = sd.kind >= _capi.SURF_ASPHERE and sd.z_min != sd.z_max
         any_numeric = any_numeric or numeric
-        outs.append([ph, hw, ext, numeric])
+        outs.append([ph, hw, ext, numeric, (wl_c, fill) if compact else None])
     rs = rays._rays_struct()
     _capi.check(lib.ot_detector_hits_multi(C.byref(rs), int(first), int(count), reqs, n, stream_ptr()))
     ill_h = ill.cpu().numpy() if any_numeric else np.zeros(2 * n, dtype=np.int64)  # no read-back, no sync otherwise
     res = []
-    for k, (ph, hw, ext, numeric) in enumerate(outs):
+    for k, (ph, hw, ext, numeric, comp) in enumerate(outs):
         if ill_h[2 * k + 1]:
             raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
-        res.append((ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill_h[2 * k])))
+        one = (ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill_h[2 * k]))
+        res.append(one + (comp,) if comp is not None else one)
     return res
 
 
@@ -82,6 +90,7 @@ def detector_extents(rays, first: int, count: int, requests: list) -> list:
         r.xy_only = 1
         r.crop4 = None
         r.ph, r.hw = None, None
+        r.wl_out, r.fill = None, None
         r.extent4 = ext.data_ptr() + 32 * k
         r.ill_count = ill.data_ptr() + 16 * k
         any_numeric = any_numeric or (sd.kind >= _capi.SURF_ASPHERE and sd.z_min != sd.z_max)

@@ -47,6 +47,9 @@ class Raytracer(Group):
     ITER_RAYS_STEP: int = None
     """Rays per chunk of `iterative_render` (the reference: 1 M, to bound host RAM, raytracer.py:40).  None: as many
     as ITER_STORAGE_BYTES of ray storage hold, in equal chunks."""
+    COMPACT_HITS_FROM: int = 1 << 21
+    """`detector_image` with an automatic extent: from this many rays on the hit list between hit search and binning
+    holds the valid hits only (`ot_detector_req.fill`)."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
     """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are
     19 M rays of a 15-surface scene with polarisation or 93 M rays of a two-surface scene without."""
@@ -455,19 +458,24 @@ class Raytracer(Group):
             # rays outside a user extent are dropped (raytracer.py:1036-1040): the hit kernel gives them weight 0
             groups.setdefault((rq["Ns"], rq["Ne"]), []).append(
                 (n, dict(surf_desc=rq["surf_desc"], want_extent=rq["crop"] is None,
-                         projection=_capi.PROJECTIONS[rq["projection"]], crop=rq["crop"], want_z=rq["want_z"])))
+                         projection=_capi.PROJECTIONS[rq["projection"]], crop=rq["crop"], want_z=rq["want_z"],
+                         compact=bool(specs[n].get("compact", False)))))
 
         out = [None] * len(specs)
         for (Ns, Ne), part_all in groups.items():
             for b in range(0, len(part_all), 8):
                 part = part_all[b:b + 8]
                 res = _detector.detector_hits_multi(self.rays, Ns, Ne - Ns, [r for _, r in part])
-                for (n, _), (ph, hw, ext4, ill_count) in zip(part, res):
+                for (n, _), one in zip(part, res):
+                    ph, hw, ext4, ill_count = one[:4]
                     rq = reqs[n]
                     extent_out = rq["crop"]
                     if extent_out is None:
                         extent_out = ext4.copy() if np.all(np.isfinite(ext4)) else rq["centre"]
-                    out[n] = (ph, hw, self.rays._dev["wl"][Ns:Ne], extent_out, rq["projection"], ill_count, rq["desc"])
+                    wl = self.rays._dev["wl"][Ns:Ne]
+                    if len(one) > 4:  # compact list: its own wavelengths, and the fill counts ride along with them
+                        wl = one[4]
+                    out[n] = (ph, hw, wl, extent_out, rq["projection"], ill_count, rq["desc"])
         return out
 
     def _render_detectors(self, specs: list, limits: list, into: list = None, **kwargs) -> list:
@@ -554,6 +562,8 @@ class Raytracer(Group):
         if source_index is not None:
             label = f"Rays from RS{source_index} at {label}"
         image = RenderImage(extent=extent_out, projection=projection, long_desc=label)
+        if isinstance(wavelengths, tuple):  # compact hit list: (wavelengths, fill counts)
+            wavelengths, kwargs["_fill"] = wavelengths
         image.render(xy, weights, wavelengths, limit=limit, **kwargs)
         self._warn_ill(ill_count, detector_index)
         return image
@@ -576,6 +586,8 @@ class Raytracer(Group):
         # way.  The extent-only pass serves where hit lists would have to be kept or exchanged: the first chunk of
         # `iterative_render` and the sharded forms in distributed.py.)
         kwargs.pop("_unfused", None)
+        # (long bundles: the hit list holds the valid hits only, gathered piece-wise -- a third of the bytes for C4)
+        spec["compact"] = extent is None and self.rays.N >= self.COMPACT_HITS_FROM
         hits = self._hit_detectors("Detector Image", [spec])[0]
         return self._image_from_hits(hits, detector_index, source_index, limit, **kwargs)
 

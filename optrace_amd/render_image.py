@@ -121,13 +121,13 @@ class RenderImage(BaseClass):
         return Nx, Ny
 
     def render(self, p=None, w=None, wl=None, limit: float = None, _dont_filter: bool = False,
-               _keep_on_device: bool = False, _into: "torch.Tensor" = None) -> None:
+               _keep_on_device: bool = False, _into: "torch.Tensor" = None, _fill: "torch.Tensor" = None) -> None:
         """Bin hit positions into the XYZW image (render_image.py:361-421).
 
         p (n, 3) positions, w (n,) powers, wl (n,) wavelengths: NumPy arrays, or device tensors in the
         layout `ot_detector_hits` produces (p flat component-major).  Hits with w == 0 add nothing.
         The image stays in HBM; `_data` copies it to the host when it is first read (`_keep_on_device` is accepted
-        for older callers and has no effect).
+        for older callers and has no effect).  `_fill`: the device lists are a compact hit list (`ot_detector_req.fill`).
         """
         self._limit = limit
         self._fix_extent()
@@ -153,8 +153,12 @@ class RenderImage(BaseClass):
                 px, py = to_dev(p[:, 0], np.float64), to_dev(p[:, 1], np.float64)
                 dw, dwl = to_dev(w, np.float32), to_dev(wl, np.float32)
             ext = (C.c_double * 4)(*[float(v) for v in self.extent])
-            _capi.check(lib.ot_render_accumulate(n, ptr(px), ptr(py), ptr(dw), ptr(dwl), ext, Nx, Ny,
-                                                 ptr(hist), stream_ptr()))
+            if _fill is not None:
+                _capi.check(lib.ot_render_accumulate_compact(n, ptr(_fill), ptr(px), ptr(py), ptr(dw), ptr(dwl), ext,
+                                                             Nx, Ny, ptr(hist), stream_ptr()))
+            else:
+                _capi.check(lib.ot_render_accumulate(n, ptr(px), ptr(py), ptr(dw), ptr(dwl), ext, Nx, Ny,
+                                                     ptr(hist), stream_ptr()))
         self._dev = hist.view(Ny, Nx, 4)
         self._host = None
         if self._limit is not None and not _dont_filter:

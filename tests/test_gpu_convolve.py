@@ -5,7 +5,9 @@ The fixture cases use PSFs with the pixel pitch of the image, where the referenc
 identity: everything else of the function -- gamma removal, PSF normalisation, colour PSFs through XYZ -> linear sRGB,
 padding modes, flipping and scaling by m, full / keep_size slicing, the result extent, the final gamut mapping with its
 rendering intents -- is pinned to the reference at 1e-9.  The area resize for other pitch ratios is checked by its
-defining properties (sum preserved, block means for integer ratios); that part is not pinned by a reference value."""
+defining properties (sum preserved, block means for integer ratios) and by the reference's own behavioural tests for
+it, restated below with the reference's tolerances (analytic Gaussian through a PSF of half the pitch; independence of the
+PSF's resolution); it is not pinned by a reference VALUE (no OpenCV in the build container)."""
 import numpy as np
 import pytest
 import torch
@@ -70,6 +72,79 @@ def test_convolve_finer_psf_keeps_power_and_position():
     cx = (lin * xs).sum() / lin.sum() / (d.shape[1] - 1) * (res.extent[1] - res.extent[0]) + res.extent[0]
     cy = (lin * ys).sum() / lin.sum() / (d.shape[0] - 1) * (res.extent[3] - res.extent[2]) + res.extent[2]
     assert abs(cx - 0.2) < 2e-3 and abs(cy) < 2e-3
+
+
+@pytest.mark.parametrize("sz", [400, 401, 1999, 2000])
+def test_coordinate_value_correctness(sz):
+    """After the reference's test_coordinate_value_correctness (tests/test_convolve.py:178-224), same numbers and
+    tolerances: a Gaussian image convolved with a Gaussian PSF of HALF its pixel pitch -- the PSF goes through the area
+    resize with a ratio of two, the case no fixture covers -- must give the analytic Gaussian of the summed variances on the
+    result's own coordinates (mean absolute deviation 5e-5 after normalisation), symmetric under transposition to 1e-12;
+    odd and even, small and large pixel counts."""
+    from optrace_amd.image import srgb_linear_to_srgb, srgb_to_srgb_linear
+
+    def gaussian(d):
+        sig = 0.175  # sigma approximating the zeroth order of an Airy disc
+        ds = 5 * sig
+        Y, X = np.mgrid[-ds:ds:sz * 1j, -ds:ds:sz * 1j]
+        Z = np.exp(-(X ** 2 + Y ** 2) / 2 / sig ** 2)
+        return np.repeat(Z[:, :, np.newaxis], 3, axis=2), [2 * ds * d / 1000, 2 * ds * d / 1000]
+
+    psf, s_psf = gaussian(1)
+    psf = srgb_linear_to_srgb(psf)[:, :, 0]
+    img, s_img = gaussian(2)
+    img = srgb_linear_to_srgb(img)
+    with ot.global_options.no_warnings():
+        res = ot.convolve(ot.RGBImage(img, s_img), ot.GrayscaleImage(psf, s_psf))
+    img2, s2 = res.data, res.s
+    img2 = srgb_to_srgb_linear(img2)[:, :, 0]
+    Y, X = np.mgrid[-s2[0] / 2:s2[0] / 2:img2.shape[1] * 1j, -s2[1] / 2:s2[1] / 2:img2.shape[0] * 1j]
+    Z = np.exp(-3.265306122449e6 * (X ** 2 + Y ** 2))
+    Z /= np.max(Z)
+    img2 = img2 / np.max(img2)
+    diff = img2 - Z
+    assert np.mean(np.abs(diff)) < 5e-5
+    assert np.mean(np.abs(diff - diff.T)) < 1e-12
+
+
+def _chart(n: int) -> np.ndarray:
+    """Synthetic stand-in for the reference's ETDRS chart (an image file): white bars and blocks of several sizes on
+    black, sampled at n x n from one continuous description so that every resolution shows the same object."""
+    y, x = (np.mgrid[0:n, 0:n] + 0.5) / n
+    img = np.zeros((n, n))
+    for k, (x0, w) in enumerate([(0.08, 0.16), (0.30, 0.10), (0.46, 0.06), (0.58, 0.04), (0.68, 0.025), (0.75, 0.015)]):
+        img[(x > x0) & (x < x0 + w) & (y > 0.1) & (y < 0.45)] = 1.0
+        img[(y > x0) & (y < x0 + w) & (x > 0.55 + 0.0 * k) & (x < 0.92) & (y > 0.55)] = 1.0
+    img[(np.hypot(x - 0.25, y - 0.72) < 0.13) & (np.hypot(x - 0.25, y - 0.72) > 0.07)] = 1.0
+    return img
+
+
+@pytest.mark.parametrize("s_psf", [0.01, 0.1, 0.99])
+def test_size_consistency(s_psf):
+    """After the reference's test_size_consistency (tests/test_convolve.py:391-416): the same object convolved with the same
+    PSF must not depend on the resolution the PSF is sampled at -- PSFs of 2000, 1999, 400, 399 pixels a side against an
+    image of fixed resolution, so the area resize runs with ratios from below one to forty, odd and even.  Tolerances of the
+    reference: 1e-3 between the two finest, 5e-3 down to 400 pixels."""
+    img = ot.GrayscaleImage(_chart(500), [1, 1])
+
+    def psf_at(res):
+        ds = s_psf / 2
+        Y, X = np.mgrid[-ds:ds:res * 1j, -ds:ds:res * 1j]
+        sig = s_psf / 8
+        core = np.exp(-(X ** 2 + Y ** 2) / 2 / sig ** 2)
+        halo = 0.1 * np.exp(-(np.hypot(X, Y) - 0.3 * s_psf) ** 2 / 2 / (sig / 3) ** 2)  # ring: structure finer than the core
+        return ot.GrayscaleImage((core + halo) / (core + halo).max(), [s_psf, s_psf])
+
+    ref = None
+    with ot.global_options.no_warnings():
+        for i, res in enumerate([2000, 1999, 400, 399]):
+            d = ot.convolve(img, psf_at(res), keep_size=True).data  # (on the image's own grid, whatever the PSF's)
+            if ref is None:
+                ref = d
+                continue
+            assert d.shape == ref.shape
+            dev = np.mean(np.abs(d - ref))
+            assert dev < (1e-3 if i == 1 else 5e-3), (res, dev)
 
 
 def test_convolve_argument_errors():

@@ -170,3 +170,45 @@ def test_fused_detector_not_behind_the_last_surface(path):
             with pinned(path):
                 same_image(RT2.detector_image(extent=[-40., 40., -40., 40.]),
                            RT2.detector_image(extent=[-40., 40., -40., 40.], _unfused=True))
+
+
+# ---- compact hit lists: automatic extents on long bundles (ot_detector_req.fill, ot_render_accumulate_compact) -------
+@pytest.mark.parametrize("path", ["direct", "tiles", None])
+@pytest.mark.parametrize("N", [3000, 400_001, 2_500_000])
+def test_compact_hit_list_equals_dense_list(path, N):
+    """`detector_image(extent=None)` through a hit list that holds the valid hits only, gathered at the front of its 1024
+    pieces, against the dense list (one entry per ray, weight 0 for no hit): same extent, same pixels, sums to 1e-11 --
+    with both binning paths, ray counts that leave pieces empty, ragged and (2.5 M rays: 3 workgroups per piece) shared."""
+    RT = image_scene(N=N)
+    old = RT.COMPACT_HITS_FROM
+    try:
+        with pinned(path), ot.global_options.no_warnings():
+            type(RT).COMPACT_HITS_FROM = 1 << 60
+            dense = RT.detector_image()
+            type(RT).COMPACT_HITS_FROM = 1
+            compact = RT.detector_image()
+            one_src = RT.detector_image(source_index=0)
+    finally:
+        type(RT).COMPACT_HITS_FROM = old
+    same_image(dense, compact)
+    same_image(dense, one_src)
+    assert abs(dense.power() - compact.power()) <= 1e-12 * dense.power()
+
+
+def test_compact_hit_list_on_a_point_image_and_without_hits():
+    """PSF-like image (the direct binning path by the probe's verdict) and a detector no ray reaches."""
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, seed=5)
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[1, 1]), pos=[1500, 0, 150]))
+        RT.trace(2_300_000)
+        old = RT.COMPACT_HITS_FROM
+        try:
+            type(RT).COMPACT_HITS_FROM = 1 << 60
+            dense, dense_empty = RT.detector_image(), RT.detector_image(detector_index=1)
+            type(RT).COMPACT_HITS_FROM = 1
+            compact, compact_empty = RT.detector_image(), RT.detector_image(detector_index=1)
+        finally:
+            type(RT).COMPACT_HITS_FROM = old
+    same_image(dense, compact)
+    assert compact_empty.power() == 0.0 and dense_empty.power() == 0.0
+    np.testing.assert_array_equal(compact_empty.extent, dense_empty.extent)
