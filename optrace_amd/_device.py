@@ -48,3 +48,27 @@ def f_order_flat(a: np.ndarray, dtype=np.float64) -> np.ndarray:
 def from_f_order(t: torch.Tensor, n: int, ncomp: int) -> np.ndarray:
     """flat component-major device buffer -> (n, ncomp) F-ordered host array."""
     return t.cpu().numpy().reshape(ncomp, n).T
+
+
+_mailbox: dict = {}
+
+
+def mailbox(n: int = 128) -> tuple[torch.Tensor, np.ndarray]:
+    """A pinned, device-mapped host buffer of n 8-byte words (one per thread of the caller, reused): small results a
+    kernel writes for the host with plain stores -- the extents of the detector hits -- arrive with the stream synchronisation, without a
+    device-to-host copy and without a host-to-device copy for their start values (two tiny DMA transfers and a
+    device allocation less per call).
+    -> (torch view as int64 for data_ptr(), numpy int64 view of the same memory).  The caller must synchronise the stream
+    before reading and must not have two calls in flight."""
+    import threading
+    key = (threading.get_ident(), n)
+    mb = _mailbox.get(key)
+    if mb is None:
+        t = torch.zeros(n, dtype=torch.int64).pin_memory()
+        mb = _mailbox[key] = (t, t.numpy())
+    return mb
+
+
+def sync_stream() -> None:
+    """Wait for torch's current stream (compute queue signal: not affected by busy DMA engines)."""
+    torch.cuda.current_stream().synchronize()

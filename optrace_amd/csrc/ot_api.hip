@@ -1255,11 +1255,25 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
         n_ext += reqs[k].extent4 != nullptr;
     }
     if (count == 0) return OT_OK;
-    // one stream-ordered scratch block: the detector records, then the extent slot tables
-    const size_t o_slots = align_up(sizeof(DetOne) * n_reqs);
-    const size_t total = o_slots + sizeof(unsigned long long) * 4 * OT_EXT_SLOTS * (size_t)n_ext;
+    // scratch: the detector records, then the extent slot tables -- a few KB, kept per thread and stream for the life of
+    // the process (launches on one stream run in order, so the block can serve call after call).  It used to come from
+    // the stream-ordered pool; that cost 0.2 ms per call, and 7-58 ms whenever the driver was still busy with memory a
+    // large free had returned to it (profiles/r3/readback_after_free.txt).
+    const size_t o_slots = align_up(sizeof(DetOne) * OT_DET_MAX);
+    const size_t total = o_slots + sizeof(unsigned long long) * 4 * OT_EXT_SLOTS * (size_t)OT_DET_MAX;
     char* scratch = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&scratch, total, st));
+    {
+        struct Block { int dev; hipStream_t st; char* p; };
+        static thread_local std::vector<Block> blocks;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        for (auto& b : blocks)
+            if (b.dev == dev && b.st == st) scratch = b.p;
+        if (!scratch) {
+            HIP_TRY(hipMalloc((void**)&scratch, total));
+            blocks.push_back({dev, st, scratch});
+        }
+    }
     unsigned long long* slots = (unsigned long long*)(scratch + o_slots);
     int e = 0;
     for (int k = 0; k < n_reqs; k++) {
@@ -1307,7 +1321,6 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
                 hipLaunchKernelGGL(extent_final_kernel, dim3(1), dim3(64), 0, st, slots + (size_t)4 * OT_EXT_SLOTS * e++, reqs[k].extent4);
         err = hipGetLastError();
     }
-    (void)hipFreeAsync(scratch, st);
     HIP_TRY(err);
     return OT_OK;
 }

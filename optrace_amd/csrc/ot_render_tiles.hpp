@@ -27,6 +27,7 @@
 #define OT_TILE_PROBE 4096         // hits the probe looks at
 #define OT_TILE_PROBE_SET 8192     // hash set of the probe (ints, 32 KB)
 #define OT_TILE_DISTINCT 1024      // more distinct pixels than this among the probed hits: tile path
+#define OT_TILE_DISTINCT_COMPACT 128  // the same for compact hit lists (see tile_probe_kernel)
 
 struct TileArgs {
     RenderArgs a;
@@ -99,7 +100,10 @@ __global__ __launch_bounds__(1024) void tile_probe_kernel(TileArgs t, const doub
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) spread[0] = distinct > OT_TILE_DISTINCT;
+    // Compact lists scatter neighbouring rays over all pieces, so a workgroup of the direct kernel no longer sees one
+    // corner of the image: its LDS table overflows earlier and a wrong verdict is expensive (C5's diffraction band, near
+    // the dense threshold: 47 instead of 3.8 ms when the probe said "direct").  Only clearly point-like images stay direct.
+    if (threadIdx.x == 0) spread[0] = distinct > (fill ? OT_TILE_DISTINCT_COMPACT : OT_TILE_DISTINCT);
 }
 
 __global__ __launch_bounds__(1024) void tile_count_kernel(TileArgs t, const double* __restrict__ px, const double* __restrict__ py,

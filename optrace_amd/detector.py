@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._device import require_device, stream_ptr, ptr, to_dev, f_order_flat, from_f_order
+from ._device import require_device, stream_ptr, ptr, to_dev, f_order_flat, from_f_order, mailbox, sync_stream
 
 
 def detector_hits_multi(rays, first: int, count: int, requests: list):
@@ -27,6 +27,10 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
     n = len(requests)
     reqs = (_capi.DetectorReq * n)()
     keep, outs = [], []
+    # extents go straight to a pinned host buffer (plain stores of one small kernel), 4 doubles per request behind 2n unused
+    # words; the ill-conditioned counts are device atomics and stay in device memory (read back for numeric detectors only)
+    mb_t, mb = mailbox()
+    mbf = mb.view(np.float64)
     ill = torch.zeros(2 * n, dtype=torch.int64, device=dev)
     any_numeric = False
     for k, rq in enumerate(requests):
@@ -40,7 +44,8 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         fill = torch.zeros(_capi.HIT_PIECES, dtype=torch.int32, device=dev) if compact else None
         ext = None
         if rq["want_extent"]:
-            ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float64, device=dev)
+            ext = 2 * n + 4 * k  # word offset in the mailbox
+            mbf[ext:ext + 4] = [np.inf, -np.inf, np.inf, -np.inf]
         crop4 = None if rq.get("crop") is None else (C.c_double * 4)(*(float(v) for v in rq["crop"]))
         keep.append((sd, crop4))
         r = reqs[k]
@@ -48,7 +53,7 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         r.projection = int(rq["projection"])
         r.xy_only = 0 if want_z else 1
         r.crop4 = None if crop4 is None else C.addressof(crop4)
-        r.ph, r.hw, r.extent4 = ph.data_ptr(), hw.data_ptr(), (ext.data_ptr() if ext is not None else None)
+        r.ph, r.hw, r.extent4 = ph.data_ptr(), hw.data_ptr(), (mb_t.data_ptr() + 8 * ext if ext is not None else None)
         r.wl_out, r.fill = (wl_c.data_ptr(), fill.data_ptr()) if compact else (None, None)
         r.ill_count = ill.data_ptr() + 16 * k
         # closed-form hits (flat / conic detectors) can neither be ill-conditioned nor time out
@@ -57,12 +62,14 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         outs.append([ph, hw, ext, numeric, (wl_c, fill) if compact else None])
     rs = rays._rays_struct()
     _capi.check(lib.ot_detector_hits_multi(C.byref(rs), int(first), int(count), reqs, n, stream_ptr()))
-    ill_h = ill.cpu().numpy() if any_numeric else np.zeros(2 * n, dtype=np.int64)  # no read-back, no sync otherwise
+    ill_h = ill.cpu().numpy() if any_numeric else np.zeros(2 * n, dtype=np.int64)  # no read-back otherwise
+    if any(o[2] is not None for o in outs):
+        sync_stream()  # the mailbox is complete; no wait at all for closed-form detectors with user extents
     res = []
     for k, (ph, hw, ext, numeric, comp) in enumerate(outs):
         if ill_h[2 * k + 1]:
             raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
-        one = (ph, hw, (ext.cpu().numpy() if ext is not None else None), int(ill_h[2 * k]))
+        one = (ph, hw, (mbf[ext:ext + 4].copy() if ext is not None else None), int(ill_h[2 * k]))
         res.append(one + (comp,) if comp is not None else one)
     return res
 
@@ -78,8 +85,10 @@ def detector_extents(rays, first: int, count: int, requests: list) -> list:
     n = len(requests)
     reqs = (_capi.DetectorReq * n)()
     keep = []
+    mb_t, mb = mailbox()
+    mbf = mb.view(np.float64)
+    mbf[2 * n:6 * n] = [np.inf, -np.inf, np.inf, -np.inf] * n
     ill = torch.zeros(2 * n, dtype=torch.int64, device=dev)
-    ext = torch.tensor([np.inf, -np.inf, np.inf, -np.inf] * n, dtype=torch.float64, device=dev)
     any_numeric = False
     for k, rq in enumerate(requests):
         sd = rq["surf_desc"]
@@ -91,12 +100,13 @@ def detector_extents(rays, first: int, count: int, requests: list) -> list:
         r.crop4 = None
         r.ph, r.hw = None, None
         r.wl_out, r.fill = None, None
-        r.extent4 = ext.data_ptr() + 32 * k
+        r.extent4 = mb_t.data_ptr() + 8 * (2 * n + 4 * k)
         r.ill_count = ill.data_ptr() + 16 * k
         any_numeric = any_numeric or (sd.kind >= _capi.SURF_ASPHERE and sd.z_min != sd.z_max)
     rs = rays._rays_struct()
     _capi.check(lib.ot_detector_hits_multi(C.byref(rs), int(first), int(count), reqs, n, stream_ptr()))
-    ext_h = ext.cpu().numpy().reshape(n, 4)
+    sync_stream()
+    ext_h = mbf[2 * n:6 * n].copy().reshape(n, 4)
     ill_h = ill.cpu().numpy() if any_numeric else np.zeros(2 * n, dtype=np.int64)
     if ill_h[1::2].any():
         raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
