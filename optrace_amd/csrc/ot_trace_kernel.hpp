@@ -25,8 +25,18 @@
 #ifndef OT_TRACE_MIN_WAVES_F0_LINES
 #define OT_TRACE_MIN_WAVES_F0_LINES 6
 #endif
-#define OT_TRACE_WAVES(FEAT, SPEC, POL) \
-    ((FEAT) == 0 ? ((SPEC) == 2 ? OT_TRACE_MIN_WAVES_F0_LINES : OT_TRACE_MIN_WAVES_F0) : OT_TRACE_MIN_WAVES)
+// level 1 (ideal lenses, filters, HURB on closed-form surfaces) fits four waves without a spill once asked (127-128
+// registers instead of 129-131); level 3 (the same on top of the asphere search, 140-148) spills 4-10 values at four
+// waves and is still faster there: the asphere test scene 1.56 -> 1.47 ms at 1e7 rays (two runs each on one box)
+#ifndef OT_TRACE_MIN_WAVES_F1
+#define OT_TRACE_MIN_WAVES_F1 4
+#endif
+#ifndef OT_TRACE_MIN_WAVES_F3
+#define OT_TRACE_MIN_WAVES_F3 4
+#endif
+#define OT_TRACE_WAVES(FEAT, SPEC, POL)                                                                    \
+    ((FEAT) == 0 ? ((SPEC) == 2 ? OT_TRACE_MIN_WAVES_F0_LINES : OT_TRACE_MIN_WAVES_F0)                     \
+                 : ((FEAT) == 1 ? OT_TRACE_MIN_WAVES_F1 : ((FEAT) == 3 ? OT_TRACE_MIN_WAVES_F3 : OT_TRACE_MIN_WAVES)))
 
 struct RangeRec {  // one source range in device memory (scenes with more than OT_MAX_RANGES ranges)
     int64_t first, count;

@@ -23,11 +23,14 @@ main = rows[0]["Kernel_Name"]  # the timed configuration comes first; the second
 rows = [r for r in rows if r["Kernel_Name"] == main]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 4) for r in rows]
-# launch order of bench.py: 1 small set-up trace, 30 warm-up traces, 50 timed traces (Raytracer.trace), then 60 raw
-# back-to-back launches and one more trace for the detector image
-timed = ms[31:81]
+# launch order of bench.py: 1 small set-up trace, S settle traces (set-up, untimed: `settle_launches` of the JSON line),
+# W warm-up traces, K timed traces (Raytracer.trace), then raw back-to-back launches and one more trace for the detector image
 line = [l for l in open(os.path.join(out, "bench_stats.log")) if l.startswith("{")]
-json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu   (1 set-up + 30 warm-up + 50 timed Raytracer.trace calls, then 60 raw launches + 1)",
+bl = json.loads(line[-1])
+i0 = 1 + int(bl.get("settle_launches", 0)) + int(bl["warmup"])
+timed = ms[i0:i0 + int(bl["steps"])]
+json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu   (1 set-up + settle + warm-up + timed Raytracer.trace calls, then raw launches + 1; counts in bench_line)",
+           "timed_launch_index_range": [i0, i0 + int(bl["steps"])],
            "kernel": rows[0]["Kernel_Name"][:40], "launch_ms": ms, "timed_mean_ms": sum(timed) / len(timed),
            "bench_line": json.loads(line[-1]) if line else None}, open(os.path.join(out, "trace_kernel_launches.json"), "w"), indent=1)
 pmc = {"rays": 10000000, "pol": True, "unit": "KB per launch",
