@@ -48,10 +48,10 @@ def surface_params(s) -> dict:
 
 
 def gen_leaf_surfaces(which: int = 1):
-    rng = np.random.default_rng(1234 if which == 1 else 4321)
+    rng = np.random.default_rng({1: 1234, 2: 4321, 3: 2468}[which])
     out = {}
     with ot.global_options.no_warnings():
-        zoo = scenes.surface_zoo(ot) if which == 1 else scenes.surface_zoo2(ot)
+        zoo = {1: scenes.surface_zoo, 2: scenes.surface_zoo2, 3: scenes.surface_zoo3}[which](ot)
     for name, sf in zoo.items():
         n = 1500
         ext = np.array(sf.extent)
@@ -94,7 +94,7 @@ def gen_leaf_surfaces(which: int = 1):
         for k, v in surface_params(sf).items():
             out[f"{name}/param/{k}"] = v
     out["names"] = np.array(list(zoo.keys()))
-    fname = "leaf_surfaces.npz" if which == 1 else "leaf_surfaces2.npz"
+    fname = {1: "leaf_surfaces.npz", 2: "leaf_surfaces2.npz", 3: "leaf_surfaces3.npz"}[which]
     np.savez_compressed(HERE / fname, **out)
     print(fname, len(out))
 
@@ -485,6 +485,8 @@ if __name__ == "__main__":
         gen_leaf_surfaces()
     if "leaf2" in which:
         gen_leaf_surfaces(2)
+    if "leaf3" in which:
+        gen_leaf_surfaces(3)
     if "media" in which:
         gen_leaf_media()
     if "trace" in which:

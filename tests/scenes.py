@@ -404,6 +404,31 @@ def surface_zoo(ot):
     return z
 
 
+def surface_zoo3(ot):
+    """Aspheres of every coefficient count the device code distinguishes (the hit search is compiled per count for
+    1 .. 4 coefficients and jumps into an unrolled chain for 5 .. 12, ot_device.hpp::AsphereSag), flipped and strongly
+    conic ones; own fixture file so that the random streams of the older zoos stay put."""
+    z = {}
+    with ot.global_options.no_warnings():
+        z["asph_c1"] = ot.AsphericSurface(r=3.0, R=10.0, k=-1.3, coeff=[1.5e-3])
+        z["asph_c2_neg"] = ot.AsphericSurface(r=3.5, R=-9.0, k=0.6, coeff=[-2e-3, 6e-5])
+        z["asph_c4"] = ot.AsphericSurface(r=4.0, R=14.0, k=-0.4, coeff=[1e-3, -3e-5, 4e-7, -2e-9])
+        z["asph_c5"] = ot.AsphericSurface(r=4.0, R=-16.0, k=2.0, coeff=[-8e-4, 2e-5, -3e-7, 2e-9, -5e-12])
+        z["asph_c8"] = ot.AsphericSurface(r=3.0, R=11.0, k=-2.5,
+                                          coeff=[2e-3, -1e-4, 3e-6, -5e-8, 6e-10, -4e-12, 2e-14, -1e-16])
+        z["asph_c12"] = ot.AsphericSurface(r=2.5, R=8.0, k=0.0,
+                                           coeff=[1e-3, -2e-4, 3e-5, -4e-6, 5e-7, -6e-8, 7e-9, -8e-10, 9e-11, -1e-11,
+                                                  1e-12, -1e-13])
+        f = ot.AsphericSurface(r=3.0, R=12.0, k=-0.7, coeff=[1e-3, -2e-5, 1e-7])
+        f.flip()
+        z["asph_c3_flipped"] = f
+    z["conic_oblate"] = ot.ConicSurface(r=2.5, R=6.0, k=1.8)
+    z["conic_hyper_neg"] = ot.ConicSurface(r=3.0, R=-7.0, k=-3.2)
+    for j, (name, s) in enumerate(z.items()):
+        s.move_to([0.08 * j - 0.3, 0.2 - 0.05 * j, 1.5 + 0.4 * j])
+    return z
+
+
 def _func2d(x, y, a=10.):
     return (x ** 2 + y ** 2 / 3) / a + 0.05 * np.cos(x)
 
