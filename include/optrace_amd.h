@@ -451,9 +451,10 @@ typedef struct ot_detector_image_req {
 int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_image_req* reqs,
                        int32_t n_reqs, void* stream);
 
-/* The binning paths take their scratch (up to ~25 B per ray and image) from the device's stream-ordered memory pool,
- * which keeps at most 16 GB of it between calls.  ot_scratch_trim waits for the device and returns all of it to
- * the driver (for a caller whose own allocator needs the room). */
+/* The binning paths keep their scratch (up to ~25 B per ray and image) between calls: one block per calling thread,
+ * device, stream and purpose, grown on demand (calls on one stream run in order, so a block serves call after call).
+ * ot_scratch_trim waits for the device and returns all of it to the driver (for a caller whose own allocator needs
+ * the room). */
 int ot_scratch_trim(void);
 
 /* SphericalSurface.sphere_projection (spherical_surface.py:36-97): p (n,3) F-order -> out (n,3) F-order */

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "ot_detector.hpp"
@@ -1357,31 +1358,64 @@ extern "C" int ot_sphere_projection(const ot_surface* surf, int32_t projection, 
     return OT_OK;
 }
 
-// Stream-ordered scratch (hipMallocAsync) goes back to the driver at every synchronisation unless the pool is told to
-// keep it; the tile paths ask for gigabytes per image and would pay for fresh pages every time.  The pool therefore
-// keeps up to OT_SCRATCH_KEEP bytes (about 5 % of the HBM of an MI355X) between calls -- torch's allocator, which
-// owns the ray storage, cannot see this memory -- and ot_scratch_trim() hands everything back on request.
-#define OT_SCRATCH_KEEP (16ull << 30)
-static hipError_t keep_async_pool(int dev) {
-    static thread_local bool done[64] = {false};
-    if (dev < 0 || dev >= 64 || done[dev]) return hipSuccess;
-    hipMemPool_t pool;
-    hipError_t e = hipDeviceGetDefaultMemPool(&pool, dev);
-    if (e != hipSuccess) return e;
-    unsigned long long keep = OT_SCRATCH_KEEP;
-    e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    done[dev] = (e == hipSuccess);
-    return e;
+// Scratch of the binning paths (hit records, slabs: up to ~25 B per ray and image).  One block per (thread, device,
+// stream, purpose), kept between calls and grown on demand: launches of a stream run in order, so the block of a purpose can
+// serve call after call without a free in between.  It used to come from the stream-ordered pool (hipMallocAsync /
+// hipFreeAsync per call, the pool told to keep 16 GB): that cost ~0.2 ms per call from the second call on and stalled for
+// 7-58 ms while the driver was digesting a large free (profiles/r3/readback_after_free.txt).  torch's allocator, which
+// owns the ray storage, cannot see this memory: ot_scratch_trim() hands all of it back on request.
+#include <mutex>
+enum { OT_WS_RENDER = 0, OT_WS_FUSED = 1, OT_WS_FUSED_HITS = 2 };
+struct WorkBlock {
+    std::thread::id tid;
+    int dev, purpose;
+    hipStream_t st;
+    char* p;
+    size_t bytes;
+};
+static std::mutex g_ws_mutex;
+static std::vector<WorkBlock> g_ws;
+
+// -> block of at least `bytes`, or nullptr (out of memory: the callers fall back to paths without scratch)
+static char* workspace(int purpose, size_t bytes, hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    WorkBlock* b = nullptr;
+    for (auto& w : g_ws)
+        if (w.tid == std::this_thread::get_id() && w.dev == dev && w.purpose == purpose && w.st == st) b = &w;
+    if (b && b->bytes >= bytes) return b->p;
+    if (b) {  // grow: hipFree waits for the work that may still use the old block
+        (void)hipFree(b->p);
+        b->p = nullptr;
+        b->bytes = 0;
+    } else {
+        g_ws.push_back({std::this_thread::get_id(), dev, purpose, st, nullptr, 0});
+        b = &g_ws.back();
+    }
+    const size_t want = bytes + bytes / 8;  // a little room: chunks of slightly different size do not reallocate
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, want) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        if (hipMalloc((void**)&p, bytes) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        b->bytes = bytes;
+    } else {
+        b->bytes = want;
+    }
+    b->p = p;
+    return p;
 }
 
 extern "C" int ot_scratch_trim(void) {
     if (int rc = require_device()) return rc;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    hipMemPool_t pool;
-    HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
-    HIP_TRY(hipDeviceSynchronize());  // frees are stream-ordered: let them happen
-    HIP_TRY(hipMemPoolTrimTo(pool, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (auto& w : g_ws)
+        if (w.p) (void)hipFree(w.p);
+    g_ws.clear();
     return OT_OK;
 }
 
@@ -1465,11 +1499,9 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
     const size_t o_cstart = carve(sizeof(int) * (t.K + 1));
     const size_t o_rec = carve(sizeof(TileRec) * (size_t)n);
     const size_t o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)t.max_chunks);
-    char* ws = nullptr;
-    HIP_TRY(keep_async_pool(dev));
-    if (hipMallocAsync((void**)&ws, off, st) != hipSuccess || !ws) {
+    char* ws = workspace(OT_WS_RENDER, off, st);
+    if (!ws) {
         // no room for the hit records (12 B per hit): the direct kernel needs no scratch
-        (void)hipGetLastError();
         hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr, fill);
         HIP_TRY(hipGetLastError());
         return OT_OK;
@@ -1502,9 +1534,7 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(OT_TILE_PIECES), dim3(1024), 0, st, t, px, py, w, wl, wk);
     hipLaunchKernelGGL(tile_accum_kernel, dim3((unsigned)t.max_chunks), dim3(1024), lds_accum, st, t, table, wk);
     hipLaunchKernelGGL(tile_reduce_kernel, dim3(OT_TILE_PX / 256, (unsigned)t.K), dim3(256), 0, st, t, wk, hist);
-    hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, st);
-    HIP_TRY(e);
+    HIP_TRY(hipGetLastError());
     return OT_OK;
 }
 
@@ -1539,9 +1569,9 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         const bool plain = q.projection == OT_PROJ_NONE || q.projection == OT_PROJ_ORTHOGRAPHIC;
         if (closed && plain) continue;
         // this request alone through ot_detector_hits + ot_render_accumulate, the others through the fused kernels
-        char* tmp = nullptr;
         const size_t o_hw = align_up(sizeof(double) * 2 * (size_t)count);
-        HIP_TRY(hipMallocAsync((void**)&tmp, o_hw + sizeof(float) * (size_t)count, st));
+        char* tmp = workspace(OT_WS_FUSED_HITS, o_hw + sizeof(float) * (size_t)count, st);
+        if (!tmp) return fail(OT_ERR_HIP, "ot_detector_images: no memory for the hit list");
         ot_detector_req dq;
         dq.detector = q.detector;
         dq.projection = q.projection;
@@ -1555,7 +1585,6 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         dq.ill_count = q.ill_count;
         int rc = ot_detector_hits_multi(rays, first, count, &dq, 1, stream);
         if (!rc) rc = ot_render_accumulate(count, dq.ph, dq.ph + count, dq.hw, rays->wl + first, q.extent, q.Nx, q.Ny, q.hist, stream);
-        (void)hipFreeAsync(tmp, st);
         if (rc) return rc;
         std::vector<ot_detector_image_req> rest;
         for (int j = 0; j < n_reqs; j++)
@@ -1646,16 +1675,15 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     // one slab per accumulation workgroup: a tile with n chunks takes ceil(n / OT_FUSE_CPW) of them
     const unsigned n_slabs = (unsigned)((capmax + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)Kmax;
     const size_t o_slabs = carve(KT ? sizeof(double) * OT_TILE_PX * 4 * (size_t)n_slabs : 0);
-    char* ws = nullptr;
-    if (KT) HIP_TRY(keep_async_pool(dev));
-    if (hipMallocAsync((void**)&ws, off, st) != hipSuccess || !ws) {
+    char* ws = workspace(OT_WS_FUSED, off, st);
+    if (!ws) {
         if (!KT) return fail(OT_ERR_HIP, "ot_detector_images: no scratch memory");
         // no room for the records: bin directly (needs the flags and the detector table only)
-        (void)hipGetLastError();
         KT = 0;
         for (auto& f : host) f.tiles_ok = 0;
         off = o_flags + sizeof(int) * 4 * n_reqs + 256;
-        HIP_TRY(hipMallocAsync((void**)&ws, off, st));
+        ws = workspace(OT_WS_FUSED, off, st);
+        if (!ws) return fail(OT_ERR_HIP, "ot_detector_images: no scratch memory");
     }
     int* flags = (int*)(ws + o_flags);
     for (int k = 0; k < n_reqs; k++) {
@@ -1739,7 +1767,6 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
             err = hipGetLastError();
         }
     }
-    (void)hipFreeAsync(ws, st);
     HIP_TRY(err);
     return OT_OK;
 }
