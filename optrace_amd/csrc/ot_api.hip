@@ -333,10 +333,11 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
                 return fail(OT_ERR_INVALID, "element: unknown kind");
         }
     }
-    bool needs_full = false;  // anything beyond lens surfaces and plain apertures
+    bool needs_hurb = false, needs_ideal_filter = false;  // anything beyond lens surfaces and plain apertures
     int hit_level = OT_HIT_CLOSED;
     for (const StepDev& d : steps) {
-        needs_full |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER || d.hurb;
+        needs_ideal_filter |= d.kind == OT_STEP_IDEAL || d.kind == OT_STEP_FILTER;
+        needs_hurb |= d.hurb != 0;
         const SurfDev& sf = surfs[d.surf];
         int lv = OT_HIT_CLOSED;
         if (sf.kind == OT_SURF_DATA1D || sf.kind == OT_SURF_DATA2D) {
@@ -478,7 +479,8 @@ extern "C" int ot_scene_create(const ot_scene_desc* desc, ot_scene** out) {
     sc->h = h;
     sc->needs_tables = needs_tables;
     sc->cnt_slots = (unsigned int*)(blob + o_cnt);
-    sc->needs_full = needs_full;
+    // the "full" bit of the kernel variants: HURB; at hit level 0 ideal lenses and filters as well (trace_ray)
+    sc->needs_full = needs_hurb || (needs_ideal_filter && hit_level == OT_HIT_CLOSED);
     sc->hit_level = hit_level;
     sc->d = (SceneDev*)(blob + o_hdr);
     sc->blob = blob;
@@ -1058,8 +1060,7 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
     if (!msgs) HIP_TRY(hipHostGetDevicePointer((void**)&m, sc->pin_msgs, 0));
     // kernel variant: polarisation x on-device generation x spectrum handling x feature set
     const bool tab = sc->needs_tables || hurb_normals != nullptr;
-    // spline scenes always take the full variant: at ~250 VGPRs the ideal-lens / filter / HURB code costs them nothing
-    const int feat = OT_FEAT(sc->hit_level, sc->needs_full || sc->hit_level == OT_HIT_SPLINE);
+    const int feat = OT_FEAT(sc->hit_level, sc->needs_full);
     // discrete-spectrum kernels: generated rays only, and no image source (their variant of the generator has none)
     bool lines = src != nullptr && sc->h.n_lines > 0 && hurb_normals == nullptr && !src->has_image;
     // dynamic LDS: the counter table, and with discrete spectra the per-line tables (3 rows per step).  Very long
@@ -1101,6 +1102,7 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
             case OT_FEAT(OT_HIT_CLOSED, 1): launch_trace_feat<OT_FEAT(OT_HIT_CLOSED, 1)>(L); break;
             case OT_FEAT(OT_HIT_ILLINOIS, 0): launch_trace_feat<OT_FEAT(OT_HIT_ILLINOIS, 0)>(L); break;
             case OT_FEAT(OT_HIT_ILLINOIS, 1): launch_trace_feat<OT_FEAT(OT_HIT_ILLINOIS, 1)>(L); break;
+            case OT_FEAT(OT_HIT_SPLINE, 0): launch_trace_feat<OT_FEAT(OT_HIT_SPLINE, 0)>(L); break;
             default: launch_trace_feat<OT_FEAT(OT_HIT_SPLINE, 1)>(L); break;
         }
     }

@@ -99,7 +99,7 @@ struct ot_scene {
     void* blob;        // one device allocation holding all tables
     int device;
     unsigned int* cnt_slots;  // OT_CNT_SLOTS x (5*nt+1) counter slot tables (zero between launches)
-    bool needs_full;   // ideal lenses, filters or HURB present: feature level 1 of the kernel variants
+    bool needs_full;   // the "full" bit of the kernel variants: HURB present; at hit level 0 also ideal lenses / filters
     int hit_level;     // OT_HIT_CLOSED / _ILLINOIS (aspheres, tilted) / _SPLINE (data surfaces, mask bitmaps), ot_device.hpp
     bool needs_tables; // some medium / filter is tabulated (DATA / LINES): per-lane global loads in the loop
     // synchronous entry points (ot_generate_and_trace_host): the counter reduction writes straight into this pinned,

@@ -356,8 +356,13 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
                       const double* __restrict__ hurb_normals, uint64_t seed, unsigned int* msgs, const double* ltab,
                       int lj, double* patch_lds) {
     constexpr bool TAB = (SPEC == 1);
-    constexpr bool FULL = (FEAT & 1) != 0;  // ideal lenses, filters, HURB
+    constexpr bool FULL = (FEAT & 1) != 0;  // HURB -- and, at hit level 0, ideal lenses and filters
     constexpr int LEVEL = FEAT / 2;         // hit level (ot_device.hpp): closed form / + Illinois search / + spline surfaces
+    // Ideal lenses and filters cost 2-4 registers: the levels with a numeric hit search carry them always (their scenes
+    // then need the 40-register HURB code only if they use HURB: the asphere test scene runs at 103 instead of 128
+    // registers, the spline scene at three waves instead of two); level 0 keeps them behind the bit, so that the bench
+    // kernel stays at 74.
+    constexpr bool IDEAL_FILTER = FULL || LEVEL >= OT_HIT_ILLINOIS;
     constexpr bool NUMERIC = LEVEL >= OT_HIT_ILLINOIS;
     constexpr bool SPLINE = LEVEL >= OT_HIT_SPLINE;
     // lj = line index of this ray (SPEC == 2), straight from the generator
@@ -417,12 +422,12 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
                 Nq = ot_div(r.n_cur, n_next);
             }
             if (hwh) {
-                if (FULL && kind == OT_STEP_IDEAL)
+                if (IDEAL_FILTER && kind == OT_STEP_IDEAL)
                     refract_ideal<POL>(sf, st, r, pn, npx, npy, npz);
                 else
                     tir = refract<POL, LEVEL>(sf, r, pn, wn, npx, npy, npz, r.n_cur, n_next, Nq, pc);
             }
-        } else if (FULL && kind == OT_STEP_FILTER) {  // raytracer.py:379-380
+        } else if (IDEAL_FILTER && kind == OT_STEP_FILTER) {  // raytracer.py:379-380
             if (hwh) {
                 double T = (SPEC == 2) ? lrow[(3 * i + 2) * OT_MAX_LINES] : filter_T<TAB>(filters[st.filter], pool, r.wl);
                 wn = (float)((double)r.w * T);

@@ -34,9 +34,15 @@
 #ifndef OT_TRACE_MIN_WAVES_F3
 #define OT_TRACE_MIN_WAVES_F3 4
 #endif
+// spline level without HURB: 165-169 registers, asked to stay inside the 168 of three waves (the patch buffer in LDS,
+// 51 KB per workgroup, allows three workgroups per CU as well)
+#ifndef OT_TRACE_MIN_WAVES_F4
+#define OT_TRACE_MIN_WAVES_F4 3
+#endif
 #define OT_TRACE_WAVES(FEAT, SPEC, POL)                                                                    \
     ((FEAT) == 0 ? ((SPEC) == 2 ? OT_TRACE_MIN_WAVES_F0_LINES : OT_TRACE_MIN_WAVES_F0)                     \
-                 : ((FEAT) == 1 ? OT_TRACE_MIN_WAVES_F1 : ((FEAT) == 3 ? OT_TRACE_MIN_WAVES_F3 : OT_TRACE_MIN_WAVES)))
+                 : ((FEAT) == 1 ? OT_TRACE_MIN_WAVES_F1                                                    \
+                                : ((FEAT) == 3 ? OT_TRACE_MIN_WAVES_F3 : ((FEAT) == 4 ? OT_TRACE_MIN_WAVES_F4 : OT_TRACE_MIN_WAVES))))
 
 struct RangeRec {  // one source range in device memory (scenes with more than OT_MAX_RANGES ranges)
     int64_t first, count;
@@ -236,7 +242,8 @@ __global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT, SPEC, POL)) void trace_ke
         if (cnt[k]) atomicAdd(&slot[k], cnt[k]);
 }
 
-// Feature levels of the kernel variants.  Bit 0: ideal lenses, filters, HURB ("full").  Upper part = hit level:
+// Feature levels of the kernel variants.  Bit 0 ("full"): HURB, and at hit level 0 ideal lenses and filters as well (the
+// higher hit levels always carry those two, see trace_ray).  Upper part = hit level:
 //   OT_HIT_CLOSED   flat and conic surfaces (closed-form hit)
 //   OT_HIT_ILLINOIS + aspheres and tilted surfaces: the numeric hit search on closed-form sag functions
 //   OT_HIT_SPLINE   + data / function surfaces: spline tables, per-lane coefficient patch in LDS, mask bitmaps

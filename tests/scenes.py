@@ -174,7 +174,7 @@ def _cosine_surface(x, y):
     return 0.1 * np.cos(2 * np.pi * x / 2)
 
 
-def freeform_scene(ot, **rt_args):
+def freeform_scene(ot, ideal_lens=True, **rt_args):
     """Function, data and tilted surfaces in one beam path: the cosine-modulated lens of
     examples/cosine_surfaces.py:20-32 (FunctionSurface2D, back side flipped and rotated by 90 deg), a lens
     from a 1-D data profile against a 2-D data grid, a tilted window and an ideal lens."""
@@ -198,7 +198,8 @@ def freeform_scene(ot, **rt_args):
     t1 = ot.TiltedSurface(r=7, normal_sph=[8., 35.])
     t2 = ot.TiltedSurface(r=7, normal_sph=[5., 200.])
     RT.add(ot.Lens(t1, t2, de=0.3, pos=[0, 0, 30], n=ot.RefractionIndex("Cauchy", coeff=[1.49, 0.00354, 0, 0])))
-    RT.add(ot.IdealLens(r=9, D=50, pos=[0, 0, 40]))
+    if ideal_lens:
+        RT.add(ot.IdealLens(r=9, D=50, pos=[0, 0, 40]))
     RT.add(ot.Detector(ot.RectangularSurface(dim=[14, 14]), pos=[0, 0, 24.4]))
     RT.add(ot.Detector(ot.RectangularSurface(dim=[14, 14]), pos=[0, 0, 60]))
     return RT

@@ -49,6 +49,7 @@ CONFIGS = {
     "A1n double gauss aspheric no_pol": (lambda o: scenes.double_gauss(o, seed=1, aspheric=True, no_pol=True), 10_000_000),
     "A2 asphere test scene": (lambda o: scenes.asphere_scene(o, seed=3), 10_000_000),
     "freeform (spline surfaces)": (lambda o: scenes.freeform_scene(o, seed=5), 10_000_000),
+    "F2 freeform without the ideal lens": (lambda o: scenes.freeform_scene(o, seed=5, ideal_lens=False), 10_000_000),
 }
 
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # optional name prefixes, e.g. `bench_configs.py C4`
