@@ -104,3 +104,37 @@ def test_two_rank_gloo_image_equals_single_process_reference(tmp_path):
     img[idx[:, 0], idx[:, 1]] = got["vals"]
     assert abs(got["power"] - float(g["det0/None/img/power"])) < 1e-9 * float(g["det0/None/img/power"])
     assert np.all(image_rel_l1(img, ref) < 1e-4)
+
+
+# ---- the exchanges of sharded_iterative_render (K images at once), two gloo ranks on CPU -------------------------------
+def _worker_k(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # K = 3 positions; rank 1 has no hit at position 2, nobody has one at position 3
+    inf = np.inf
+    raw = [np.array([[-1.0, 2.0, -3.0, 0.5], [0.1, 0.2, 0.3, 0.4], [inf, -inf, inf, -inf]]),
+           np.array([[-1.5, 1.0, -2.0, 4.0], [inf, -inf, inf, -inf], [inf, -inf, inf, -inf]])][rank]
+    ext = D.allreduce_extents(raw)
+    stack = torch.full((3, 4, 5, 4), float(rank + 1), dtype=torch.float64)
+    D.allreduce_image(stack)
+    cnt = D.allreduce_counters(np.arange(10).reshape(5, 2) * (rank + 1))
+    if rank == 0:
+        np.savez(out, ext=ext, stack=stack.numpy(), cnt=cnt)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_k_image_extent_agreement_and_stacked_histogram_exchange(tmp_path):
+    out = str(tmp_path / "k.npz")
+    mp.spawn(_worker_k, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    np.testing.assert_array_equal(got["ext"][0], [-1.5, 2.0, -3.0, 4.0])   # min / max over the ranks, per image
+    np.testing.assert_array_equal(got["ext"][1], [0.1, 0.2, 0.3, 0.4])     # one rank without a hit: the other's extent
+    assert not np.any(np.isfinite(got["ext"][2]))                          # no hit anywhere: the caller collapses it
+    assert np.all(got["stack"] == 3.0)
+    np.testing.assert_array_equal(got["cnt"], np.arange(10).reshape(5, 2) * 3)
+    # without a process group the helpers are the identity
+    raw = np.array([[0.0, 1.0, 2.0, 3.0]])
+    np.testing.assert_array_equal(D.allreduce_extents(raw), raw)
