@@ -108,8 +108,23 @@ struct GenCtx {
     uint32_t n2;     // floor(sqrt(n)): side of the jittered grid of the 2-D samplers
     double inv_n, inv_n2;  // 1 / n, 1 / n2 (host)
     float w;         // power of each ray of the range (host)
-    double u[12];    // dither values in [0,1), 32 random bits each: one to three Philox-4x32-10 blocks per ray
+    // dither values in [0, 1): the raw words of one or two Philox blocks, turned into doubles where they are used
+    // (`dither`): twelve ready-made doubles occupied 24 vector registers from the top of the generator to the last use
+    uint32_t ra[4], rb[4];
+    bool image, has_b;  // wave-uniform: eight 16-bit dithers out of block A (image sources); block B was drawn
 };
+
+// dither value of slot k (see dither_slot): 32 bits of block A (slots 0-3) or B (4-7); image sources cut block A into
+// eight 16-bit values for the slots 0-3 and 8-11.  Slots nobody filled read 0.5.
+OT_DEV double dither(const GenCtx& g, int k) {
+    if (k >= 4 && k < 8) return g.has_b ? ((double)g.rb[k - 4] + 0.5) * 0x1.0p-32 : 0.5;
+    if (g.image) {
+        const int j = (k < 4) ? k : k - 4;  // 0 .. 7: word j / 2, low or high half
+        const uint32_t wv = g.ra[j >> 1];
+        return ((double)((j & 1) ? (wv >> 16) : (wv & 0xffffu)) + 0.5) * 0x1.0p-16;
+    }
+    return (k < 4) ? ((double)g.ra[k] + 0.5) * 0x1.0p-32 : 0.5;
+}
 
 // stream -> which dither value(s) it uses (consecutive pairs for the 2-D samplers).  The slots are grouped so
 // that a source only pays for the Philox blocks it needs: block A (u0-u3) serves every source -- point sources
@@ -131,33 +146,21 @@ OT_DEV int dither_slot(uint32_t stream) {
 
 OT_DEV void fill_dither(GenCtx& g, bool need_b, bool image) {
     const uint32_t i0 = (uint32_t)g.gidx, i1 = (uint32_t)(g.gidx >> 32), k0 = (uint32_t)g.seed, k1 = (uint32_t)(g.seed >> 32);
-    Philox a = philox4x32<7>(i0, i1, 0x67656e31u, 0, k0, k1);
+    // image sources draw eight dithers (direction x 2, wavelength, polarisation, pixel, in-pixel x 2, primary): the one
+    // block serves them all with 16 bits each -- a dither only places the ray inside its stratum, whose width is
+    // 1 / (rays of the range) of the sampled interval already
+    const Philox a = philox4x32<7>(i0, i1, 0x67656e31u, 0, k0, k1);
+    g.image = image;
+    g.has_b = need_b;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        g.u[k] = ((double)a.c[k] + 0.5) * 0x1.0p-32;
-        g.u[4 + k] = 0.5;
-        g.u[8 + k] = 0.5;
-    }
-    if (image) {
-        // image sources draw eight dithers (direction x 2, wavelength, polarisation, pixel, in-pixel x 2, primary):
-        // the one block serves them all with 16 bits each -- a dither only places the ray inside its stratum, whose
-        // width is 1 / (rays of the range) of the sampled interval already
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double lo = ((double)(a.c[k] & 0xffffu) + 0.5) * 0x1.0p-16, hi = ((double)(a.c[k] >> 16) + 0.5) * 0x1.0p-16;
-            if (k < 2) {
-                g.u[2 * k] = lo;      // u0, u2
-                g.u[2 * k + 1] = hi;  // u1, u3
-            } else {
-                g.u[8 + 2 * (k - 2)] = lo;      // u8, u10
-                g.u[8 + 2 * (k - 2) + 1] = hi;  // u9, u11
-            }
-        }
+        g.ra[k] = a.c[k];
+        g.rb[k] = 0u;
     }
     if (need_b) {
-        Philox b = philox4x32<7>(i0, i1, 0x67656e32u, 1, k0, k1);
+        const Philox b = philox4x32<7>(i0, i1, 0x67656e32u, 1, k0, k1);
 #pragma unroll
-        for (int k = 0; k < 4; k++) g.u[4 + k] = ((double)b.c[k] + 0.5) * 0x1.0p-32;
+        for (int k = 0; k < 4; k++) g.rb[k] = b.c[k];
     }
 }
 
@@ -172,7 +175,7 @@ OT_DEV void fill_dither_for(GenCtx& g, SRC& src) {
 // random.stratified_interval_sampling random.py:48-67: one of n strata of [a, b), uniformly dithered
 OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double b) {
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
-    double u0 = g.u[dither_slot(stream)];
+    double u0 = dither(g, dither_slot(stream));
     double dba = (b - a) * g.inv_n;
     return a + ((double)k + u0) * dba;
 }
@@ -182,7 +185,7 @@ OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double 
 OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, double c, double d, double& x, double& y) {
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
     const int slot = dither_slot(stream);
-    double u0 = g.u[slot], u1 = g.u[slot + 1];
+    double u0 = dither(g, slot), u1 = dither(g, slot + 1);
     const uint32_t N2 = g.n2;
     if (k < N2 * N2) {
         // k / N2 through the host's 1 / N2 with an exact fix-up instead of an integer division
@@ -383,8 +386,8 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         // and shuffled independently of the pixel choice (ray_source.py:247), so the rays that share a pixel carry a
         // random subset of that grid -- indistinguishable from independent uniform values.  The dithers serve directly;
         // a permutation and the grid arithmetic (~45 vector instructions per ray) bought nothing.
-        rx = g.u[dither_slot(ST_PIX_JITTER)];
-        ry = g.u[dither_slot(ST_PIX_JITTER) + 1];
+        rx = dither(g, dither_slot(ST_PIX_JITTER));
+        ry = dither(g, dither_slot(ST_PIX_JITTER) + 1);
         if (src.shape == OT_SRC_IMAGE_RGB) choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
     }
     // ---- image sources, round trip 2: the records of the first two pixels of the range ----
