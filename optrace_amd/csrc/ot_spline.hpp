@@ -227,10 +227,17 @@ OT_HD double spl2_eval(TP tx, int nx, TP ty, int ny, TP c, double inv_h, double 
                 for (int j1 = 0; j1 <= KY; j1++) pc->slot[(i1 * (KY + 1) + j1) * pc->stride] = c[l1 + i1 * nky1 + j1];
             pc->key = first;
         }
+        // Row sums with fused multiply-adds: sum_i hx_i (sum_j c_ij hy_j), 30 instructions instead of the 75 of fpbisp's
+        // term-by-term order (sp += c hx hy).  The value moves by ~1e-16 relative -- three orders below what the
+        // equidistant-knot arithmetic of this path already differs from the table path by (1e-13) -- and this branch
+        // serves the hit search of the trace kernel only; the leaf operators (pc == nullptr) keep FITPACK's order.
 #pragma unroll
-        for (int i1 = 0; i1 <= KX; i1++)
+        for (int i1 = 0; i1 <= KX; i1++) {
+            double row = 0.0;
 #pragma unroll
-            for (int j1 = 0; j1 <= KY; j1++) sp = sp + pc->slot[(i1 * (KY + 1) + j1) * pc->stride] * hx[i1] * hy[j1];
+            for (int j1 = 0; j1 <= KY; j1++) row = __builtin_fma(pc->slot[(i1 * (KY + 1) + j1) * pc->stride], hy[j1], row);
+            sp = __builtin_fma(row, hx[i1], sp);
+        }
         return sp;
     }
 #pragma unroll
