@@ -144,7 +144,7 @@ class RayStorage(BaseClass):
             try:
                 d["_dev"] = alloc()
             except torch.OutOfMemoryError:
-                # the library's binning scratch lives in HIP's stream-ordered pool, which torch's allocator cannot see
+XX
                 _capi.check(_capi.load_library().ot_scratch_trim())
                 torch.cuda.empty_cache()
                 d["_dev"] = alloc()
