@@ -144,7 +144,7 @@ class RayStorage(BaseClass):
             try:
                 d["_dev"] = alloc()
             except torch.OutOfMemoryError:
-XX
+                # the library keeps its binning scratch between calls (ot_api.hip::workspace): torch's allocator cannot see it
                 _capi.check(_capi.load_library().ot_scratch_trim())
                 torch.cuda.empty_cache()
                 d["_dev"] = alloc()
