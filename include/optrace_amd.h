@@ -416,7 +416,7 @@ typedef struct ot_detector_req {
     float* hw;            /* device (count)      extent-only request, nothing but extent4 and ill_count is written   */
     double* extent4;      /* device f64[4] or NULL, initialised by the caller       */
     int64_t* ill_count;   /* device int64[2], added to                              */
-    /* Compact hit list (fill != NULL; needs xy_only): only the VALID hits are written, into a list of OT_HIT_PIECES
+    /* Compact hit list (fill != NULL; needs xy_only; ph may be NULL = no positions): only the VALID hits are written, into a list of OT_HIT_PIECES
      * pieces of L = ot_hit_piece_len(count) entries each -- CAPACITY = OT_HIT_PIECES * L entries, which the caller
      * allocates: ph = x plane [CAPACITY] then y plane [CAPACITY], hw [CAPACITY], wl_out [CAPACITY] (the hit's
      * wavelength: the list no longer lines up with the rays).  Piece k holds fill[k] hits at its front, [k * L,
@@ -518,6 +518,12 @@ int ot_image_convolve(const double* in, int32_t Nx, int32_t Ny, const double* ps
 int ot_spectrum_range(int64_t n, const float* wl, const float* w, double* range2, int64_t* count, void* stream);
 int ot_spectrum_histogram(int64_t n, const float* wl, const float* w, const float* edges, int32_t nbins, double* hist,
                           void* stream);
+/* The same over a compact hit list of a bundle of n rays (ot_detector_req.fill; positions are not needed: such a request may
+ * leave ph NULL): piece k contributes its first fill[k] entries of wl and w. */
+int ot_spectrum_range_compact(int64_t n, const uint32_t* fill, const float* wl, const float* w, double* range2,
+                              int64_t* count, void* stream);
+int ot_spectrum_histogram_compact(int64_t n, const uint32_t* fill, const float* wl, const float* w, const float* edges,
+                                  int32_t nbins, double* hist, void* stream);
 
 /* Raytracer.focus_search (raytracer.py:1463-1640).  next row, SURVEY 8f rank 3.
  * ot_focus_prepare: for rays [first, first + count) pick the section crossing z (pos = argmax(z < p_z) - 1,

@@ -155,6 +155,8 @@ SIGNATURES = {
     "ot_hit_piece_len": (i64, [i64]),
     "ot_spectrum_range": (C.c_int, [i64, vp, vp, vp, vp, vp]),
     "ot_spectrum_histogram": (C.c_int, [i64, vp, vp, vp, i32, vp, vp]),
+    "ot_spectrum_range_compact": (C.c_int, [i64, vp, vp, vp, vp, vp, vp]),
+    "ot_spectrum_histogram_compact": (C.c_int, [i64, vp, vp, vp, vp, i32, vp, vp]),
     "ot_focus_prepare": (C.c_int, [C.POINTER(Rays), i64, i64, C.c_double, vp, vp, vp, vp]),
     "ot_focus_cost": (C.c_int, [i64, vp, vp, i32, C.POINTER(C.c_double), i32, i32, vp, vp, vp]),
     "ot_focus_moments": (C.c_int, [i64, vp, vp, C.c_double, C.c_double, vp, vp]),

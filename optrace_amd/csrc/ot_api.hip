@@ -1241,10 +1241,11 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
         const ot_detector_req& q = reqs[k];
         if (!q.detector || !q.ill_count) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
         // ph and hw both NULL: extent-only request (no hit list is written)
-        if ((!q.ph || !q.hw) && (q.ph || q.hw || !q.extent4))
+        // compact lists may go without positions (weights and wavelengths: the detector spectrum)
+        if (q.fill && (!q.hw || !q.wl_out || !q.xy_only || !rays->wl))
+            return fail(OT_ERR_INVALID, "ot_detector_hits: a compact hit list needs hw, wl_out and xy_only");
+        if (!q.fill && (!q.ph || !q.hw) && (q.ph || q.hw || !q.extent4))
             return fail(OT_ERR_INVALID, "ot_detector_hits: ph and hw may only be NULL together, and only with extent4");
-        if (q.fill && (!q.ph || !q.hw || !q.wl_out || !q.xy_only || !rays->wl))
-            return fail(OT_ERR_INVALID, "ot_detector_hits: a compact hit list needs ph, hw, wl_out and xy_only");
         if (q.projection < OT_PROJ_NONE || q.projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
     }
     if (int rc = require_device()) return rc;
@@ -1846,7 +1847,31 @@ static int cu_count() {
     return 256;
 }
 
+static int spectrum_range(int64_t n, const unsigned int* fill, const float* wl, const float* w, double* range2, int64_t* count,
+                          void* stream);
+static int spectrum_histogram(int64_t n, const unsigned int* fill, const float* wl, const float* w, const float* edges,
+                              int32_t nbins, double* hist, void* stream);
+
 extern "C" int ot_spectrum_range(int64_t n, const float* wl, const float* w, double* range2, int64_t* count, void* stream) {
+    return spectrum_range(n, nullptr, wl, w, range2, count, stream);
+}
+extern "C" int ot_spectrum_histogram(int64_t n, const float* wl, const float* w, const float* edges, int32_t nbins,
+                                     double* hist, void* stream) {
+    return spectrum_histogram(n, nullptr, wl, w, edges, nbins, hist, stream);
+}
+extern "C" int ot_spectrum_range_compact(int64_t n, const uint32_t* fill, const float* wl, const float* w, double* range2,
+                                         int64_t* count, void* stream) {
+    if (!fill) return fail(OT_ERR_INVALID, "ot_spectrum_range_compact: fill counts missing");
+    return spectrum_range(n, fill, wl, w, range2, count, stream);
+}
+extern "C" int ot_spectrum_histogram_compact(int64_t n, const uint32_t* fill, const float* wl, const float* w,
+                                             const float* edges, int32_t nbins, double* hist, void* stream) {
+    if (!fill) return fail(OT_ERR_INVALID, "ot_spectrum_histogram_compact: fill counts missing");
+    return spectrum_histogram(n, fill, wl, w, edges, nbins, hist, stream);
+}
+
+static int spectrum_range(int64_t n, const unsigned int* fill, const float* wl, const float* w, double* range2, int64_t* count,
+                          void* stream) {
     if (n < 0 || !range2 || !count || (n && (!wl || !w))) return fail(OT_ERR_INVALID, "ot_spectrum_range: bad argument");
     if (int rc = require_device()) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1858,13 +1883,13 @@ extern "C" int ot_spectrum_range(int64_t n, const float* wl, const float* w, dou
     const int64_t cap = (int64_t)cu_count() * 8;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(spectrum_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, wl, w, range2,
-                       (unsigned long long*)count);
+                       (unsigned long long*)count, fill);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }
 
-extern "C" int ot_spectrum_histogram(int64_t n, const float* wl, const float* w, const float* edges, int32_t nbins,
-                                     double* hist, void* stream) {
+static int spectrum_histogram(int64_t n, const unsigned int* fill, const float* wl, const float* w, const float* edges,
+                              int32_t nbins, double* hist, void* stream) {
     if (n < 0 || !edges || !hist || nbins < 1 || (n && (!wl || !w)))
         return fail(OT_ERR_INVALID, "ot_spectrum_histogram: bad argument");
     if (int rc = require_device()) return rc;
@@ -1877,7 +1902,7 @@ extern "C" int ot_spectrum_histogram(int64_t n, const float* wl, const float* w,
     const int64_t cap = cu_count();
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(spectrum_hist_kernel, dim3((unsigned)blocks), dim3(1024), lds_bins ? lds : 0, st, n, wl, w, edges,
-                       nbins, lds_bins, hist);
+                       nbins, lds_bins, hist, fill);
     HIP_TRY(hipGetLastError());
     return OT_OK;
 }

@@ -321,8 +321,10 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
             base = (unsigned int)__shfl((int)base, (int)__ffsll((long long)m) - 1);
             if (valid) {
                 const int64_t i = (piece << D.piece_shift) + base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-                D.ph[i] = ph.x;
-                D.ph[i + ((int64_t)OT_HIT_PIECES_N << D.piece_shift)] = ph.y;  // the y plane follows the x plane's capacity
+                if (D.ph) {  // (weights and wavelengths alone serve the detector spectrum)
+                    D.ph[i] = ph.x;
+                    D.ph[i + ((int64_t)OT_HIT_PIECES_N << D.piece_shift)] = ph.y;  // the y plane follows the x plane's capacity
+                }
                 D.hw[i] = w;
                 D.wl_out[i] = R.wl[r];
             }

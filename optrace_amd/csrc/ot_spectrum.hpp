@@ -2,27 +2,43 @@
 // The reference histograms the float32 wavelengths of the selected rays with np.histogram(wl, bins=N, weights=w,
 // range=[wl0, wl1]).  With float32 data and float32 range NumPy keeps the whole bin search in float32
 // (bin_type = result_type(first, last, a)); the kernels below follow that arithmetic so that a ray lands in the
-// same bin.  Rays are given dense (weight 0 = not selected), as ot_detector_hits leaves them.
+// same bin.  Rays are given dense (weight 0 = not selected), as ot_detector_hits leaves them, or as a compact list
+// (`fill`: 1024 pieces of hit_piece_len(n) entries, piece k holding fill[k] entries at its front, ot_detector_req.fill).
 #pragma once
 #include "ot_detector.hpp"
 #include "ot_device.hpp"
 
 // pass 1: wavelength range and number of selected rays.  stats = {min wl, max wl} (pre-set to +inf / -inf),
 // count[0] += rays with w > 0 (np.count_nonzero(w) over the selected rays, light_spectrum.py:60,70)
+// index walk shared by both passes: dense = grid-stride over [0, n); compact = the workgroup takes whole pieces
+template <class F>
+OT_DEV void spectrum_for_each(int64_t n, const unsigned int* __restrict__ fill, F&& body) {
+    if (!fill) {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) body(i);
+        return;
+    }
+    const int shift = hit_piece_shift(n);
+    for (int64_t pc = blockIdx.x; pc < OT_HIT_PIECES_N; pc += gridDim.x) {
+        const int64_t i0 = pc << shift, i1 = i0 + (int64_t)fill[pc];
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) body(i);
+    }
+}
+
 __global__ __launch_bounds__(256) void spectrum_stats_kernel(int64_t n, const float* __restrict__ wl, const float* __restrict__ w,
-                                                             double* __restrict__ stats, unsigned long long* __restrict__ count) {
+                                                             double* __restrict__ stats, unsigned long long* __restrict__ count,
+                                                             const unsigned int* __restrict__ fill) {
     const double inf = __builtin_inf();
     double lo = inf, hi = -inf;
     unsigned long long c = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    spectrum_for_each(n, fill, [&](int64_t i) {
         if (w[i] > 0.f) {
             double l = (double)wl[i];
             lo = fmin(lo, l);
             hi = fmax(hi, l);
             c++;
         }
-    }
+    });
     lo = wave_min(lo);
     hi = wave_max(hi);
 #pragma unroll
@@ -40,7 +56,7 @@ __global__ __launch_bounds__(256) void spectrum_stats_kernel(int64_t n, const fl
 // LDS-privatised when the bins fit (lds_bins > 0), otherwise global atomics.
 __global__ __launch_bounds__(1024) void spectrum_hist_kernel(int64_t n, const float* __restrict__ wl, const float* __restrict__ w,
                                                              const float* __restrict__ edges, int nbins, int lds_bins,
-                                                             double* __restrict__ hist) {
+                                                             double* __restrict__ hist, const unsigned int* __restrict__ fill) {
     extern __shared__ double sh[];  // [lds_bins] sums, then [lds_bins + 1] edges as float
     float* sedge = (float*)(sh + lds_bins);
     if (lds_bins) {
@@ -52,12 +68,11 @@ __global__ __launch_bounds__(1024) void spectrum_hist_kernel(int64_t n, const fl
     const float first = edges[0], last = edges[nbins];
     const float denom = last - first;
     const float fn = (float)nbins;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    spectrum_for_each(n, fill, [&](int64_t i) {
         float wi = w[i];
-        if (!(wi > 0.f)) continue;
+        if (!(wi > 0.f)) return;
         float x = wl[i];
-        if (!(x >= first && x <= last)) continue;
+        if (!(x >= first && x <= last)) return;
         int idx = (int)(((x - first) / denom) * fn);
         if (idx == nbins) idx -= 1;
         if (x < e[idx]) idx -= 1;
@@ -66,7 +81,7 @@ __global__ __launch_bounds__(1024) void spectrum_hist_kernel(int64_t n, const fl
             unsafeAtomicAdd(&sh[idx], (double)wi);
         else
             unsafeAtomicAdd(&hist[idx], (double)wi);
-    }
+    });
     if (lds_bins) {
         __syncthreads();
         for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) {

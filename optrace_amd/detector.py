@@ -38,7 +38,8 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         want_z = bool(rq.get("want_z", False))
         compact = bool(rq.get("compact", False)) and not want_z
         cap = _capi.HIT_PIECES * int(lib.ot_hit_piece_len(int(count))) if compact else count  # entries per plane
-        ph = torch.empty((3 if want_z else 2) * cap, dtype=torch.float64, device=dev)
+        no_pos = compact and bool(rq.get("weights_only", False))  # (detector spectrum: weights and wavelengths alone)
+        ph = None if no_pos else torch.empty((3 if want_z else 2) * cap, dtype=torch.float64, device=dev)
         hw = torch.empty(cap, dtype=torch.float32, device=dev)
         wl_c = torch.empty(cap, dtype=torch.float32, device=dev) if compact else None
         fill = torch.zeros(_capi.HIT_PIECES, dtype=torch.int32, device=dev) if compact else None
@@ -53,7 +54,8 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         r.projection = int(rq["projection"])
         r.xy_only = 0 if want_z else 1
         r.crop4 = None if crop4 is None else C.addressof(crop4)
-        r.ph, r.hw, r.extent4 = ph.data_ptr(), hw.data_ptr(), (mb_t.data_ptr() + 8 * ext if ext is not None else None)
+        r.ph, r.hw = (None if ph is None else ph.data_ptr()), hw.data_ptr()
+        r.extent4 = mb_t.data_ptr() + 8 * ext if ext is not None else None
         r.wl_out, r.fill = (wl_c.data_ptr(), fill.data_ptr()) if compact else (None, None)
         r.ill_count = ill.data_ptr() + 16 * k
         # closed-form hits (flat / conic detectors) can neither be ill-conditioned nor time out

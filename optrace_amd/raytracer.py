@@ -459,7 +459,8 @@ class Raytracer(Group):
             groups.setdefault((rq["Ns"], rq["Ne"]), []).append(
                 (n, dict(surf_desc=rq["surf_desc"], want_extent=rq["crop"] is None,
                          projection=_capi.PROJECTIONS[rq["projection"]], crop=rq["crop"], want_z=rq["want_z"],
-                         compact=bool(specs[n].get("compact", False)))))
+                         compact=bool(specs[n].get("compact", False)),
+                         weights_only=bool(specs[n].get("weights_only", False)))))
 
         out = [None] * len(specs)
         for (Ns, Ne), part_all in groups.items():
@@ -594,7 +595,14 @@ class Raytracer(Group):
     def detector_spectrum(self, detector_index: int = 0, source_index: int = None, extent=None,
                           **kwargs) -> LightSpectrum:
         """Spectrum of the light hitting a detector (raytracer.py:1100-1132); hit search and histogram on the GPU."""
-        _, w, wl, _, _, ill_count = self._hit_detector("Detector Spectrum", detector_index, source_index, extent)
+        # long bundles: a compact list of the valid hits' weights and wavelengths (no positions: 8 B per valid hit written
+        # instead of 28 B per ray, and the two histogram passes read those alone)
+        compact = self.rays.N >= self.COMPACT_HITS_FROM
+        spec_rq = dict(detector_index=detector_index, source_index=source_index, extent=extent,
+                       projection_method="Equidistant", want_z=not compact, compact=compact, weights_only=compact)
+        _, w, wl, _, _, ill_count = self._hit_detectors("Detector Spectrum", [spec_rq])[0][:6]
+        if isinstance(wl, tuple):
+            wl, kwargs["_fill"] = wl
 
         prefix = "Spectrum at " if source_index is None else f"Spectrum of RS{source_index} at "
         spec = LightSpectrum.render(wl, w, long_desc=prefix + self._detector_label(detector_index), **kwargs)

@@ -320,11 +320,12 @@ class LightSpectrum(Spectrum):
         return float(grid[hi] - grid[lo])
 
     @staticmethod
-    def render(wl, w, **kwargs) -> "LightSpectrum":
+    def render(wl, w, _fill=None, **kwargs) -> "LightSpectrum":
         """Histogram spectrum (unit W/nm) of rays with wavelengths `wl` and powers `w`
         (light_spectrum.py:41-79).  `wl`, `w`: float32 device tensors (or host arrays, uploaded as they are);
         rays with weight 0 count as not selected, which is how `Raytracer._hit_detector` hands them over.
-        Range search and binning run on the GPU (ot_spectrum_range / ot_spectrum_histogram)."""
+        Range search and binning run on the GPU (ot_spectrum_range / ot_spectrum_histogram).  `_fill`: wl and w are a
+        compact hit list (`ot_detector_req.fill`: 1024 pieces, piece k holding `_fill[k]` entries at its front)."""
         import torch
         from ._device import require_device, ptr, stream_ptr
         lib = _capi.load_library()
@@ -338,7 +339,10 @@ class LightSpectrum(Spectrum):
 
         rng = torch.empty(2, dtype=torch.float64, device=dev)
         cnt = torch.empty(1, dtype=torch.int64, device=dev)
-        _capi.check(lib.ot_spectrum_range(n, ptr(wl), ptr(w), ptr(rng), ptr(cnt), stream_ptr()))
+        if _fill is not None:
+            _capi.check(lib.ot_spectrum_range_compact(n, ptr(_fill), ptr(wl), ptr(w), ptr(rng), ptr(cnt), stream_ptr()))
+        else:
+            _capi.check(lib.ot_spectrum_range(n, ptr(wl), ptr(w), ptr(rng), ptr(cnt), stream_ptr()))
         nz = int(cnt.item())
 
         # at least 51 bins, growing with sqrt(N) above that; odd, so there is a bin for the range centre
@@ -357,7 +361,11 @@ class LightSpectrum(Spectrum):
         edges = np.linspace(wl0, wl1, N + 1, endpoint=True, dtype=np.float32)
         d_edges = torch.from_numpy(edges).to(dev)
         hist = torch.zeros(N, dtype=torch.float64, device=dev)
-        _capi.check(lib.ot_spectrum_histogram(n, ptr(wl), ptr(w), ptr(d_edges), N, ptr(hist), stream_ptr()))
+        if _fill is not None:
+            _capi.check(lib.ot_spectrum_histogram_compact(n, ptr(_fill), ptr(wl), ptr(w), ptr(d_edges), N, ptr(hist),
+                                                          stream_ptr()))
+        else:
+            _capi.check(lib.ot_spectrum_histogram(n, ptr(wl), ptr(w), ptr(d_edges), N, ptr(hist), stream_ptr()))
         spec._wls = edges
         spec._vals = hist.cpu().numpy() * (1 / (spec._wls[1] - spec._wls[0]))  # W -> W/nm
         return spec

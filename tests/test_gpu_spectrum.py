@@ -128,3 +128,28 @@ def test_source_checks():
         RT.lenses[0].move_to([0, 0, RT.lenses[0].pos[2] + 0.5])
         with pytest.raises(RuntimeError):
             RT.source_image(0)  # geometry changed
+
+
+@pytest.mark.parametrize("N", [5000, 2_300_000])
+def test_detector_spectrum_through_a_compact_hit_list_equals_the_dense_one(N):
+    """`detector_spectrum` on long bundles takes the valid hits' weights and wavelengths from a compact list
+    (`ot_detector_req.fill` without positions, `ot_spectrum_*_compact`): same bins, same edges, sums to 1e-12 -- with an
+    automatic and a user extent, and for one source alone."""
+    with ot.global_options.no_warnings():
+        RT = scenes.double_gauss(ot, seed=11)
+        RT.trace(N)
+        old = RT.COMPACT_HITS_FROM
+        try:
+            e = RT.detector_image().extent
+            cx, cy, hx, hy = (e[0] + e[1]) / 2, (e[2] + e[3]) / 2, (e[1] - e[0]) / 2, (e[3] - e[2]) / 2
+            part = [cx - 0.6 * hx, cx + 0.3 * hx, cy - 0.2 * hy, cy + 0.7 * hy]  # an off-centre part of the lit area
+            for kw in (dict(), dict(extent=part), dict(source_index=0)):
+                type(RT).COMPACT_HITS_FROM = 1 << 60
+                dense = RT.detector_spectrum(**kw)
+                type(RT).COMPACT_HITS_FROM = 1
+                compact = RT.detector_spectrum(**kw)
+                np.testing.assert_array_equal(dense._wls, compact._wls)
+                assert dense._vals.sum() > 0
+                np.testing.assert_allclose(compact._vals, dense._vals, rtol=1e-12, atol=1e-15 * dense._vals.max())
+        finally:
+            type(RT).COMPACT_HITS_FROM = old
