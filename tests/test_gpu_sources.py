@@ -434,3 +434,48 @@ def test_image_orientation_is_consistent():
     # and the first row / column of the array is the low-y / low-x side of the source plane
     p = RT.rays.p_list[:, 0]
     assert p[:, 0].max() < -0.3 + 1e-12 and p[:, 1].max() < -0.3 + 1e-12
+
+
+def _pixel_frequencies(img, N=400_000, gray=False):
+    h, w = img.shape[:2]
+    src = ot.GrayscaleImage(img, [2.0, 1.0]) if gray else ot.RGBImage(img, [2.0, 1.0])
+    RT = ot.Raytracer(outline=[-3, 3, -3, 3, -1, 10], seed=5)
+    kw = dict(spectrum=ot.LightSpectrum("Monochromatic", wl=550.)) if gray else {}
+    RT.add(ot.RaySource(src, divergence="None", s=[0, 0, 1], pos=[0, 0, 0], **kw))
+    with ot.global_options.no_warnings():
+        RT.trace(N)
+    p = RT.rays.p_list[:, 0]
+    ix = np.clip(((p[:, 0] + 1.0) / 2.0 * w).astype(int), 0, w - 1)
+    iy = np.clip(((p[:, 1] + 0.5) / 1.0 * h).astype(int), 0, h - 1)
+    cnt = np.zeros((h, w))
+    np.add.at(cnt, (iy, ix), 1)
+    return cnt / N
+
+
+def test_pixel_pick_edge_cases():
+    """The pixel of an image source (ray_source.py:239-245: inverse transform of the pixel pdf with a stratified variable) on the
+    inputs that stress the two-round-trip pick (bucket range, then the records of two pixels): a single pixel, a dark pixel
+    next to a lit one, an image with 60 % dark pixels (many pixels share a bucket), a strongly peaked image (one pixel spans
+    thousands of buckets), a grayscale image.  Stratified sampling: frequencies equal the pdf to ~1 / N, dark pixels never."""
+    from optrace_amd.image import srgb_to_srgb_linear, power_from_srgb_linear
+    rng = np.random.default_rng(3)
+    assert _pixel_frequencies(np.full((1, 1, 3), 0.7))[0, 0] == 1.0
+    im = np.zeros((1, 2, 3))
+    im[0, 1] = [1, 0.5, 0.2]
+    np.testing.assert_array_equal(_pixel_frequencies(im), [[0.0, 1.0]])
+    im = rng.uniform(0, 1, (17, 23, 3))
+    im[rng.uniform(size=(17, 23)) < 0.6] = 0
+    pw = power_from_srgb_linear(srgb_to_srgb_linear(im))
+    pdf = pw / pw.sum()
+    c = _pixel_frequencies(im)
+    assert np.abs(c - pdf).max() < 5e-5 and c[pdf == 0].sum() == 0
+    im = np.full((64, 64, 3), 1e-3)
+    im[10, 20] = 1.0
+    pw = power_from_srgb_linear(srgb_to_srgb_linear(im))
+    pdf = pw / pw.sum()
+    assert np.abs(_pixel_frequencies(im) - pdf).max() < 5e-5
+    g = rng.uniform(0, 1, (9, 31))
+    g[g < 0.3] = 0
+    gl = srgb_to_srgb_linear(g)  # ray_source.py:142-144
+    c = _pixel_frequencies(g, gray=True)
+    assert np.abs(c - gl / gl.sum()).max() < 5e-5 and c[g == 0].sum() == 0
