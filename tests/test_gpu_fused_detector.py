@@ -212,3 +212,21 @@ def test_compact_hit_list_on_a_point_image_and_without_hits():
     same_image(dense, compact)
     assert compact_empty.power() == 0.0 and dense_empty.power() == 0.0
     np.testing.assert_array_equal(compact_empty.extent, dense_empty.extent)
+
+
+def test_kept_scratch_grows_and_can_be_handed_back():
+    """The binning paths keep their scratch per stream between calls (csrc/ot_api.hip::workspace): a larger bundle after a
+    smaller one reallocates, `ot_scratch_trim` returns everything to the driver, and the images do not depend on any of it."""
+    from optrace_amd import _capi
+    lib = _capi.load_library()
+    with pinned("tiles"), ot.global_options.no_warnings():
+        small = image_scene(N=300_000)
+        a1 = small.detector_image(extent=[-8., 8., -8., 8.])
+        big = image_scene(N=2_400_000)
+        b1, b1a = big.detector_image(extent=[-8., 8., -8., 8.]), big.detector_image()
+        _capi.check(lib.ot_scratch_trim())
+        a2 = small.detector_image(extent=[-8., 8., -8., 8.])
+        b2, b2a = big.detector_image(extent=[-8., 8., -8., 8.]), big.detector_image()
+    same_image(a1, a2, tol=1e-12)
+    same_image(b1, b2, tol=1e-12)
+    same_image(b1a, b2a, tol=1e-12)
