@@ -233,21 +233,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Set-up: the first collective of a process group builds its communicator (milliseconds to seconds).  Done here, the
+    # barrier in front of the timed region is a warm one (~50 us).  That matters beyond its own duration: an idle gap of
+    # more than ~1 ms sends the GPU's power controller through a transient -- the first launch after it runs boosted, the
+    # next twenty throttled (2.2 ms falling back to 1.6; tools/nccl_after_effect.py, profiles/r3/idle_gap_transient.txt) --
+    # and a cold barrier right before the timed steps cost them 7 %.
+    if use_dist:
+        for _ in range(2):
+            barrier()
+
     # Set-up, untimed: let the clocks settle.  The first launches of this size run while the GPU ramps its clock under
     # the f64 load and runs into its power limit (the driver calls with --warmup 5, fewer than that takes; the very first
     # launches are the FAST ones, 1.56 against 1.61 ms): full-size traces until the kernel time the library measures, averaged
     # over five launches, moves by less than 0.5 % against the five before, at most 40 (~70 ms).
+    # With several ranks the phase runs in LOCKSTEP: after every launch the ranks exchange one flag (a warm 50 us collective)
+    # and go on until ALL have settled.  They then reach the warm-up steps and the barrier in front of the timed region within
+    # a fraction of a step of one another -- a rank that settled early would otherwise wait there idle for tens of
+    # milliseconds and walk into the transient described above.
     settle_launches, settle_hist = 0, []
+    flag = torch.zeros(1, dtype=torch.int32, device="cpu" if (use_dist and backend != "nccl") else dev)
     with ot.global_options.no_warnings():
         while settle_launches < 40:
             RT.trace(N)
             _capi.check(lib.ot_scene_last_trace_ms(RT._scene_handle, C.byref(ms)))
             settle_hist.append(ms.value)
             settle_launches += 1
+            settled = False
             if settle_launches >= 10:  # means of the last five launches and of the five before within 0.5 %
                 a5, b5 = sum(settle_hist[-5:]) / 5, sum(settle_hist[-10:-5]) / 5
-                if abs(a5 - b5) < 0.005 * b5:
-                    break
+                settled = abs(a5 - b5) < 0.005 * b5
+            if use_dist:
+                flag.fill_(1 if settled else 0)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                settled = bool(flag.item())
+            if settled:
+                break
 
     with ot.global_options.no_warnings():
         for i in range(args.warmup):
@@ -259,8 +279,10 @@ def main():
             RT.trace(N)  # synchronous like the reference's: returns when the rays and the counters are there
             _capi.check(lib.ot_scene_last_trace_ms(RT._scene_handle, C.byref(ms)))  # events around the kernel
             kernel_ms.append(ms.value)
-        barrier()
-        t_local = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0  # this rank's K steps (all ranks left the opening barrier together; the MAX over
+        barrier()                           # ranks below is the job's time -- the closing barrier itself, an RCCL collective
+                                            # of ~1.5 ms, is not part of the steps)
     kernel_ms = float(np.mean(kernel_ms))
     _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 0))
 
