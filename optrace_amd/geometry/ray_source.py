@@ -54,7 +54,9 @@ class RaySource(Element):
         if self._image is not None:
             linear = srgb_to_srgb_linear(surface._data if isinstance(surface, RGBImage) else surface.data)
             weight = (power_from_srgb_linear(linear) if isinstance(surface, RGBImage) else linear).ravel()
-            self._pIf = 1 / weight.sum() * weight
+            pdf = 1 / weight.sum() * weight
+            pdf.setflags(write=False)  # (derived from the read-only image data: a writeable array of this size would switch
+            self._pIf = pdf            # off the unchanged-scene shortcut of Raytracer.trace and be checksummed at every trace)
             surface = RectangularSurface(dim=surface.s)
         Element.__init__(self, surface, [0, 0, 0] if pos is None else pos, **kwargs)
 

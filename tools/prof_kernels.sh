@@ -13,9 +13,9 @@ import csv, glob, os, sys, re
 f = max(glob.glob(os.path.join(sys.argv[1], "*/*_kernel_stats.csv")), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-print(f"{'kernel':70s} {'calls':>6s} {'avg ms':>9s} {'total ms':>9s} {'%':>6s}")
+print(f"{'kernel':70s} {'calls':>6s} {'avg ms':>9s} {'min ms':>9s} {'total ms':>9s} {'%':>6s}")
 for r in rows[:25]:
     name = re.sub(r"\(.*", "", r["Name"])[:70]
-    print(f"{name:70s} {int(r['Calls']):6d} {float(r['AverageNs'])/1e6:9.3f} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['Percentage']):6.2f}")
+    print(f"{name:70s} {int(r['Calls']):6d} {float(r['AverageNs'])/1e6:9.3f} {float(r['MinNs'])/1e6:9.3f} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['Percentage']):6.2f}")
 PY
 cat "$R/gpurun_out/prof_$NAME.txt"
