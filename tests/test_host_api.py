@@ -418,3 +418,40 @@ def test_function_surface_z_bounds_like_the_reference():
             assert abs(a[0] - (z_min + dz[0])) > 1e-4 and abs(a[1] - (z_max + dz[1])) > 1e-4
         a = bounds(0, 5)                                                                          # generous: taken
         assert abs(a[0] - z_min) < 1e-7 and abs(a[1] - (z_max + 5)) < 1e-12
+
+
+def test_no_large_writeable_arrays_on_tracked_objects():
+    """The unchanged-scene shortcut of `Raytracer.trace` relies on large arrays of tracked objects being read-only (a
+    writeable one switches the shortcut off and is checksummed at every trace: 0.45 ms per trace for the pixel pdf of a
+    256 x 256 image source before it was locked).  Image sources, data surfaces, tabulated spectra and media included."""
+    import scenes
+    from optrace_amd.base import BaseClass
+
+    def writeable_arrays(root):
+        seen, out = set(), []
+
+        def walk(o, path):
+            if id(o) in seen:
+                return
+            seen.add(id(o))
+            for k, v in vars(o).items():
+                if isinstance(v, np.ndarray) and v.size >= 20 and v.flags.writeable:
+                    out.append(f"{path}.{k} {v.shape}")
+                elif isinstance(v, BaseClass):
+                    walk(v, f"{path}.{k}")
+                elif isinstance(v, list):
+                    for i, e in enumerate(v):
+                        if isinstance(e, BaseClass):
+                            walk(e, f"{path}.{k}[{i}]")
+        walk(root, "RT")
+        return out
+
+    with ot.global_options.no_warnings():
+        builders = {**scenes.SCENES, **scenes.SCENES2, **scenes.SCENES3}
+        for name, (build, _) in builders.items():
+            assert writeable_arrays(build(ot)) == [], name
+        RT = ot.Raytracer(outline=[-8, 8, -8, 8, 0, 40])
+        RT.add(ot.RaySource(ot.RGBImage(scenes.synthetic_rgb_image(), [4, 3]), pos=[0, 0, 0]))
+        RT.add(ot.RaySource(ot.GrayscaleImage(scenes.synthetic_gray_image(), [4, 3]), pos=[0, 0, 1],
+                            spectrum=ot.LightSpectrum("Data", wls=np.linspace(400., 700., 50), vals=np.linspace(1., 2., 50))))
+        assert writeable_arrays(RT) == []
