@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 5
+#define OT_ABI_VERSION 6
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -450,6 +450,38 @@ typedef struct ot_detector_image_req {
 } ot_detector_image_req;
 int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_image_req* reqs,
                        int32_t n_reqs, void* stream);
+
+/* Detector image with an AUTOMATIC extent (Raytracer.detector_image(extent=None), raytracer.py:1042-1049 + 1053-1098) in
+ * one pass over the ray sections, for detectors with a closed-form hit (flat, conic / spherical) without a sphere
+ * projection -- others: OT_ERR_UNSUPPORTED, use ot_detector_hits_multi (compact list) + ot_render_accumulate_compact.
+ * The image extent is the bounding box of the hits, known only after the last one; the calls below bin the hits on a
+ * provisional tile grid first and into the final pixel grid afterwards (csrc/ot_detector_fused.hpp, last section):
+ *
+ *   ot_detector_extent_sample      extent4 (x0, x1, y0, y1; +-inf without a hit) of the hits of every stride-th wave of 64
+ *                                  rays.  It lies inside the extent of all hits.  The caller lays a grid of tiles[0] x
+ *                                  tiles[1] <= 2048 tiles of tile[0] x tile[1] mm with its corner at origin over it (plus
+ *                                  a margin), such that one tile covers at most 61 x 61 pixels of the final image.
+ *   ot_detector_image_auto_begin   hit search, records (x, y, w, wl: 24 B per valid hit) by tile, result6 = the exact
+ *                                  extent of all valid hits (as ot_detector_req.extent4 reports it), result6[4] = hits
+ *                                  outside the grid (kept in a list of result6[5] entries: more than that -> cancel and
+ *                                  take the other path).
+ *   ot_detector_image_auto_finish  extent = the image extent after RenderImage.__fix_extent, Nx, Ny its pixel counts,
+ *                                  hist (Ny, Nx, 4) f64 device, ADDED to.  Same pixels and sums as ot_detector_hits_multi +
+ *                                  ot_render_accumulate (sums in another order).  Frees the handle, also on failure.
+ *   ot_detector_image_auto_cancel  frees the handle without an image.
+ *
+ * extent4 / result6: device-visible host memory (pinned, mapped) or device memory.  Both calls that report wait for the
+ * stream before they return.  Between begin and finish the calling thread must not start another automatic image on the
+ * same stream (the records live in the kept scratch block of that thread and stream, see ot_scratch_trim). */
+typedef struct ot_auto_image ot_auto_image;
+int ot_detector_extent_sample(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
+                              int32_t projection, int32_t stride, double* extent4, void* stream);
+int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
+                                 int32_t projection, const double origin[2], const double tile[2], const int32_t tiles[2],
+                                 double* result6, ot_auto_image** out, void* stream);
+int ot_detector_image_auto_finish(ot_auto_image* image, const double extent[4], int32_t Nx, int32_t Ny, double* hist,
+                                  void* stream);
+void ot_detector_image_auto_cancel(ot_auto_image* image);
 
 /* The binning paths keep their scratch (up to ~25 B per ray and image) between calls: one block per calling thread,
  * device, stream and purpose, grown on demand (calls on one stream run in order, so a block serves call after call).

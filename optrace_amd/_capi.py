@@ -146,6 +146,11 @@ SIGNATURES = {
     "ot_detector_hits": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(Surface), i32, C.POINTER(C.c_double), vp, vp, vp, vp, vp]),
     "ot_detector_hits_multi": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(DetectorReq), i32, vp]),
     "ot_detector_images": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(DetectorImageReq), i32, vp]),
+    "ot_detector_extent_sample": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(Surface), i32, i32, vp, vp]),
+    "ot_detector_image_auto_begin": (C.c_int, [C.POINTER(Rays), i64, i64, C.POINTER(Surface), i32, C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.POINTER(i32), vp, C.POINTER(vp), vp]),
+    "ot_detector_image_auto_finish": (C.c_int, [vp, C.POINTER(C.c_double), i32, i32, vp, vp]),
+    "ot_detector_image_auto_cancel": (None, [vp]),
     "ot_scratch_trim": (C.c_int, []),
     "ot_sphere_projection": (C.c_int, [C.POINTER(Surface), i32, i64, vp, vp, vp]),
     "ot_image_convert": (C.c_int, [vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]),
@@ -166,7 +171,7 @@ SIGNATURES = {
 
 FOCUS_WS = 16  # OT_FOCUS_WS
 HIT_PIECES = 1024  # OT_HIT_PIECES
-ABI_VERSION = 5  # OT_ABI_VERSION
+ABI_VERSION = 6  # OT_ABI_VERSION
 
 _lib = None
 

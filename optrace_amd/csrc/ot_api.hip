@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <algorithm>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -1368,7 +1369,7 @@ extern "C" int ot_sphere_projection(const ot_surface* surf, int32_t projection, 
 // 7-58 ms while the driver was digesting a large free (profiles/r3/readback_after_free.txt).  torch's allocator, which
 // owns the ray storage, cannot see this memory: ot_scratch_trim() hands all of it back on request.
 #include <mutex>
-enum { OT_WS_RENDER = 0, OT_WS_FUSED = 1, OT_WS_FUSED_HITS = 2 };
+enum { OT_WS_RENDER = 0, OT_WS_FUSED = 1, OT_WS_FUSED_HITS = 2, OT_WS_AUTO = 3 };
 struct WorkBlock {
     std::thread::id tid;
     int dev, purpose;
@@ -1544,6 +1545,19 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
 // ---- detector image in one pass (ot_detector_fused.hpp) ------------------------------------------------------
 static int cu_count();
 
+// the one-detector tile kernels stage their records in LDS: with many tiles more than the 64 KB a kernel gets unasked
+static int fuse_tiles_allow_lds(int dev) {
+    static thread_local bool done[64] = {false};
+    if (dev < 0 || dev >= 64 || done[dev]) return OT_OK;
+    const int most = 96 * 1024;
+    HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_kernel<false, 1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+    HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_kernel<false, 1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+    HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_kernel<false, 1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+    HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_kernel<false, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+    done[dev] = true;
+    return OT_OK;
+}
+
 extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_image_req* reqs,
                                   int32_t n_reqs, void* stream) {
     if (!rays || !reqs || n_reqs < 1) return fail(OT_ERR_INVALID, "ot_detector_images: null argument");
@@ -1661,7 +1675,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
             // a workgroup hands out chunks of its own part of the pool; every (workgroup, tile) pair leaves at most one
             // chunk partly filled
             f.per_wg = (uint32_t)((piece + OT_FUSE_CH - 1) / OT_FUSE_CH + f.K + 2);
-            f.cap = (uint32_t)std::min<int64_t>((int64_t)f.per_wg * n_wg, 0x7fffffffll);
+            f.cap = (uint32_t)std::min<int64_t>((int64_t)f.per_wg * n_wg, 0xffffffffll / OT_FUSE_CH - 1);  // record numbers: 32 bits
             o_ctile[k] = carve(sizeof(uint32_t) * f.cap);
             o_cfill[k] = carve(sizeof(uint32_t) * f.cap);
             o_rec[k] = carve(sizeof(TileRec) * (size_t)f.cap * OT_FUSE_CH);
@@ -1709,6 +1723,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         HIP_TRY(hipFuncSetAttribute((const void*)fuse_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
         lds_set[dev] = true;
     }
+    if (int rc = fuse_tiles_allow_lds(dev)) return rc;
     if (err == hipSuccess) {
         if (KT) {
             if (pin_tiles) {  // spread = 1 for every detector with a pool
@@ -1723,7 +1738,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
             }
         }
         const unsigned blocks = (unsigned)std::min<int64_t>(cus, (count + 1023) / 1024);
-        const size_t lds_tiles = sizeof(unsigned int) * (5 * (size_t)std::max(KT, 1) + OT_DET_MAX);
+        const size_t lds_tiles = fuse_tiles_lds(KT, general ? 8 : (n_reqs == 1 ? 1 : 2), small_k ? 2 : 1, false);
         ot_rays part = *rays;  // the tile kernel addresses its rays with 32 bits from the start of the range
         part.p += first;
         part.w += first;
@@ -1771,6 +1786,229 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         }
     }
     HIP_TRY(err);
+    return OT_OK;
+}
+
+// ---- detector image with an automatic extent in one pass (ot_detector_fused.hpp, last section) ---------------------
+// Scratch layout of OT_WS_AUTO: the head (detector record, flags, extent slots) is shared by the sample pass and the image.
+struct AutoHead {
+    size_t o_dets, o_flags, o_slots, end;
+    AutoHead() {
+        o_dets = 0;
+        o_flags = align_up(sizeof(FuseOne));
+        o_slots = o_flags + 256;
+        end = o_slots + align_up(sizeof(unsigned long long) * 4 * OT_EXT_SLOTS);
+    }
+};
+
+// a small record to device memory through the kernel arguments (no staging copy, nothing for the host to wait for)
+template <class T>
+__global__ void put_kernel(T v, T* dst) {
+    if (threadIdx.x == 0) *dst = v;
+}
+
+struct ot_auto_image {
+    FuseOne f;  // host copy; the image grid (a, hist) is filled in by finish
+    char* ws;
+    size_t o_tn, o_ts, o_list, o_ws, o_slabs;
+    unsigned n_slabs;
+    hipStream_t st;
+    int dev;
+};
+
+static int auto_detector(const char* who, const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
+                         int32_t projection) {
+    if (!rays || !detector) return fail(OT_ERR_INVALID, std::string(who) + ": null argument");
+    if (!rays->p || !rays->w || !rays->wl) return fail(OT_ERR_INVALID, std::string(who) + ": ray storage has null buffers");
+    if (first < 0 || count < 1 || first + count > rays->N) return fail(OT_ERR_INVALID, std::string(who) + ": range outside the storage");
+    if (count >= (1ll << 31)) return fail(OT_ERR_UNSUPPORTED, std::string(who) + ": at most 2^31 - 1 rays per call");
+    const bool closed = detector->kind <= OT_SURF_CONIC || detector->z_min == detector->z_max;
+    const bool plain = projection == OT_PROJ_NONE || projection == OT_PROJ_ORTHOGRAPHIC;
+    if (!closed || !plain)
+        return fail(OT_ERR_UNSUPPORTED, std::string(who) + ": detectors with a numeric hit search or a sphere projection take ot_detector_hits_multi");
+    return OT_OK;
+}
+
+static void auto_fill_detector(FuseOne& f, const LeafSurface& ls, const ot_surface* detector, int32_t projection) {
+    std::memset(&f, 0, sizeof(f));
+    f.det = ls.d;
+    f.Rcurv = detector->R;
+    f.projection = projection;
+}
+
+extern "C" int ot_detector_extent_sample(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
+                                         int32_t projection, int32_t stride, double* extent4, void* stream) {
+    if (int rc = auto_detector("ot_detector_extent_sample", rays, first, count, detector, projection)) return rc;
+    if (!extent4 || stride < 1) return fail(OT_ERR_INVALID, "ot_detector_extent_sample: bad argument");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LeafSurface ls;
+    if (int rc = ls.init(detector, st)) return rc;
+    const AutoHead h;
+    char* ws = workspace(OT_WS_AUTO, h.end, st);
+    if (!ws) return fail(OT_ERR_HIP, "ot_detector_extent_sample: no scratch memory");
+    FuseOne f;
+    auto_fill_detector(f, ls, detector, projection);
+    f.g.ext_slots = (unsigned long long*)(ws + h.o_slots);
+    hipLaunchKernelGGL(put_kernel<FuseOne>, dim3(1), dim3(64), 0, st, f, (FuseOne*)(ws + h.o_dets));
+    hipLaunchKernelGGL(extent_init_kernel, dim3(1), dim3(4 * OT_EXT_SLOTS), 0, st, f.g.ext_slots);
+    ot_rays part = *rays;
+    part.p += first;
+    part.w += first;
+    part.wl += first;
+    const int64_t waves = (count + 64ll * stride - 1) / (64ll * stride);
+    hipLaunchKernelGGL(spec_sample_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, part, (uint32_t)count,
+                       (const FuseOne*)(ws + h.o_dets), (uint32_t)stride);
+    hipLaunchKernelGGL(spec_result_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)f.g.ext_slots,
+                       (const unsigned int*)nullptr, extent4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // the caller reads extent4 next (and the detector's tables may go)
+    return OT_OK;
+}
+
+extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
+                                            int32_t projection, const double origin[2], const double tile[2],
+                                            const int32_t tiles[2], double* result6, ot_auto_image** out, void* stream) {
+    if (out) *out = nullptr;
+    if (int rc = auto_detector("ot_detector_image_auto_begin", rays, first, count, detector, projection)) return rc;
+    if (!origin || !tile || !tiles || !result6 || !out) return fail(OT_ERR_INVALID, "ot_detector_image_auto_begin: null argument");
+    if (!(tile[0] > 0.0) || !(tile[1] > 0.0) || tiles[0] < 1 || tiles[1] < 1 || !std::isfinite(origin[0]) || !std::isfinite(origin[1]))
+        return fail(OT_ERR_INVALID, "ot_detector_image_auto_begin: bad tile grid");
+    const int64_t K = (int64_t)tiles[0] * tiles[1];
+    if (K > OT_TILE_MAX || K > OT_FUSE_LDS_ENTRIES) return fail(OT_ERR_UNSUPPORTED, "ot_detector_image_auto_begin: more than 2048 tiles");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LeafSurface ls;
+    if (int rc = ls.init(detector, st)) return rc;
+    const int cus = cu_count();
+    const bool small_k = K <= 1024 && !std::getenv("OT_AUTO_RPT1");  // two rays per thread and sub-block (10-bit tile numbers), as in ot_detector_images
+    const int64_t brt = OT_FUSE_BR * (small_k ? 2 : 1);
+    const unsigned n_wg = (unsigned)std::min<int64_t>(2 * (int64_t)cus, (count + brt - 1) / brt);
+    const int64_t piece = ((count + n_wg - 1) / n_wg + brt - 1) / brt * brt;
+
+    std::unique_ptr<ot_auto_image> im(new ot_auto_image);
+    FuseOne& f = im->f;
+    auto_fill_detector(f, ls, detector, projection);
+    f.tx = tiles[0];
+    f.K = (int32_t)K;
+    f.tiles_ok = 1;
+    f.koff = 0;
+    f.per_wg = (uint32_t)((piece + OT_FUSE_CH - 1) / OT_FUSE_CH + f.K + 2);
+    f.cap = (uint32_t)std::min<int64_t>((int64_t)f.per_wg * n_wg, 0xffffffffll / OT_FUSE_CH - 1);  // record numbers: 32 bits
+    f.g.X0 = origin[0];
+    f.g.Y0 = origin[1];
+    f.g.tw = tile[0];
+    f.g.th = tile[1];
+    f.g.itw = 1.0 / tile[0];
+    f.g.ith = 1.0 / tile[1];
+    f.g.tx = tiles[0];
+    f.g.ty = tiles[1];
+    f.g.esc_cap = (unsigned int)std::max<int64_t>(1ll << 18, count / 64);
+
+    const AutoHead h;
+    size_t off = h.end;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_ctile = carve(sizeof(uint32_t) * f.cap);
+    const size_t o_cfill = carve(sizeof(uint32_t) * f.cap);
+    const size_t o_rec = carve(sizeof(SpecRec) * (size_t)f.cap * OT_FUSE_CH);
+    const size_t o_esc = carve(sizeof(SpecRec) * (size_t)f.g.esc_cap);
+    im->o_tn = carve(sizeof(unsigned int) * f.K);
+    im->o_ts = carve(sizeof(unsigned int) * (f.K + 1));
+    im->o_list = carve(sizeof(unsigned int) * f.cap);
+    im->o_ws = carve(sizeof(unsigned int) * (f.K + 1));
+    im->n_slabs = (unsigned)((f.cap + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)f.K;
+    im->o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)im->n_slabs);
+    char* ws = workspace(OT_WS_AUTO, off, st);
+    if (!ws) return fail(OT_ERR_HIP, "ot_detector_image_auto_begin: no scratch memory");
+    im->ws = ws;
+    im->st = st;
+    (void)hipGetDevice(&im->dev);
+    if (int rc = fuse_tiles_allow_lds(im->dev)) return rc;
+    int* flags = (int*)(ws + h.o_flags);
+    f.spread = flags;
+    f.overflow = flags + 2;
+    f.g.esc_n = (unsigned int*)(flags + 3);
+    f.g.ext_slots = (unsigned long long*)(ws + h.o_slots);
+    f.chunk_tile = (uint32_t*)(ws + o_ctile);
+    f.chunk_fill = (uint32_t*)(ws + o_cfill);
+    f.rec = (TileRec*)(ws + o_rec);
+    f.g.esc = (SpecRec*)(ws + o_esc);
+    hipLaunchKernelGGL(put_kernel<int4>, dim3(1), dim3(64), 0, st, make_int4(1, 0, 0, 0), (int4*)flags);  // spread = 1: tiles always
+    hipLaunchKernelGGL(put_kernel<FuseOne>, dim3(1), dim3(64), 0, st, f, (FuseOne*)(ws + h.o_dets));
+    hipLaunchKernelGGL(extent_init_kernel, dim3(1), dim3(4 * OT_EXT_SLOTS), 0, st, f.g.ext_slots);
+    ot_rays part = *rays;  // the tile kernel addresses its rays with 32 bits from the start of the range
+    part.p += first;
+    part.w += first;
+    part.wl += first;
+    const FuseOne* dd = (const FuseOne*)(ws + h.o_dets);
+    const size_t lds_tiles = fuse_tiles_lds(f.K, 1, small_k ? 2 : 1, true);
+    if (small_k)
+        hipLaunchKernelGGL((fuse_tiles_kernel<false, 1, 2, true>), dim3(n_wg), dim3(OT_FUSE_BR), lds_tiles, st, part, (uint32_t)count,
+                           dd, 1, f.K, (uint32_t)piece);
+    else
+        hipLaunchKernelGGL((fuse_tiles_kernel<false, 1, 1, true>), dim3(n_wg), dim3(OT_FUSE_BR), lds_tiles, st, part, (uint32_t)count,
+                           dd, 1, f.K, (uint32_t)piece);
+    hipLaunchKernelGGL(spec_result_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)f.g.ext_slots,
+                       (const unsigned int*)f.g.esc_n, result6);
+    HIP_TRY(hipGetLastError());
+    // the caller needs the extent before it can go on: wait here (also: the detector's tables may go, result6[5] is ours)
+    HIP_TRY(hipStreamSynchronize(st));
+    result6[5] = (double)f.g.esc_cap;
+    *out = im.release();
+    return OT_OK;
+}
+
+extern "C" void ot_detector_image_auto_cancel(ot_auto_image* im) { delete im; }
+
+extern "C" int ot_detector_image_auto_finish(ot_auto_image* im_raw, const double extent[4], int32_t Nx, int32_t Ny,
+                                             double* hist, void* stream) {
+    std::unique_ptr<ot_auto_image> im(im_raw);  // freed whatever happens
+    if (!im || !extent || !hist || Nx < 1 || Ny < 1) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: bad argument");
+    if (!(extent[1] > extent[0]) || !(extent[3] > extent[2])) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: empty image extent");
+    if ((int64_t)Nx * Ny > (1ll << 27)) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: image too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (st != im->st) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: not the stream of ot_detector_image_auto_begin");
+    // (the scratch block of begin is still ours: a block changes only through calls of this thread on this stream)
+    if (workspace(OT_WS_AUTO, 1, st) != im->ws) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: the scratch of this image was reused");
+    const double* table = observer_table_device();
+    if (!table) return fail(OT_ERR_HIP, "could not upload the CIE observer table");
+    FuseOne& f = im->f;
+    f.a.x0 = extent[0];
+    f.a.x1 = extent[1];
+    f.a.y0 = extent[2];
+    f.a.y1 = extent[3];
+    f.a.fx = (double)Nx / (extent[1] - extent[0]);  // Nx / s[0]  misc.py:75
+    f.a.fy = (double)Ny / (extent[3] - extent[2]);
+    f.a.Nx = Nx;
+    f.a.Ny = Ny;
+    f.hist = hist;
+    char* ws = im->ws;
+    FuseIndex ix;
+    ix.tile_n = (unsigned int*)(ws + im->o_tn);
+    ix.tstart = (unsigned int*)(ws + im->o_ts);
+    ix.wstart = (unsigned int*)(ws + im->o_ws);
+    ix.n_slabs = im->n_slabs;
+    ix.list = (unsigned int*)(ws + im->o_list);
+    ix.slabs = (double*)(ws + im->o_slabs);
+    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
+    static thread_local bool lds_set[64] = {false};
+    if (im->dev >= 0 && im->dev < 64 && !lds_set[im->dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)spec_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
+        lds_set[im->dev] = true;
+    }
+    HIP_TRY(hipMemsetAsync(ix.tile_n, 0, sizeof(unsigned int) * f.K, st));
+    const unsigned gc = (f.cap + 1024 * OT_FUSE_IDX_PER - 1) / (1024 * OT_FUSE_IDX_PER);
+    hipLaunchKernelGGL(fuse_chunk_hist_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
+    hipLaunchKernelGGL(fuse_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, f, ix);
+    hipLaunchKernelGGL(fuse_chunk_place_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
+    hipLaunchKernelGGL(spec_accum_kernel, dim3(ix.n_slabs), dim3(1024), lds_accum, st, f, ix, table);
+    hipLaunchKernelGGL(spec_reduce_kernel, dim3(OT_TILE_PX / 256, (unsigned)f.K), dim3(256), 0, st, f, ix);
+    hipLaunchKernelGGL(spec_escaped_kernel, dim3(64), dim3(256), 0, st, f, table);
+    HIP_TRY(hipGetLastError());
     return OT_OK;
 }
 

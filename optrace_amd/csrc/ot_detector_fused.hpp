@@ -24,6 +24,23 @@
 #define OT_FUSE_NONE 0xffffffffu
 #define OT_FUSE_LDS_ENTRIES 2400  // (detector, tile) entries a tile-kernel workgroup can keep (20 B each)
 
+// Automatic extent in one pass ("speculative grid", see the section at the end of this file): tiles of a provisional
+// grid laid over the extent of a sample of the rays; records carry the hit position itself.
+struct SpecRec {
+    double x, y;
+    float w, wl;
+};
+struct SpecGrid {
+    double X0, Y0;    // lower left corner of tile (0, 0)
+    double tw, th;    // tile width / height (mm), and their reciprocals
+    double itw, ith;
+    int32_t tx, ty;   // tiles along x / y
+    unsigned long long* ext_slots;  // OT_EXT_SLOTS x 4 ordered values: extent of the valid hits
+    SpecRec* esc;                   // hits outside the grid (binned with global atomics)
+    unsigned int* esc_n;            // [1] hits that asked for a place in esc
+    unsigned int esc_cap;
+};
+
 struct FuseOne {  // one detector of a fused launch
     SurfDev det;
     double Rcurv;
@@ -43,6 +60,7 @@ struct FuseOne {  // one detector of a fused launch
     uint32_t cap;          // = workgroups of the tile kernel * per_wg
     uint32_t per_wg;       // every workgroup hands out chunks of its own part of the pool: no global atomics
     int* overflow;         // [1] set if a part ran dry (cannot happen with the size the host computes)
+    SpecGrid g;            // SPECX kernels only
 };
 
 template <class FT>
@@ -217,23 +235,86 @@ OT_DEV void fuse_advance(unsigned int* fill, unsigned int* cur, const unsigned i
     }
 }
 
+// extent of a workgroup's valid hits -> one of the slot tables (ordered integer atomics, as extent_flush does)
+OT_DEV void spec_extent_flush(unsigned long long* slots, const double ext[4]) {
+    __shared__ double sx[16][4];  // up to 1024 threads
+    const double e[4] = {wave_min(ext[0]), wave_max(ext[1]), wave_min(ext[2]), wave_max(ext[3])};
+    const int wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+    if (__lane_id() == 0)
+        for (int c = 0; c < 4; c++) sx[wave][c] = e[c];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int c = threadIdx.x;
+        const double inf = __builtin_inf();
+        double v = sx[0][c];
+        for (int k = 1; k < n_waves; k++) v = (c & 1) ? fmax(v, sx[k][c]) : fmin(v, sx[k][c]);
+        if (v == v && v != ((c & 1) ? -inf : inf)) {
+            unsigned long long* dst = slots + 4 * (blockIdx.x % OT_EXT_SLOTS) + c;
+            if (c & 1)
+                atomicMax(dst, f64_to_ordered(v));
+            else
+                atomicMin(dst, f64_to_ordered(v));
+        }
+    }
+}
+
 // RPT rays per thread and sub-block (2 where the detectors' images have at most 1024 tiles: more loads in flight per
 // barrier); R's pointers are advanced to the first ray of the range by the host, rays are addressed with 32 bits.
-template <bool GENERAL, int NDET, int RPT>
+// LDS of the tile kernel: 6 KT + 10 counters, then (one detector) the staging area of a sub-block's records
+__host__ __device__ static inline size_t fuse_stage_offset(int KT) {
+    return (sizeof(unsigned int) * (6 * (size_t)KT + OT_DET_MAX + 2) + 15) / 16 * 16;
+}
+__host__ __device__ static inline size_t fuse_tiles_lds(int KT, int n_det, int rpt, bool specx) {
+    const size_t counters = sizeof(unsigned int) * (5 * (size_t)(KT > 1 ? KT : 1) + OT_DET_MAX);
+#ifndef OT_FUSE_SORT
+    return counters;
+#endif
+    if (n_det != 1) return counters;
+    return fuse_stage_offset(KT) + (size_t)OT_FUSE_BR * rpt * (specx ? 28 : 16);
+}
+
+// SPECX: the speculative-grid form (one detector, closed-form hit): the tile comes from SpecGrid instead of the image's
+// pixel grid, the record is a SpecRec, and the extent of the valid hits is gathered on the way.
+template <bool GENERAL, int NDET, int RPT, bool SPECX = false>
 __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint32_t count, const FuseOne* __restrict__ dets,
                                                                 int n_det, int KT, uint32_t piece) {
-    bool any = false;
-    for (int d = 0; d < n_det; d++) any = any || as_const(dets)[d].spread[0];
-    if (!any) return;
+    // the probe's verdicts, read ONCE: a load of spread[0] inside the loop below is a vector-memory operation like the
+    // prefetch of the next sub-block's sections, and the wait for it (vmcnt(0)) was a wait for that prefetch as well
+    unsigned int spread_mask = 0u;
+    for (int d = 0; d < n_det; d++)
+        if (as_const(dets)[d].spread[0]) spread_mask |= 1u << d;
+    spread_mask = (unsigned int)__builtin_amdgcn_readfirstlane((int)spread_mask);
+    if (!spread_mask) return;
     constexpr uint32_t BRT = OT_FUSE_BR * RPT;        // rays per sub-block
     constexpr int TB = (RPT == 1) ? 11 : 10;          // bits of the tile number in a record key
+    // SORT (one detector, -DOT_FUSE_SORT): the records of a sub-block are gathered tile by tile in LDS before they are stored,
+    // so that neighbouring lanes write neighbouring records of one chunk instead of 64 different chunks per store
+    // instruction.  Built because the record stores cost as much as everything else in this kernel together (C5, 9.3e7
+    // records of 24 B: 2.10 ms; 1.05 ms without the stores, 1.62 ms with the same stores aimed at 400 KB per workgroup);
+    // measured: no gain (C5 image 3.17 = 3.17 ms, C4 with a known extent 3.4 against 3.2 ms) -- a tile receives ~3 records
+    // per sub-block, the runs stay shorter than a cache line.  Off by default.
+#ifdef OT_FUSE_SORT
+    constexpr bool SORT = (NDET == 1);
+#else
+    constexpr bool SORT = false;
+#endif
     extern __shared__ unsigned int fl[];
     unsigned int* cnt = fl;  // [2][KT]
     unsigned int* fill = fl + 2 * KT;
     unsigned int* cur = fl + 3 * KT;
     unsigned int* nb = fl + 4 * KT;
     unsigned int* next = fl + 5 * KT;  // [n_det] next free chunk of this workgroup's part of each detector's pool
+    unsigned int* sbase = next + OT_DET_MAX;  // SORT [KT]: first staging slot of a tile's records of this sub-block
+    unsigned int* stop = sbase + KT;          // SORT [2]: staging slots taken (by sub-block parity)
+    char* stg = (char*)fl + fuse_stage_offset(KT);
+    double* sx = (double*)stg;                // SPECX: [BRT] x, [BRT] y
+    double* sy = sx + BRT;
+    float* sw = (float*)(SPECX ? stg + 16 * BRT : stg);  // [BRT] weight, [BRT] wavelength
+    float* swl = sw + BRT;
+    unsigned int* sdst = (unsigned int*)(swl + BRT);     // [BRT] record number in the pool, OT_FUSE_NONE: dropped
+    unsigned int* spx = sdst + BRT;                      // plain records: [BRT] pixel in the tile
     if (threadIdx.x < (unsigned)n_det) next[threadIdx.x] = blockIdx.x * as_const(dets)[threadIdx.x].per_wg;
+    if (SORT && threadIdx.x < 2) stop[threadIdx.x] = 0u;
     for (int e = threadIdx.x; e < KT; e += blockDim.x) {
         cnt[e] = 0u;
         cnt[KT + e] = 0u;
@@ -244,17 +325,26 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
     __syncthreads();
     const uint32_t i0 = blockIdx.x * piece;
     const uint32_t i1 = (i0 + piece < count) ? i0 + piece : count;
-    // sections of the first sub-block
+    // Software pipeline: the sections of sub-block i + 1 are requested at the top of round i and awaited between its
+    // second barrier and its record stores (`arrive`), where they have had the round's arithmetic and both barriers to
+    // travel; at the top of the next round nothing is pending but those stores.  The loads carry no condition (lanes
+    // beyond the range read the last ray and are switched off by `act`): see load_section_pair_always.
     SectionPair sp_n[RPT];
     float wl_n[RPT];
     bool act_n[RPT];
+    auto request = [&](uint32_t base) {
 #pragma unroll
-    for (int j = 0; j < RPT; j++) {
-        const uint32_t q = i0 + j * OT_FUSE_BR + threadIdx.x;
-        act_n[j] = q < i1;
-        sp_n[j] = load_section_pair(R, (int64_t)(act_n[j] ? q : 0u), act_n[j]);
-        wl_n[j] = act_n[j] ? OT_STREAM_LOAD(&R.wl[q]) : 0.f;
-    }
+        for (int j = 0; j < RPT; j++) {
+            const uint32_t q = base + j * OT_FUSE_BR + threadIdx.x;
+            act_n[j] = q < i1;  // (count < 2^31: no wrap)
+            const uint32_t qc = act_n[j] ? q : count - 1u;
+            sp_n[j] = load_section_pair_always(R, (int64_t)qc);
+            wl_n[j] = OT_STREAM_LOAD(&R.wl[qc]);
+        }
+    };
+    request(i0);
+    const double inf = __builtin_inf();
+    double ext[4] = {inf, -inf, inf, -inf};  // SPECX: x_min, x_max, y_min, y_max of this lane's valid hits
     int par = 0;
     for (uint32_t s = i0; s < i1; s += BRT, par ^= 1) {
         SectionPair sp[RPT];
@@ -265,12 +355,8 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
             sp[j] = sp_n[j];
             wl[j] = wl_n[j];
             act[j] = act_n[j];
-            // request the next sub-block's sections now: they travel while this one is processed
-            const uint32_t q = s + BRT + j * OT_FUSE_BR + threadIdx.x;
-            act_n[j] = q < i1;  // (count < 2^31: no wrap)
-            sp_n[j] = load_section_pair(R, (int64_t)(act_n[j] ? q : 0u), act_n[j]);
-            wl_n[j] = act_n[j] ? OT_STREAM_LOAD(&R.wl[q]) : 0.f;
         }
+        request(s + BRT);
 
         // The detector records are read through a pointer the optimiser cannot see through, once per sub-block:
         // otherwise lane constants derived from them are hoisted out of this loop and kept in vector registers.
@@ -281,6 +367,7 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
         // phase 1: hits, pixel, rank inside the tile's share of this sub-block
         float wk[RPT][NDET];
         unsigned int key[RPT][NDET];  // rank << (12 + TB) | tile << 12 | pixel in tile
+        double hx[RPT], hy[RPT];      // SPECX: the hit itself
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
             const uint32_t q = s + j * OT_FUSE_BR + threadIdx.x;
@@ -292,10 +379,10 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
                 key[j][d] = 0u;
                 if (d >= n_det) continue;
                 const auto& F = as_const(dl)[d];
-                if (!F.spread[0]) continue;
+                if (!((spread_mask >> d) & 1u)) continue;
                 V3 ph;
                 float w;
-                bool valid, ill = false, to = false;
+                bool valid = false, ill = false, to = false;
                 // flat detector behind the last surface (the usual case): no section search; the wave takes the general
                 // path only if one of its lanes needs it
                 bool settled = false;
@@ -305,10 +392,26 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
                 }
                 if (GENERAL) fuse_count_ill(F, ill, to);
                 if (!valid) continue;
-                int32_t ix, iy;
-                if (fuse_pixel(F, ph, ix, iy) < 0) continue;
-                const unsigned int local = (unsigned int)(((iy & (OT_TILE_W - 1)) << 6) | (ix & (OT_TILE_W - 1)));
-                const unsigned int tile = (unsigned int)((iy >> 6) * F.tx + (ix >> 6));
+                unsigned int local, tile;
+                if constexpr (SPECX) {
+                    ext[0] = fmin(ext[0], ph.x), ext[1] = fmax(ext[1], ph.x);
+                    ext[2] = fmin(ext[2], ph.y), ext[3] = fmax(ext[3], ph.y);
+                    const double u = (ph.x - F.g.X0) * F.g.itw, v = (ph.y - F.g.Y0) * F.g.ith;
+                    if (!(u >= 0.0 && u < (double)F.g.tx && v >= 0.0 && v < (double)F.g.ty)) {
+                        // outside the provisional grid (the tail of a distribution the sample did not reach): kept aside
+                        const unsigned int k = atomicAdd(F.g.esc_n, 1u);
+                        if (k < F.g.esc_cap) F.g.esc[k] = {ph.x, ph.y, w, wl[j]};
+                        continue;
+                    }
+                    local = 0u;
+                    tile = (unsigned int)((int)v * F.g.tx + (int)u);
+                    hx[j] = ph.x, hy[j] = ph.y;
+                } else {
+                    int32_t ix, iy;
+                    if (fuse_pixel(F, ph, ix, iy) < 0) continue;
+                    local = (unsigned int)(((iy & (OT_TILE_W - 1)) << 6) | (ix & (OT_TILE_W - 1)));
+                    tile = (unsigned int)((iy >> 6) * F.tx + (ix >> 6));
+                }
                 const unsigned int rank = atomicAdd(&cnt_a[F.koff + (int)tile], 1u);
                 wk[j][d] = w;
                 key[j][d] = (rank << (12 + TB)) | (tile << 12) | local;
@@ -317,6 +420,7 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
         fuse_lds_barrier();
         // phase 2: the previous sub-block's counts move the open chunks on; tiles whose open chunk overflows with this
         // sub-block's records take new chunks from the workgroup's part of their detector's pool
+        if (SORT && threadIdx.x == 0) stop[par ^ 1] = 0u;  // (last read before this round's first barrier)
         for (int e = threadIdx.x; e < KT; e += blockDim.x) {
             const unsigned int cb = cnt_b[e];
             if (cb) {
@@ -325,6 +429,7 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
             }
             const unsigned int c = cnt_a[e];
             if (!c) continue;
+            if (SORT) sbase[e] = atomicAdd(&stop[par], c);  // the tile's records stand together, tiles in any order
             const unsigned int f = fill[e] + c;
             if (f <= OT_FUSE_CH) continue;
             int d = 0;
@@ -344,8 +449,12 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
             }
         }
         fuse_lds_barrier();
+        if constexpr (!SORT) {
+#pragma unroll
+            for (int j = 0; j < RPT; j++) arrive(sp_n[j], wl_n[j]);
+        }
         // phase 3: one 12-byte store per hit.  (The next phase 2 changes fill / cur / nb only behind the next barrier,
-        // which every wave reaches after these reads.)
+        // which every wave reaches after these reads.)  SORT: into the staging slots first.
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
 #pragma unroll
@@ -364,9 +473,46 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
                     chunk = nb[e] + dest / OT_FUSE_CH;
                     dest %= OT_FUSE_CH;
                 }
-                if (chunk < F.cap) {
-                    TileRec rec = {wk[j][d], wl[j], local};
-                    F.rec[(size_t)chunk * OT_FUSE_CH + dest] = rec;
+                if constexpr (SORT) {
+                    const unsigned int t = sbase[e] + rank;
+                    sdst[t] = (chunk < F.cap) ? chunk * OT_FUSE_CH + dest : OT_FUSE_NONE;  // (pool < 2^32 records: host)
+                    sw[t] = wk[j][d];
+                    swl[t] = wl[j];
+                    if constexpr (SPECX) {
+                        sx[t] = hx[j];
+                        sy[t] = hy[j];
+                    } else {
+                        spx[t] = local;
+                    }
+                } else if (chunk < F.cap) {
+                    if constexpr (SPECX) {
+                        SpecRec* dst = (SpecRec*)F.rec + ((size_t)chunk * OT_FUSE_CH + dest);
+                        SpecRec rec = {hx[j], hy[j], wk[j][d], wl[j]};
+                        *dst = rec;
+                    } else {
+                        TileRec rec = {wk[j][d], wl[j], local};
+                        F.rec[(size_t)chunk * OT_FUSE_CH + dest] = rec;
+                    }
+                }
+            }
+        }
+        if constexpr (SORT) {
+            // phase 4: the staged records in slot order -- lanes next to each other write records next to each other
+            fuse_lds_barrier();
+#pragma unroll
+            for (int j = 0; j < RPT; j++) arrive(sp_n[j], wl_n[j]);
+            const auto& F = as_const(dl)[0];
+            const unsigned int n_rec = stop[par];
+            for (unsigned int t = threadIdx.x; t < n_rec; t += OT_FUSE_BR) {
+                unsigned int dsti = sdst[t];
+                if (dsti == OT_FUSE_NONE) continue;
+
+                if constexpr (SPECX) {
+                    SpecRec rec = {sx[t], sy[t], sw[t], swl[t]};
+                    ((SpecRec*)F.rec)[dsti] = rec;
+                } else {
+                    TileRec rec = {sw[t], swl[t], spx[t]};
+                    F.rec[dsti] = rec;
                 }
             }
         }
@@ -386,10 +532,11 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
     // chunks of this workgroup's parts that were never handed out
     for (int d = 0; d < n_det; d++) {
         const auto& F = as_const(dets)[d];
-        if (!F.spread[0]) continue;
+        if (!((spread_mask >> d) & 1u)) continue;
         const unsigned int end = (blockIdx.x + 1) * F.per_wg;
         for (unsigned int c = min(next[d], end) + threadIdx.x; c < end; c += blockDim.x) F.chunk_tile[c] = OT_FUSE_NONE;
     }
+    if constexpr (SPECX) spec_extent_flush(as_const(dets)[0].g.ext_slots, ext);
 }
 
 // ---- tile path, pass 2: chunks grouped by tile ------------------------------------------------------------------
@@ -426,22 +573,30 @@ __global__ __launch_bounds__(1024) void fuse_chunk_hist_kernel(FuseOne F, FuseIn
 
 __global__ __launch_bounds__(1024) void fuse_chunk_scan_kernel(FuseOne F, FuseIndex ix) {
     if (!F.spread[0]) return;
-    __shared__ unsigned int n_s[OT_TILE_MAX];
-    for (int i = threadIdx.x; i < F.K; i += blockDim.x) n_s[i] = ix.tile_n[i];
-    __syncthreads();
-    if (threadIdx.x == 0) {  // K <= 2048 entries in LDS: a serial scan costs a few microseconds
-        unsigned int acc = 0, wg = 0;
-        for (int i = 0; i < F.K; i++) {
-            ix.tstart[i] = acc;
-            ix.wstart[i] = wg;
-            acc += n_s[i];
-            wg += (n_s[i] + OT_FUSE_CPW - 1) / OT_FUSE_CPW;
-        }
-        ix.tstart[F.K] = acc;
-        ix.wstart[F.K] = wg;
+    // exclusive scans of the chunk counts (tstart) and of the workgroups they take (wstart) over K <= 2048 tiles: two
+    // tiles per thread, wave scans by shuffles, the 16 wave totals through LDS
+    __shared__ unsigned int wsum[2][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i0 = 2 * t, i1 = 2 * t + 1;
+    const unsigned int n0 = i0 < F.K ? ix.tile_n[i0] : 0u, n1 = i1 < F.K ? ix.tile_n[i1] : 0u;
+    const unsigned int g0 = (n0 + OT_FUSE_CPW - 1) / OT_FUSE_CPW, g1 = (n1 + OT_FUSE_CPW - 1) / OT_FUSE_CPW;
+    unsigned int a = n0 + n1, w = g0 + g1;  // inclusive scans over the threads
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int ua = __shfl_up(a, o), uw = __shfl_up(w, o);
+        if (lane >= o) a += ua, w += uw;
     }
+    if (lane == 63) wsum[0][wave] = a, wsum[1][wave] = w;
     __syncthreads();
-    for (int i = threadIdx.x; i < F.K; i += blockDim.x) ix.tile_n[i] = 0u;  // becomes the placement cursor
+    unsigned int base_a = 0, base_w = 0;
+    for (int k = 0; k < wave; k++) base_a += wsum[0][k], base_w += wsum[1][k];
+    const unsigned int ea = base_a + a - (n0 + n1), ew = base_w + w - (g0 + g1);  // exclusive, at tile i0
+    if (i0 < F.K) ix.tstart[i0] = ea, ix.wstart[i0] = ew;
+    if (i1 < F.K) ix.tstart[i1] = ea + n0, ix.wstart[i1] = ew + g0;
+    if (i0 == F.K - 1 || i1 == F.K - 1) ix.tstart[F.K] = base_a + a, ix.wstart[F.K] = base_w + w;  // the totals
+    __syncthreads();  // (tile_n is read above by its own thread only; the barrier keeps the kernel's phases apart)
+    if (i0 < F.K) ix.tile_n[i0] = 0u;  // becomes the placement cursor
+    if (i1 < F.K) ix.tile_n[i1] = 0u;
 }
 
 // the workgroup's chunks of a tile get consecutive places behind one global reservation per tile
@@ -484,10 +639,10 @@ __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex i
     double* obs = lds + OT_TILE_PX * 4;
     unsigned int* ws = (unsigned int*)lds;
     const int K = F.K;
+    const unsigned int b = blockIdx.x;
+    if (b >= ix.wstart[K]) return;  // (the grid is sized for the worst case: most workgroups leave here, before the table)
     for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
     __syncthreads();
-    const unsigned int b = blockIdx.x;
-    if (b >= ws[K]) return;
     int lo = 0, hi = K;  // ws[lo] <= b < ws[hi]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -501,23 +656,29 @@ __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex i
     const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
     for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
     for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
+    __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
+    for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
+        const unsigned int c = ix.list[c0 + j_begin + i];
+        s_chunk[i] = c;
+        s_fill[i] = F.chunk_fill[c];
+    }
     __syncthreads();
+    // The workgroup's chunk numbers and fill counts go to LDS first (list -> fill -> record used to be three dependent
+    // round trips per round), and the records of round i + 1 are requested before those of round i are added.
     constexpr int PER = 1024 / OT_FUSE_CH;  // chunks a workgroup handles at once
-    constexpr int DEPTH = 8;                // chunk rounds in flight per thread (list -> fill -> record are dependent loads)
+    constexpr int DEPTH = 4;                // chunk rounds per stage; two stages in flight per thread
     const int g = threadIdx.x / OT_FUSE_CH, slot = threadIdx.x % OT_FUSE_CH;
-    for (unsigned int j0 = j_begin + (unsigned int)g; j0 < j_end; j0 += PER * DEPTH) {
-        TileRec rec[DEPTH];
-        bool ok[DEPTH];
+    const int n_c = (int)(j_end - j_begin);
+    const TileRec* __restrict__ recs = F.rec;
+    auto load = [&](int first, TileRec* rec, bool* ok) {
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) {
-            const unsigned int j = j0 + k * PER;
-            ok[k] = j < j_end;
-            if (ok[k]) {
-                const unsigned int c = ix.list[c0 + j];
-                ok[k] = (unsigned int)slot < F.chunk_fill[c];
-                if (ok[k]) rec[k] = F.rec[(size_t)c * OT_FUSE_CH + slot];
-            }
+            const int i = first + k * PER, ic = i < n_c ? i : 0;
+            ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
+            rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];  // (no condition: every slot of a chunk exists; see load_section_pair_always)
         }
+    };
+    auto add = [&](const TileRec* rec, const bool* ok) {
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) {
             if (!ok[k]) continue;
@@ -532,6 +693,15 @@ __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex i
             unsafeAtomicAdd(hv + 2 * OT_TILE_PX, zo * wm);
             unsafeAtomicAdd(hv + 3 * OT_TILE_PX, 1.0 * wm);
         }
+    };
+    TileRec ra[DEPTH], rb[DEPTH];
+    bool oa[DEPTH], ob[DEPTH];
+    load(g, ra, oa);
+    for (int i0 = g; i0 < n_c; i0 += 2 * PER * DEPTH) {
+        load(i0 + PER * DEPTH, rb, ob);
+        add(ra, oa);
+        load(i0 + 2 * PER * DEPTH, ra, oa);
+        add(rb, ob);
     }
     __syncthreads();
     double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
@@ -561,4 +731,200 @@ __global__ __launch_bounds__(256) void fuse_reduce_kernel(FuseOne F, FuseIndex i
     hg[1] += s1;
     hg[2] += s2;
     hg[3] += s3;
+}
+
+// ---- automatic extent in one pass over the ray sections ---------------------------------------------------------
+// Raytracer.detector_image(extent=None) (raytracer.py:1042-1049): the image extent is the bounding box of the hits, so
+// the pixel a hit falls into is known only after the last hit.  The chain "hit list, then binning" writes every valid
+// hit (24 B) and reads the list three more times; an extent-only pass in front of the fused kernels reads the sections
+// twice.  Here the sections are read ONCE:
+//
+//   sample   extent E0 of the hits of every 128th wave of rays (~1 % of the bytes).  E0 lies inside the final extent E,
+//            so E's pixels are at least as large as those of E0's own image (up to the ratio snap of
+//            RenderImage._pixel_counts, which the host anticipates)
+//   tiles    fuse_tiles_kernel<SPECX>: hit -> tile of a PROVISIONAL grid (tiles of ~60 E0-pixels, laid over E0 plus a
+//            margin) -> 24-byte record (x, y, w, wl) appended to the tile's chunk list; the exact extent E of all hits
+//            is gathered on the way; hits outside the grid go to a short list of their own         reads 56, writes 24 B
+//   (host)   E -> RenderImage.__fix_extent, pixel counts, histogram
+//   accum    per tile: a provisional tile covers at most ~62 x 62 pixels of the final grid, so its records are binned
+//            with the exact rule (hit_pixel on the f64 position) into a 64 x 64 LDS window whose origin is the pixel
+//            of the tile's corner; windows of neighbouring tiles overlap, the reduction adds them with atomics.  A
+//            record outside its window (cannot happen while the host's check of the tile span holds) and the hits of
+//            the escape list are added straight to the image.                                      reads 24 B
+//
+// 104 B per ray instead of 136; same pixels and sums as the chain (the sums in another order).
+OT_DEV void spec_origin(const FuseOne& F, int t, int& ox, int& oy) {
+    const int tcx = t % F.g.tx, tcy = t / F.g.tx;
+    // one pixel of slack: membership in a tile was decided by floor((x - X0) / tw), its corner here is X0 + tcx * tw
+    ox = (int)floor(F.a.fx * (F.g.X0 + (double)tcx * F.g.tw - F.a.x0)) - 1;
+    oy = (int)floor(F.a.fy * (F.g.Y0 + (double)tcy * F.g.th - F.a.y0)) - 1;
+}
+
+// extent of the hits of a sample of the rays: wave k of the launch takes rays [64 k stride, 64 k stride + 64)
+__global__ __launch_bounds__(256) void spec_sample_kernel(ot_rays R, uint32_t count, const FuseOne* __restrict__ dets,
+                                                          uint32_t stride) {
+    const auto& F = as_const(dets)[0];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t q = (uint64_t)(t >> 6) * 64u * stride + (t & 63u);
+    const bool active = q < count;
+    const SectionPair sp = load_section_pair(R, (int64_t)(active ? q : 0u), active);
+    const V3 sdir = pair_direction(sp);
+    V3 ph;
+    float w;
+    bool valid, ill = false, to = false;
+    const bool settled = detector_hit_last(F, R.nt, active, sp, sdir, ph, w, valid);
+    if (__ballot(!settled) != 0ull) {
+        if (!settled) detector_hit<false, false>(R, (int64_t)(active ? q : 0u), active, F, sp, sdir, ph, w, valid, ill, to);
+    }
+    const double inf = __builtin_inf();
+    const double ext[4] = {valid ? ph.x : inf, valid ? ph.x : -inf, valid ? ph.y : inf, valid ? ph.y : -inf};
+    spec_extent_flush(F.g.ext_slots, ext);
+}
+
+// out[0..3] = extent of the slot tables (+-inf where no hit); with esc_n: out[4] = hits that asked for the escape list
+__global__ __launch_bounds__(64) void spec_result_kernel(const unsigned long long* __restrict__ slots,
+                                                         const unsigned int* __restrict__ esc_n, double* __restrict__ out) {
+    const int k = threadIdx.x;  // one slot table per lane (OT_EXT_SLOTS = 64), then a wave reduction
+    const double inf = __builtin_inf();
+    double e[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const unsigned long long u = slots[4 * k + c];
+        const bool untouched = u == ((c & 1) ? 0ull : ~0ull);
+        e[c] = untouched ? ((c & 1) ? -inf : inf) : ordered_to_f64(u);
+    }
+    e[0] = wave_min(e[0]), e[1] = wave_max(e[1]), e[2] = wave_min(e[2]), e[3] = wave_max(e[3]);
+    if (k < 4) out[k] = e[k];
+    if (k == 4 && esc_n) out[4] = (double)esc_n[0];
+}
+
+// fuse_accum_kernel for SpecRec chunks: LDS window of tile t = final pixels [ox, ox + 64) x [oy, oy + 64)
+__global__ __launch_bounds__(1024) void spec_accum_kernel(FuseOne F, FuseIndex ix, const double* __restrict__ table) {
+    extern __shared__ double lds[];  // [TILE_PX * 4 window] [471 * 3 observer table]; the window part first holds wstart
+    double* tile = lds;
+    double* obs = lds + OT_TILE_PX * 4;
+    unsigned int* ws = (unsigned int*)lds;
+    const int K = F.K;
+    const unsigned int b = blockIdx.x;
+    if (b >= ix.wstart[K]) return;  // (the grid is sized for the worst case: most workgroups leave here, before the table)
+    for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
+    __syncthreads();
+    int lo = 0, hi = K;  // ws[lo] <= b < ws[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ws[mid] <= b) lo = mid; else hi = mid;
+    }
+    const int t = lo;
+    const unsigned int part = b - ws[t];
+    __syncthreads();  // everyone has read ws: the window may be cleared
+    const unsigned int c0 = ix.tstart[t], n_t = ix.tstart[t + 1] - c0;
+    const unsigned int j_begin = part * OT_FUSE_CPW;
+    const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
+    for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
+    for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
+    __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
+    for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
+        const unsigned int c = ix.list[c0 + j_begin + i];
+        s_chunk[i] = c;
+        s_fill[i] = F.chunk_fill[c];
+    }
+    __syncthreads();
+    int ox, oy;
+    spec_origin(F, t, ox, oy);
+    const SpecRec* __restrict__ recs = (const SpecRec*)F.rec;
+    constexpr int PER = 1024 / OT_FUSE_CH;
+    constexpr int DEPTH = 4;  // two stages of DEPTH records in flight per thread, see fuse_accum_kernel
+    const int g = threadIdx.x / OT_FUSE_CH, slot = threadIdx.x % OT_FUSE_CH;
+    const int n_c = (int)(j_end - j_begin);
+    auto load = [&](int first, SpecRec* rec, bool* ok) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            const int i = first + k * PER, ic = i < n_c ? i : 0;
+            ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
+            rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];  // (no condition: every slot of a chunk exists; see load_section_pair_always)
+        }
+    };
+    auto add = [&](const SpecRec* rec, const bool* ok) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            if (!ok[k]) continue;
+            int32_t px, py;
+            const int pix = hit_pixel(F.a, rec[k].x, rec[k].y, px, py);
+            if (pix < 0) continue;
+            const double wm = (double)rec[k].w;
+            double xo, yo, zo;
+            observer_xyz_at(obs, (double)rec[k].wl, xo, yo, zo);
+            const int lx = px - ox, ly = py - oy;
+            if ((unsigned)lx < (unsigned)OT_TILE_W && (unsigned)ly < (unsigned)OT_TILE_W) {
+                double* hv = tile + ((ly << 6) | lx);  // plane-major window, see fuse_accum_kernel
+                unsafeAtomicAdd(hv + 0 * OT_TILE_PX, xo * wm);
+                unsafeAtomicAdd(hv + 1 * OT_TILE_PX, yo * wm);
+                unsafeAtomicAdd(hv + 2 * OT_TILE_PX, zo * wm);
+                unsafeAtomicAdd(hv + 3 * OT_TILE_PX, 1.0 * wm);
+            } else {
+                double* hg = F.hist + (int64_t)pix * 4;
+                unsafeAtomicAdd(hg + 0, xo * wm);
+                unsafeAtomicAdd(hg + 1, yo * wm);
+                unsafeAtomicAdd(hg + 2, zo * wm);
+                unsafeAtomicAdd(hg + 3, 1.0 * wm);
+            }
+        }
+    };
+    SpecRec ra[DEPTH], rb[DEPTH];
+    bool oa[DEPTH], ob[DEPTH];
+    load(g, ra, oa);
+    for (int i0 = g; i0 < n_c; i0 += 2 * PER * DEPTH) {
+        load(i0 + PER * DEPTH, rb, ob);
+        add(ra, oa);
+        load(i0 + 2 * PER * DEPTH, ra, oa);
+        add(rb, ob);
+    }
+    __syncthreads();
+    double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
+    for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) slab[i] = tile[i];
+}
+
+// grid (16, K): thread = one pixel of the window of tile blockIdx.y, all four planes; windows overlap -> atomics
+__global__ __launch_bounds__(256) void spec_reduce_kernel(FuseOne F, FuseIndex ix) {
+    const int tl = blockIdx.y;
+    const unsigned int s_first = ix.wstart[tl], s_end = ix.wstart[tl + 1];
+    if (s_end == s_first) return;
+    const int local = blockIdx.x * blockDim.x + threadIdx.x;
+    int ox, oy;
+    spec_origin(F, tl, ox, oy);
+    const int px = ox + (local & (OT_TILE_W - 1)), py = oy + (local >> 6);
+    if (px < 0 || py < 0 || px >= F.a.Nx || py >= F.a.Ny) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (unsigned int s = s_first; s < s_end; s++) {
+        const double* sl = ix.slabs + (size_t)s * (OT_TILE_PX * 4) + local;
+        s0 += sl[0 * OT_TILE_PX];
+        s1 += sl[1 * OT_TILE_PX];
+        s2 += sl[2 * OT_TILE_PX];
+        s3 += sl[3 * OT_TILE_PX];
+    }
+    if (s3 == 0.0) return;  // (weights are positive: no hit in this pixel)
+    double* hg = F.hist + ((int64_t)py * F.a.Nx + px) * 4;
+    unsafeAtomicAdd(hg + 0, s0);
+    unsafeAtomicAdd(hg + 1, s1);
+    unsafeAtomicAdd(hg + 2, s2);
+    unsafeAtomicAdd(hg + 3, s3);
+}
+
+// the escape list: a few hits far outside the sample's extent, straight into the image
+__global__ __launch_bounds__(256) void spec_escaped_kernel(FuseOne F, const double* __restrict__ table) {
+    const unsigned int n = min(F.g.esc_n[0], F.g.esc_cap);
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const SpecRec r = F.g.esc[i];
+        int32_t px, py;
+        const int pix = hit_pixel(F.a, r.x, r.y, px, py);
+        if (pix < 0) continue;
+        double xo, yo, zo;
+        observer_xyz_at(table, (double)r.wl, xo, yo, zo);
+        const double wm = (double)r.w;
+        double* hg = F.hist + (int64_t)pix * 4;
+        unsafeAtomicAdd(hg + 0, xo * wm);
+        unsafeAtomicAdd(hg + 1, yo * wm);
+        unsafeAtomicAdd(hg + 2, zo * wm);
+        unsafeAtomicAdd(hg + 3, 1.0 * wm);
+    }
 }

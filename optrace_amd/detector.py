@@ -115,6 +115,69 @@ def detector_extents(rays, first: int, count: int, requests: list) -> list:
     return [(ext_h[k].copy(), int(ill_h[2 * k])) for k in range(n)]
 
 
+def auto_image_supported(surf_desc: _capi.Surface, projection: int) -> bool:
+    """Detectors `AutoImage` serves: closed-form hit (flat, conic / spherical), no sphere projection with transcendentals."""
+    closed = surf_desc.kind <= _capi.SURF_CONIC or surf_desc.z_min == surf_desc.z_max
+    return closed and projection in (_capi.PROJECTIONS[None], _capi.PROJECTIONS["Orthographic"])
+
+
+def detector_extent_sample(rays, first: int, count: int, surf_desc: _capi.Surface, projection: int,
+                           stride: int) -> np.ndarray:
+    """Extent [x0, x1, y0, y1] (+-inf without a hit) of the hits of every `stride`-th wave of 64 rays
+    (`ot_detector_extent_sample`): a box inside the automatic extent of raytracer.py:1042-1046, for ~1 / stride of the
+    bytes."""
+    lib = _capi.load_library()
+    require_device()
+    mb_t, mb = mailbox()
+    rs = rays._rays_struct()
+    _capi.check(lib.ot_detector_extent_sample(C.byref(rs), int(first), int(count), C.byref(surf_desc), int(projection),
+                                              int(stride), C.c_void_p(mb_t.data_ptr()), stream_ptr()))
+    return mb.view(np.float64)[:4].copy()  # (the call waits for the stream)
+
+
+class AutoImage:
+    """Detector image with an automatic extent in one pass over the ray sections (`ot_detector_image_auto_*`): the hits
+    are sorted into the tiles of a provisional grid, the exact extent comes back, `finish` bins into the final grid.
+
+    grid: (X0, Y0, tile_w, tile_h, tiles_x, tiles_y).  After construction: extent (numpy, +-inf without a hit),
+    escaped (hits outside the grid) and escape_capacity; `finish` or `cancel` must follow."""
+
+    def __init__(self, rays, first: int, count: int, surf_desc: _capi.Surface, projection: int, grid: tuple) -> None:
+        self._lib = _capi.load_library()
+        require_device()
+        mb_t, mb = mailbox()
+        rs = rays._rays_struct()
+        origin = (C.c_double * 2)(float(grid[0]), float(grid[1]))
+        tile = (C.c_double * 2)(float(grid[2]), float(grid[3]))
+        tiles = (C.c_int32 * 2)(int(grid[4]), int(grid[5]))
+        self._handle = C.c_void_p()
+        _capi.check(self._lib.ot_detector_image_auto_begin(C.byref(rs), int(first), int(count), C.byref(surf_desc),
+                                                           int(projection), origin, tile, tiles,
+                                                           C.c_void_p(mb_t.data_ptr()), C.byref(self._handle),
+                                                           stream_ptr()))
+        res = mb.view(np.float64)[:6].copy()  # (the call waits for the stream)
+        self.extent = res[:4]
+        self.escaped = int(res[4])
+        self.escape_capacity = int(res[5])
+
+    def finish(self, extent, Nx: int, Ny: int, hist: torch.Tensor) -> None:
+        """Add the image to hist (flat f64 device tensor of Ny * Nx * 4 entries); extent = the fixed image extent."""
+        h, self._handle = self._handle, C.c_void_p()
+        ext = (C.c_double * 4)(*[float(v) for v in extent])
+        _capi.check(self._lib.ot_detector_image_auto_finish(h, ext, int(Nx), int(Ny), ptr(hist), stream_ptr()))
+
+    def cancel(self) -> None:
+        if self._handle:
+            self._lib.ot_detector_image_auto_cancel(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.cancel()
+        except Exception:
+            pass
+
+
 def detector_images(rays, first: int, count: int, requests: list) -> list:
     """Hit search and binning fused (`ot_detector_images`) for detector images whose extent is known beforehand.
 

@@ -50,6 +50,13 @@ class Raytracer(Group):
     COMPACT_HITS_FROM: int = 1 << 21
     """`detector_image` with an automatic extent: from this many rays on the hit list between hit search and binning
     holds the valid hits only (`ot_detector_req.fill`)."""
+    AUTO_ONE_PASS_FROM: int = 1 << 25
+    """... and from this many rays on, where the detector allows it, the sections are read once and the hits sorted on a
+    provisional tile grid laid over the extent of a sample: every AUTO_SAMPLE_STRIDE-th wave of 64 rays
+    (`_auto_image_one_pass`)."""
+    AUTO_SAMPLE_STRIDE: int = 128
+    AUTO_MARGINS: tuple = ((0.5, 1024), (0.3, 1024), (0.15, 1024), (0.3, 2048), (0.15, 2048), (0.05, 2048))
+    """(margin around the sample's extent as a fraction of its sides, most tiles) in order of preference."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
     """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are
     19 M rays of a 15-surface scene with polarisation or 93 M rays of a two-surface scene without."""
@@ -586,11 +593,76 @@ class Raytracer(Group):
         # 3.0 against 1.9 ms -- or the image is point-like, C2 1.3 against 0.9 ms: the sections are read twice either
         # way.  The extent-only pass serves where hit lists would have to be kept or exchanged: the first chunk of
         # `iterative_render` and the sharded forms in distributed.py.)
-        kwargs.pop("_unfused", None)
+        unfused = kwargs.pop("_unfused", False)
+        # Long bundles, detectors with a closed-form hit: the sections are read once, the hits are sorted on a provisional
+        # tile grid while their extent is found (`_auto_image_one_pass`; None: not applicable, the chain below runs)
+        if not unfused and self.rays.N >= self.AUTO_ONE_PASS_FROM:
+            img = self._auto_image_one_pass(spec, limit, **kwargs)
+            if img is not None:
+                return img
         # (long bundles: the hit list holds the valid hits only, gathered piece-wise -- a third of the bytes for C4)
         spec["compact"] = extent is None and self.rays.N >= self.COMPACT_HITS_FROM
         hits = self._hit_detectors("Detector Image", [spec])[0]
         return self._image_from_hits(hits, detector_index, source_index, limit, **kwargs)
+
+    def _auto_image_one_pass(self, spec: dict, limit, **kwargs):
+        """Image with an automatic extent (raytracer.py:1042-1049, 1053-1098) in one pass over the ray sections
+        (`detector.AutoImage`, csrc/ot_detector_fused.hpp last section).  The extent E0 of the hits of a sample of the
+        rays lies inside the final extent E, so the pixels of E's image are at least as large as those of E0's own
+        image; tiles of 60 such pixels therefore fit 64 x 64 windows of the final grid.  -> RenderImage, or None where
+        this form does not apply (detector with a numeric hit search or a sphere projection, no hit in the sample,
+        point- / line-like or very elongated sample extent, too many hits outside the provisional grid): the caller
+        takes the hit-list chain."""
+        rq = self._detector_requests([spec])[0]
+        Ns, count = rq["Ns"], rq["Ne"] - rq["Ns"]
+        sd, proj = rq["surf_desc"], _capi.PROJECTIONS[rq["projection"]]
+        if count < 1 or not _detector.auto_image_supported(sd, proj):
+            return None
+        e0 = _detector.detector_extent_sample(self.rays, Ns, count, sd, proj, self.AUTO_SAMPLE_STRIDE)
+        if not np.all(np.isfinite(e0)):
+            return None
+        sx0, sy0 = e0[1] - e0[0], e0[3] - e0[2]
+        MR, side = RenderImage.MAX_IMAGE_RATIO, RenderImage.MAX_IMAGE_SIDE
+        if min(sx0, sy0) <= 0 or max(sx0, sy0) / min(sx0, sy0) > MR / 1.2:
+            return None
+        probe = RenderImage(extent=e0.copy(), projection=rq["projection"])
+        probe._limit = limit
+        probe._fix_extent()
+        sx, sy = probe.s
+        n_long = side * min(MR, 1 + 2 * int(1.2 * max(sx, sy) / min(sx, sy) / 2))  # (a ratio 20 % larger may snap up)
+        Nx0, Ny0 = (n_long, side) if sx > sy else (side, n_long)
+        tw, th = 60 * sx / Nx0, 60 * sy / Ny0  # 60 pixels of the sample's image (lower bounds of the final pixels)
+        grid = None
+        for margin, most in self.AUTO_MARGINS:
+            tx = int(np.ceil((1 + 2 * margin) * sx0 / tw)) + 1
+            ty = int(np.ceil((1 + 2 * margin) * sy0 / th)) + 1
+            if tx * ty <= most:  # (1024: the tile kernel's faster form, two rays per thread)
+                grid = (e0[0] - margin * sx0, e0[2] - margin * sy0, tw, th, tx, ty)
+                break
+        if grid is None:
+            return None
+
+        auto = _detector.AutoImage(self.rays, Ns, count, sd, proj, grid)
+        if auto.escaped > auto.escape_capacity or not np.all(np.isfinite(auto.extent)):
+            auto.cancel()
+            return None
+        label = rq["desc"]
+        if spec.get("source_index") is not None:
+            label = f"Rays from RS{spec['source_index']} at {label}"
+        img = RenderImage(extent=auto.extent.copy(), projection=rq["projection"], long_desc=label)
+        img._limit = limit
+        img._fix_extent()
+        Nx, Ny = img._pixel_counts()
+        if tw * Nx / img.s[0] > 61 or th * Ny / img.s[1] > 61:  # a tile would not fit its window (ratio snapped further)
+            auto.cancel()
+            return None
+        hist = torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=require_device())
+        auto.finish(img.extent, Nx, Ny, hist)
+        img._dev = hist.view(Ny, Nx, 4)
+        img._host = None
+        if limit is not None and not kwargs.get("_dont_filter", False):
+            img._apply_rayleigh_filter()
+        return img
 
     def detector_spectrum(self, detector_index: int = 0, source_index: int = None, extent=None,
                           **kwargs) -> LightSpectrum:
