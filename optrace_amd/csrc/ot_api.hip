@@ -1881,7 +1881,7 @@ extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, 
     LeafSurface ls;
     if (int rc = ls.init(detector, st)) return rc;
     const int cus = cu_count();
-    const bool small_k = K <= 1024 && !std::getenv("OT_AUTO_RPT1");  // two rays per thread and sub-block (10-bit tile numbers), as in ot_detector_images
+    const bool small_k = K <= 1024;  // two rays per thread and sub-block (10-bit tile numbers), as in ot_detector_images
     const int64_t brt = OT_FUSE_BR * (small_k ? 2 : 1);
     const unsigned n_wg = (unsigned)std::min<int64_t>(2 * (int64_t)cus, (count + brt - 1) / brt);
     const int64_t piece = ((count + n_wg - 1) / n_wg + brt - 1) / brt * brt;

@@ -403,29 +403,6 @@ OT_DEV SectionPair load_section_pair(const ot_rays& R, int64_t r, bool active) {
     return sp;
 }
 
-// The same without a condition around the loads, for software-pipelined loops (r must be a valid ray): a load inside a
-// branch leaves the compiler without a count of the memory operations in flight, and its wait for OLDER loads becomes a
-// wait for everything (s_waitcnt vmcnt(0)), the prefetch included.
-OT_DEV SectionPair load_section_pair_always(const ot_rays& R, int64_t r) {
-    SectionPair sp;
-    const int64_t N = R.N;
-    const int nt = R.nt;
-    const double* __restrict__ zp = R.p + r + N * (2 * (int64_t)nt);
-    const double* __restrict__ xp = R.p + r;
-    const double* __restrict__ yp = R.p + r + N * (int64_t)nt;
-    const int kq = nt >= 2 ? nt - 2 : 0;
-    sp.zl = OT_STREAM_LOAD(&zp[N * (int64_t)(nt - 1)]), sp.zq = OT_STREAM_LOAD(&zp[N * (int64_t)kq]);
-    sp.xl = OT_STREAM_LOAD(&xp[N * (int64_t)(nt - 1)]), sp.xq = OT_STREAM_LOAD(&xp[N * (int64_t)kq]);
-    sp.yl = OT_STREAM_LOAD(&yp[N * (int64_t)(nt - 1)]), sp.yq = OT_STREAM_LOAD(&yp[N * (int64_t)kq]);
-    sp.wq = OT_STREAM_LOAD(&R.w[r + N * (int64_t)kq]);
-    return sp;
-}
-
-// "these values are needed here": the compiler places its wait for their loads at this point
-OT_DEV void arrive(SectionPair& sp, float& wl) {
-    asm volatile("" : "+v"(sp.zl), "+v"(sp.zq), "+v"(sp.xl), "+v"(sp.xq), "+v"(sp.yl), "+v"(sp.yq), "+v"(sp.wq), "+v"(wl));
-}
-
 // one detector, its record in the kernel arguments (scalar registers)
 template <bool NUMERIC>
 __global__ __launch_bounds__(256) void detector_kernel(ot_rays R, int64_t first, int64_t count, DetOne D) {

@@ -325,10 +325,10 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
     __syncthreads();
     const uint32_t i0 = blockIdx.x * piece;
     const uint32_t i1 = (i0 + piece < count) ? i0 + piece : count;
-    // Software pipeline: the sections of sub-block i + 1 are requested at the top of round i and awaited between its
-    // second barrier and its record stores (`arrive`), where they have had the round's arithmetic and both barriers to
-    // travel; at the top of the next round nothing is pending but those stores.  The loads carry no condition (lanes
-    // beyond the range read the last ray and are switched off by `act`): see load_section_pair_always.
+    // The sections of sub-block i + 1 are requested at the top of round i.  (Tried: loads without a condition around them,
+    // so that the compiler can count the operations in flight instead of waiting for all of them, and the wait for the
+    // prefetch moved behind the second barrier -- no measurable difference in an interleaved A/B: the kernel is bound by its
+    // scattered record stores, see below.)
     SectionPair sp_n[RPT];
     float wl_n[RPT];
     bool act_n[RPT];
@@ -337,9 +337,8 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
         for (int j = 0; j < RPT; j++) {
             const uint32_t q = base + j * OT_FUSE_BR + threadIdx.x;
             act_n[j] = q < i1;  // (count < 2^31: no wrap)
-            const uint32_t qc = act_n[j] ? q : count - 1u;
-            sp_n[j] = load_section_pair_always(R, (int64_t)qc);
-            wl_n[j] = OT_STREAM_LOAD(&R.wl[qc]);
+            sp_n[j] = load_section_pair(R, (int64_t)(act_n[j] ? q : 0u), act_n[j]);
+            wl_n[j] = act_n[j] ? OT_STREAM_LOAD(&R.wl[q]) : 0.f;
         }
     };
     request(i0);
@@ -449,10 +448,6 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
             }
         }
         fuse_lds_barrier();
-        if constexpr (!SORT) {
-#pragma unroll
-            for (int j = 0; j < RPT; j++) arrive(sp_n[j], wl_n[j]);
-        }
         // phase 3: one 12-byte store per hit.  (The next phase 2 changes fill / cur / nb only behind the next barrier,
         // which every wave reaches after these reads.)  SORT: into the staging slots first.
 #pragma unroll
@@ -499,8 +494,6 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
         if constexpr (SORT) {
             // phase 4: the staged records in slot order -- lanes next to each other write records next to each other
             fuse_lds_barrier();
-#pragma unroll
-            for (int j = 0; j < RPT; j++) arrive(sp_n[j], wl_n[j]);
             const auto& F = as_const(dl)[0];
             const unsigned int n_rec = stop[par];
             for (unsigned int t = threadIdx.x; t < n_rec; t += OT_FUSE_BR) {
@@ -675,7 +668,7 @@ __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex i
         for (int k = 0; k < DEPTH; k++) {
             const int i = first + k * PER, ic = i < n_c ? i : 0;
             ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
-            rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];  // (no condition: every slot of a chunk exists; see load_section_pair_always)
+            if (ok[k]) rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];
         }
     };
     auto add = [&](const TileRec* rec, const bool* ok) {
@@ -841,7 +834,7 @@ __global__ __launch_bounds__(1024) void spec_accum_kernel(FuseOne F, FuseIndex i
         for (int k = 0; k < DEPTH; k++) {
             const int i = first + k * PER, ic = i < n_c ? i : 0;
             ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
-            rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];  // (no condition: every slot of a chunk exists; see load_section_pair_always)
+            if (ok[k]) rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];
         }
     };
     auto add = [&](const SpecRec* rec, const bool* ok) {
