@@ -605,6 +605,32 @@ class Raytracer(Group):
         hits = self._hit_detectors("Detector Image", [spec])[0]
         return self._image_from_hits(hits, detector_index, source_index, limit, **kwargs)
 
+    @staticmethod
+    def _auto_grid(e0, limit, projection, margins):
+        """Provisional tile grid for an image whose final extent E contains the sample extent e0 (`_auto_image_one_pass`).
+        Tiles are 60 x 60 pixels of e0's OWN image (after `RenderImage._fix_extent` with `limit`); E's image has pixels at
+        least that large, because its sides are at least e0's and its pixel counts at most those assumed here (the long
+        side's count is taken for a side ratio 20 % beyond e0's, `RenderImage._pixel_counts` snaps at 2 and 4).
+        -> ((X0, Y0, tile_w, tile_h, tiles_x, tiles_y), tile_w, tile_h), or None for point- / line-like and very
+        elongated sample extents and where no margin of `margins` ((fraction of e0's sides, most tiles), ...) fits."""
+        sx0, sy0 = e0[1] - e0[0], e0[3] - e0[2]
+        MR, side = RenderImage.MAX_IMAGE_RATIO, RenderImage.MAX_IMAGE_SIDE
+        if min(sx0, sy0) <= 0 or max(sx0, sy0) / min(sx0, sy0) > MR / 1.2:
+            return None
+        probe = RenderImage(extent=np.array(e0, dtype=np.float64), projection=projection)
+        probe._limit = limit
+        probe._fix_extent()
+        sx, sy = probe.s
+        n_long = side * min(MR, 1 + 2 * int(1.2 * max(sx, sy) / min(sx, sy) / 2))
+        Nx0, Ny0 = (n_long, side) if sx > sy else (side, n_long)
+        tw, th = 60 * sx / Nx0, 60 * sy / Ny0
+        for margin, most in margins:
+            tx = int(np.ceil((1 + 2 * margin) * sx0 / tw)) + 1
+            ty = int(np.ceil((1 + 2 * margin) * sy0 / th)) + 1
+            if tx * ty <= most:  # (up to 1024 tiles: the tile kernel's faster form, two rays per thread)
+                return (e0[0] - margin * sx0, e0[2] - margin * sy0, tw, th, tx, ty), tw, th
+        return None
+
     def _auto_image_one_pass(self, spec: dict, limit, **kwargs):
         """Image with an automatic extent (raytracer.py:1042-1049, 1053-1098) in one pass over the ray sections
         (`detector.AutoImage`, csrc/ot_detector_fused.hpp last section).  The extent E0 of the hits of a sample of the
@@ -621,26 +647,10 @@ class Raytracer(Group):
         e0 = _detector.detector_extent_sample(self.rays, Ns, count, sd, proj, self.AUTO_SAMPLE_STRIDE)
         if not np.all(np.isfinite(e0)):
             return None
-        sx0, sy0 = e0[1] - e0[0], e0[3] - e0[2]
-        MR, side = RenderImage.MAX_IMAGE_RATIO, RenderImage.MAX_IMAGE_SIDE
-        if min(sx0, sy0) <= 0 or max(sx0, sy0) / min(sx0, sy0) > MR / 1.2:
+        plan = self._auto_grid(e0, limit, rq["projection"], self.AUTO_MARGINS)
+        if plan is None:
             return None
-        probe = RenderImage(extent=e0.copy(), projection=rq["projection"])
-        probe._limit = limit
-        probe._fix_extent()
-        sx, sy = probe.s
-        n_long = side * min(MR, 1 + 2 * int(1.2 * max(sx, sy) / min(sx, sy) / 2))  # (a ratio 20 % larger may snap up)
-        Nx0, Ny0 = (n_long, side) if sx > sy else (side, n_long)
-        tw, th = 60 * sx / Nx0, 60 * sy / Ny0  # 60 pixels of the sample's image (lower bounds of the final pixels)
-        grid = None
-        for margin, most in self.AUTO_MARGINS:
-            tx = int(np.ceil((1 + 2 * margin) * sx0 / tw)) + 1
-            ty = int(np.ceil((1 + 2 * margin) * sy0 / th)) + 1
-            if tx * ty <= most:  # (1024: the tile kernel's faster form, two rays per thread)
-                grid = (e0[0] - margin * sx0, e0[2] - margin * sy0, tw, th, tx, ty)
-                break
-        if grid is None:
-            return None
+        grid, tw, th = plan
 
         auto = _detector.AutoImage(self.rays, Ns, count, sd, proj, grid)
         if auto.escaped > auto.escape_capacity or not np.all(np.isfinite(auto.extent)):
