@@ -18,7 +18,7 @@ sys.argv = [sys.argv[0], "NONE"]
 import bench_configs as bc
 
 
-def timeit(f, n=5):
+def timeit(f, n=int(os.environ.get("AB_N", "5"))):
     f()
     torch.cuda.synchronize()
     ts = []
