@@ -464,7 +464,8 @@ int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const 
  *   ot_detector_image_auto_begin   hit search, records (x, y, w, wl: 24 B per valid hit) by tile, result6 = the exact
  *                                  extent of all valid hits (as ot_detector_req.extent4 reports it), result6[4] = hits
  *                                  outside the grid (kept in a list of result6[5] entries: more than that -> cancel and
- *                                  take the other path).
+ *                                  take the other path).  OT_ERR_UNSUPPORTED also where the records (24 B per ray,
+ *                                  worst case) do not fit the device: the hit-list path needs less.
  *   ot_detector_image_auto_finish  extent = the image extent after RenderImage.__fix_extent, Nx, Ny its pixel counts,
  *                                  hist (Ny, Nx, 4) f64 device, ADDED to.  Same pixels and sums as ot_detector_hits_multi +
  *                                  ot_render_accumulate (sums in another order).  Frees the handle, also on failure.

@@ -172,6 +172,7 @@ SIGNATURES = {
 FOCUS_WS = 16  # OT_FOCUS_WS
 HIT_PIECES = 1024  # OT_HIT_PIECES
 ABI_VERSION = 6  # OT_ABI_VERSION
+ERR_UNSUPPORTED = -3  # OT_ERR_UNSUPPORTED
 
 _lib = None
 
@@ -210,4 +211,6 @@ def load_library() -> C.CDLL:
 def check(status: int) -> None:
     if status != 0:
         msg = load_library().ot_last_error()
-        raise BackendError(f"optrace_amd backend error {status}: {msg.decode() if msg else '?'}")
+        err = BackendError(f"optrace_amd backend error {status}: {msg.decode() if msg else '?'}")
+        err.status = status  # OT_ERR_*
+        raise err

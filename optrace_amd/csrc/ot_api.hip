@@ -1923,7 +1923,7 @@ extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, 
     im->n_slabs = (unsigned)((f.cap + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)f.K;
     im->o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)im->n_slabs);
     char* ws = workspace(OT_WS_AUTO, off, st);
-    if (!ws) return fail(OT_ERR_HIP, "ot_detector_image_auto_begin: no scratch memory");
+    if (!ws) return fail(OT_ERR_UNSUPPORTED, "ot_detector_image_auto_begin: no memory for the records (take the hit-list path)");
     im->ws = ws;
     im->st = st;
     (void)hipGetDevice(&im->dev);

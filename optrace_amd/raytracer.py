@@ -652,7 +652,12 @@ class Raytracer(Group):
             return None
         grid, tw, th = plan
 
-        auto = _detector.AutoImage(self.rays, Ns, count, sd, proj, grid)
+        try:
+            auto = _detector.AutoImage(self.rays, Ns, count, sd, proj, grid)
+        except _capi.BackendError as err:
+            if getattr(err, "status", 0) == _capi.ERR_UNSUPPORTED:  # e.g. no room for the records: the chain needs less
+                return None
+            raise
         if auto.escaped > auto.escape_capacity or not np.all(np.isfinite(auto.extent)):
             auto.cancel()
             return None
