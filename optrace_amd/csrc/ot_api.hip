@@ -1545,6 +1545,12 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
 // ---- detector image in one pass (ot_detector_fused.hpp) ------------------------------------------------------
 static int cu_count();
 
+// one detector, an image of few tiles: the tile kernel with line buffers (OT_TILE_LINEBUF=0 in the environment: the plain one)
+static bool fuse_use_linebuf(int K) {
+    const char* v = std::getenv("OT_TILE_LINEBUF");
+    return K <= OT_LB_MAXK && !(v && v[0] == '0');
+}
+
 // the one-detector tile kernels stage their records in LDS: with many tiles more than the 64 KB a kernel gets unasked
 static int fuse_tiles_allow_lds(int dev) {
     static thread_local bool done[64] = {false};
@@ -1554,6 +1560,9 @@ static int fuse_tiles_allow_lds(int dev) {
     HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_kernel<false, 1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
     HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_kernel<false, 1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
     HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_kernel<false, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+    const int lb = (int)fuse_lb_lds(OT_LB_MAXK);
+    HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_lb_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    HIP_TRY(hipFuncSetAttribute((const void*)fuse_tiles_lb_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     done[dev] = true;
     return OT_OK;
 }
@@ -1631,8 +1640,11 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     bool small_k = n_reqs == 1;
     for (int k = 0; k < n_reqs; k++)
         small_k = small_k && ((reqs[k].Nx + OT_TILE_W - 1) / OT_TILE_W) * ((reqs[k].Ny + OT_TILE_W - 1) / OT_TILE_W) <= 1024;
-    const int64_t brt = OT_FUSE_BR * (small_k ? 2 : 1);
-    const unsigned n_wg = (unsigned)std::min<int64_t>(2 * (int64_t)cus, (count + brt - 1) / brt);
+    // one detector with a closed-form hit and an image of few tiles: the kernel with line buffers, one 1024-thread workgroup per CU
+    // (every request that reaches this point has a closed-form hit and no sphere projection)
+    const bool linebuf = n_reqs == 1 && fuse_use_linebuf(((reqs[0].Nx + OT_TILE_W - 1) / OT_TILE_W) * ((reqs[0].Ny + OT_TILE_W - 1) / OT_TILE_W));
+    const int64_t brt = linebuf ? OT_LB_BR * OT_LB_RPT : OT_FUSE_BR * (small_k ? 2 : 1);
+    const unsigned n_wg = (unsigned)std::min<int64_t>((linebuf ? 1 : 2) * (int64_t)cus, (count + brt - 1) / brt);
     const int64_t piece = ((count + n_wg - 1) / n_wg + brt - 1) / brt * brt;
 
     std::vector<FuseOne> host(n_reqs);
@@ -1752,6 +1764,11 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     } while (0)
         if (general) {
             OT_LAUNCH_FUSE(true, 8, 1);
+        } else if (linebuf) {
+            hipLaunchKernelGGL((fuse_direct_kernel<false, 1>), dim3(blocks), dim3(1024), 0, st, *rays, first, count, dd, n_reqs, table);
+            if (KT)
+                hipLaunchKernelGGL(fuse_tiles_lb_kernel<false>, dim3(n_wg), dim3(OT_LB_BR), fuse_lb_lds(KT), st, part, (uint32_t)count,
+                                   dd, KT, (uint32_t)piece);
         } else if (n_reqs == 1) {
             if (small_k) OT_LAUNCH_FUSE(false, 1, 2); else OT_LAUNCH_FUSE(false, 1, 1);
         } else if (n_reqs <= 2) {
@@ -1882,8 +1899,9 @@ extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, 
     if (int rc = ls.init(detector, st)) return rc;
     const int cus = cu_count();
     const bool small_k = K <= 1024;  // two rays per thread and sub-block (10-bit tile numbers), as in ot_detector_images
-    const int64_t brt = OT_FUSE_BR * (small_k ? 2 : 1);
-    const unsigned n_wg = (unsigned)std::min<int64_t>(2 * (int64_t)cus, (count + brt - 1) / brt);
+    const bool linebuf = fuse_use_linebuf((int)K);  // few tiles: line buffers, one 1024-thread workgroup per CU
+    const int64_t brt = linebuf ? OT_LB_BR * OT_LB_RPT : OT_FUSE_BR * (small_k ? 2 : 1);
+    const unsigned n_wg = (unsigned)std::min<int64_t>((linebuf ? 1 : 2) * (int64_t)cus, (count + brt - 1) / brt);
     const int64_t piece = ((count + n_wg - 1) / n_wg + brt - 1) / brt * brt;
 
     std::unique_ptr<ot_auto_image> im(new ot_auto_image);
@@ -1946,7 +1964,10 @@ extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, 
     part.wl += first;
     const FuseOne* dd = (const FuseOne*)(ws + h.o_dets);
     const size_t lds_tiles = fuse_tiles_lds(f.K, 1, small_k ? 2 : 1, true);
-    if (small_k)
+    if (linebuf)
+        hipLaunchKernelGGL(fuse_tiles_lb_kernel<true>, dim3(n_wg), dim3(OT_LB_BR), fuse_lb_lds(f.K), st, part, (uint32_t)count, dd, f.K,
+                           (uint32_t)piece);
+    else if (small_k)
         hipLaunchKernelGGL((fuse_tiles_kernel<false, 1, 2, true>), dim3(n_wg), dim3(OT_FUSE_BR), lds_tiles, st, part, (uint32_t)count,
                            dd, 1, f.K, (uint32_t)piece);
     else

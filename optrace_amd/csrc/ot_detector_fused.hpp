@@ -16,6 +16,7 @@
 //
 // 80 B per ray and detector instead of 140, and 56 + 24 * n for n detector positions instead of 52 + 88 * n.
 #pragma once
+#include <type_traits>
 #include "ot_render_tiles.hpp"
 
 #define OT_FUSE_CH 256       // records per chunk (3 KB)
@@ -530,6 +531,252 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
         for (unsigned int c = min(next[d], end) + threadIdx.x; c < end; c += blockDim.x) F.chunk_tile[c] = OT_FUSE_NONE;
     }
     if constexpr (SPECX) spec_extent_flush(as_const(dets)[0].g.ext_slots, ext);
+}
+
+// ---- tile path, pass 1 with line buffers (one detector, images of up to OT_LB_MAXK tiles) ---------------------------
+// The record stores of fuse_tiles_kernel are half of its time (profiles/r3/tile_kernel_store_cost.txt): every store
+// instruction touches 64 cache lines with 12 or 24 bytes each, the partial lines leave the L2 before the next sub-block
+// adds to them, and the memory side pays for each visit.  Here a workgroup keeps, for every tile, the records of the
+// chunk segment that is being filled (384 B: 16 or 32 records) in LDS and writes a segment when it is complete: 384
+// contiguous bytes, three whole cache lines.  State per tile: fill / cur / nb as in fuse_tiles_kernel, and lo = the
+// position in the open chunk from which records stand in LDS (positions below are in memory).  Per sub-block and tile with
+// c new records at positions [fill, fill + c), seg_end = the end of the segment that holds position fill:
+//   * positions below seg_end go to the LDS segment (slot = position mod segment length);
+//   * if fill + c reaches seg_end the segment [lo, seg_end) is written out -- a "job", carried out by the threads that have
+//     no tile to look after during phase 2 of the NEXT sub-block, so the round keeps its two barriers --; records beyond
+//     seg_end bypass the buffer (straight to memory, as in fuse_tiles_kernel) and the buffer is empty afterwards (lo =
+//     the new fill): a tile that receives more than a segment per sub-block (point-like images) simply streams.
+// One 1024-thread workgroup per CU (the buffers of 361 tiles are 139 KB), two rays per thread and sub-block.
+#define OT_LB_BR 1024
+#define OT_LB_RPT 2
+#define OT_LB_MAXK 361
+#define OT_LB_SEG_BYTES 384
+
+__host__ __device__ static inline size_t fuse_lb_buf_offset(int K) { return (sizeof(unsigned int) * (10 * (size_t)K + 8) + 15) / 16 * 16; }
+__host__ __device__ static inline size_t fuse_lb_lds(int K) { return fuse_lb_buf_offset(K) + (size_t)K * OT_LB_SEG_BYTES; }
+
+template <bool SPECX>
+__global__ __launch_bounds__(OT_LB_BR) void fuse_tiles_lb_kernel(ot_rays R, uint32_t count, const FuseOne* __restrict__ dets,
+                                                                 int K, uint32_t piece) {
+    using REC = typename std::conditional<SPECX, SpecRec, TileRec>::type;
+    constexpr unsigned int SEG = OT_LB_SEG_BYTES / sizeof(REC);  // records per segment: 16 (24 B) or 32 (12 B)
+    constexpr int RPT = OT_LB_RPT;
+    constexpr uint32_t BRT = OT_LB_BR * RPT;
+    static_assert(OT_FUSE_CH % SEG == 0, "segments must not straddle chunks");
+    const auto& F = as_const(dets)[0];
+    if (!F.spread[0]) return;
+    extern __shared__ unsigned int fl[];
+    unsigned int* cnt = fl;  // [2][K]
+    unsigned int* fill = fl + 2 * K;
+    unsigned int* cur = fl + 3 * K;
+    unsigned int* nb = fl + 4 * K;
+    unsigned int* lo = fl + 5 * K;
+    unsigned int* job = fl + 6 * K;    // [2][K] by sub-block parity: tile | first slot << 11 | records << 22
+    unsigned int* jdst = fl + 8 * K;   // [2][K] record number of the job's first record
+    unsigned int* next = fl + 10 * K;  // [1] next free chunk of this workgroup's part of the pool
+    unsigned int* jn = next + 1;       // [2] jobs of a sub-block (by parity)
+    REC* buf = (REC*)((char*)fl + fuse_lb_buf_offset(K));  // [K][SEG]
+    if (threadIdx.x == 0) {
+        next[0] = blockIdx.x * F.per_wg;
+        jn[0] = jn[1] = 0u;
+    }
+    for (int e = threadIdx.x; e < K; e += blockDim.x) {
+        cnt[e] = 0u;
+        cnt[K + e] = 0u;
+        fill[e] = OT_FUSE_CH;  // "full": the first record of a tile takes a chunk
+        cur[e] = OT_FUSE_NONE;
+        nb[e] = 0u;
+        lo[e] = OT_FUSE_CH;    // nothing in the buffer
+    }
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * piece;
+    const uint32_t i1 = (i0 + piece < count) ? i0 + piece : count;
+    // position p of a tile's record stream (relative to its open chunk; >= CH: in the chunks taken this round) -> record number
+    auto place = [&](int e, unsigned int p) -> unsigned int {
+        unsigned int chunk;
+        if (p < OT_FUSE_CH) {
+            chunk = cur[e];
+        } else {
+            p -= OT_FUSE_CH;
+            chunk = nb[e] + p / OT_FUSE_CH;
+            p %= OT_FUSE_CH;
+        }
+        return chunk < F.cap ? chunk * OT_FUSE_CH + p : OT_FUSE_NONE;  // (pool < 2^32 records: host)
+    };
+    // the previous sub-block's c records join the open chunk: fill / cur move on, and lo with them
+    auto advance = [&](int e, unsigned int c) {
+        const unsigned int f_old = fill[e];
+        const bool completed = f_old + c >= (f_old / SEG + 1) * SEG;  // its segment was written out, the rest bypassed the buffer
+        fuse_advance(fill, cur, nb, e, c);
+        const unsigned int l = lo[e];
+        lo[e] = completed ? fill[e] : (l >= OT_FUSE_CH ? l - OT_FUSE_CH : l);
+    };
+    // the jobs of one sub-block: SEG lanes per job, neighbouring lanes write neighbouring records -- whole cache lines
+    auto run_jobs = [&](int parity, unsigned int first_thread) {
+        if (threadIdx.x < first_thread) return;
+        const unsigned int n_jobs = jn[parity];
+        const unsigned int t = threadIdx.x - first_thread, groups = (OT_LB_BR - first_thread) / SEG;
+        const unsigned int g = t / SEG, r = t % SEG;
+        if (g >= groups) return;
+        for (unsigned int j = g; j < n_jobs; j += groups) {
+            const unsigned int jb = job[parity * K + j], dst = jdst[parity * K + j];
+            const unsigned int e = jb & 0x7ffu, slot = (jb >> 11) & 0x7ffu, n = jb >> 22;
+            if (r < n && dst != OT_FUSE_NONE) ((REC*)F.rec)[dst + r] = buf[(size_t)e * SEG + slot + r];
+        }
+    };
+    SectionPair sp_n[RPT];
+    float wl_n[RPT];
+    bool act_n[RPT];
+    auto request = [&](uint32_t base) {
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            const uint32_t q = base + j * OT_LB_BR + threadIdx.x;
+            act_n[j] = q < i1;
+            sp_n[j] = load_section_pair(R, (int64_t)(act_n[j] ? q : 0u), act_n[j]);
+            wl_n[j] = act_n[j] ? OT_STREAM_LOAD(&R.wl[q]) : 0.f;
+        }
+    };
+    request(i0);
+    const double inf = __builtin_inf();
+    double ext[4] = {inf, -inf, inf, -inf};
+    const unsigned int k_threads = ((unsigned int)K + 63u) & ~63u;  // phase 2 occupies the first waves, the jobs the others
+    int par = 0;
+    for (uint32_t s = i0; s < i1; s += BRT, par ^= 1) {
+        SectionPair sp[RPT];
+        float wl[RPT];
+        bool act[RPT];
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            sp[j] = sp_n[j];
+            wl[j] = wl_n[j];
+            act[j] = act_n[j];
+        }
+        request(s + BRT);
+        unsigned int* cnt_a = cnt + par * K;
+        unsigned int* cnt_b = cnt + (par ^ 1) * K;
+        // phase 1: hit, tile, rank inside the tile's share of this sub-block
+        float wk[RPT];
+        unsigned int tile[RPT], rank[RPT], local[RPT];
+        double hx[RPT], hy[RPT];
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            wk[j] = 0.f;
+            tile[j] = rank[j] = local[j] = 0u;
+            hx[j] = hy[j] = 0.0;
+            const uint32_t q = s + j * OT_LB_BR + threadIdx.x;
+            const int64_t r = (int64_t)(act[j] ? q : 0u);
+            const V3 sdir = pair_direction(sp[j]);
+            V3 ph;
+            float w;
+            bool valid = false, ill = false, to = false;
+            const bool settled = detector_hit_last(F, R.nt, act[j], sp[j], sdir, ph, w, valid);
+            if (__ballot(!settled) != 0ull) {
+                if (!settled) detector_hit<false, false>(R, r, act[j], F, sp[j], sdir, ph, w, valid, ill, to);
+            }
+            if (!valid) continue;
+            if constexpr (SPECX) {
+                ext[0] = fmin(ext[0], ph.x), ext[1] = fmax(ext[1], ph.x);
+                ext[2] = fmin(ext[2], ph.y), ext[3] = fmax(ext[3], ph.y);
+                const double u = (ph.x - F.g.X0) * F.g.itw, v = (ph.y - F.g.Y0) * F.g.ith;
+                if (!(u >= 0.0 && u < (double)F.g.tx && v >= 0.0 && v < (double)F.g.ty)) {
+                    const unsigned int k = atomicAdd(F.g.esc_n, 1u);
+                    if (k < F.g.esc_cap) F.g.esc[k] = {ph.x, ph.y, w, wl[j]};
+                    continue;
+                }
+                tile[j] = (unsigned int)((int)v * F.g.tx + (int)u);
+                hx[j] = ph.x, hy[j] = ph.y;
+            } else {
+                int32_t ix, iy;
+                if (fuse_pixel(F, ph, ix, iy) < 0) continue;
+                local[j] = (unsigned int)(((iy & (OT_TILE_W - 1)) << 6) | (ix & (OT_TILE_W - 1)));
+                tile[j] = (unsigned int)((iy >> 6) * F.tx + (ix >> 6));
+            }
+            rank[j] = atomicAdd(&cnt_a[tile[j]], 1u);
+            wk[j] = w;
+        }
+        fuse_lds_barrier();
+        // phase 2, one thread per tile: the previous sub-block's counts move the open chunks on; chunks for this sub-block's
+        // records; a job for every segment they complete.  Meanwhile the other threads carry out the previous sub-block's jobs
+        // (their destinations were settled when they were made; the slots they read are written again only behind the barrier).
+        run_jobs(par ^ 1, k_threads);
+        for (int e = threadIdx.x; e < K; e += blockDim.x) {
+            const unsigned int cb = cnt_b[e];
+            if (cb) {
+                advance(e, cb);
+                cnt_b[e] = 0u;
+            }
+            const unsigned int c = cnt_a[e];
+            if (!c) continue;
+            const unsigned int f0 = fill[e], f = f0 + c;
+            if (f > OT_FUSE_CH) {
+                const unsigned int n_new = (f - 1) / OT_FUSE_CH;
+                const unsigned int base = atomicAdd(&next[0], n_new);
+                nb[e] = base;
+                if (base + n_new > (blockIdx.x + 1) * F.per_wg) {
+                    F.overflow[0] = 1;
+                    nb[e] = F.cap;  // records of these chunks are dropped (place() checks the chunk number)
+                } else {
+                    for (unsigned int m = 0; m < n_new; m++) {
+                        F.chunk_tile[base + m] = (unsigned int)e;
+                        F.chunk_fill[base + m] = OT_FUSE_CH;  // every chunk but a tile's last one ends up full
+                    }
+                }
+            }
+            const unsigned int seg_end = (f0 / SEG + 1) * SEG;
+            if (f >= seg_end) {
+                const unsigned int l = lo[e] < f0 ? lo[e] : f0;  // (an empty buffer has lo = f0)
+                const unsigned int j = atomicAdd(&jn[par], 1u);
+                job[par * K + j] = (unsigned int)e | ((l % SEG) << 11) | ((seg_end - l) << 22);
+                jdst[par * K + j] = place(e, l);  // the segment lies in one chunk
+            }
+        }
+        fuse_lds_barrier();
+        if (threadIdx.x == 0) jn[par ^ 1] = 0u;  // its jobs are done; next written behind the next round's first barrier
+        // phase 3: a record below its tile's segment end goes to the LDS segment, the others straight to memory
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            if (!(wk[j] > 0.f)) continue;
+            const int e = (int)tile[j];
+            const unsigned int f0 = fill[e], p = f0 + rank[j];
+            REC rec;
+            if constexpr (SPECX) rec = {hx[j], hy[j], wk[j], wl[j]}; else rec = {wk[j], wl[j], local[j]};
+            if (p < (f0 / SEG + 1) * SEG) {
+                buf[(size_t)e * SEG + p % SEG] = rec;
+            } else {
+                const unsigned int dst = place(e, p);
+                if (dst != OT_FUSE_NONE) ((REC*)F.rec)[dst] = rec;
+            }
+        }
+    }
+    __syncthreads();
+    // the last sub-block's jobs and counts; what still stands in the buffers; the open chunks: the only ones that are not full
+    run_jobs(par ^ 1, 0u);
+    unsigned int* cnt_l = cnt + (par ^ 1) * K;
+    __syncthreads();
+    for (int e = threadIdx.x; e < K; e += blockDim.x) {
+        const unsigned int c = cnt_l[e];
+        if (c) advance(e, c);
+    }
+    __syncthreads();
+    {
+        const unsigned int g = threadIdx.x / SEG, r = threadIdx.x % SEG;
+        for (int e = (int)g; e < K; e += OT_LB_BR / SEG) {
+            const unsigned int l = lo[e], f = fill[e];
+            if (cur[e] == OT_FUSE_NONE || l >= f) continue;
+            const unsigned int p = l + r;  // (l and f lie in one segment)
+            if (p < f && cur[e] < F.cap) ((REC*)F.rec)[cur[e] * OT_FUSE_CH + p] = buf[(size_t)e * SEG + p % SEG];
+        }
+    }
+    for (int e = threadIdx.x; e < K; e += blockDim.x) {
+        if (cur[e] == OT_FUSE_NONE) continue;
+        if (cur[e] < F.cap) F.chunk_fill[cur[e]] = fill[e];
+    }
+    // chunks of this workgroup's part that were never handed out
+    {
+        const unsigned int end = (blockIdx.x + 1) * F.per_wg;
+        for (unsigned int c = min(next[0], end) + threadIdx.x; c < end; c += blockDim.x) F.chunk_tile[c] = OT_FUSE_NONE;
+    }
+    if constexpr (SPECX) spec_extent_flush(F.g.ext_slots, ext);
 }
 
 // ---- tile path, pass 2: chunks grouped by tile ------------------------------------------------------------------

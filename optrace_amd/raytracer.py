@@ -55,7 +55,7 @@ class Raytracer(Group):
     provisional tile grid laid over the extent of a sample: every AUTO_SAMPLE_STRIDE-th wave of 64 rays
     (`_auto_image_one_pass`)."""
     AUTO_SAMPLE_STRIDE: int = 128
-    AUTO_MARGINS: tuple = ((0.5, 1024), (0.3, 1024), (0.15, 1024), (0.3, 2048), (0.15, 2048), (0.05, 2048))
+    AUTO_MARGINS: tuple = ((0.05, 361), (0.02, 361), (0.5, 1024), (0.3, 1024), (0.15, 1024), (0.3, 2048), (0.15, 2048), (0.05, 2048))
     """(margin around the sample's extent as a fraction of its sides, most tiles) in order of preference."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
     """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are

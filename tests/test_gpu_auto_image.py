@@ -2,6 +2,8 @@
 `ot_detector_image_auto_*`, csrc/ot_detector_fused.hpp last section) against the chain hit list -> binning
 (`ot_detector_hits_multi` + `ot_render_accumulate`), which the reference fixtures pin (tests/test_gpu_parity.py):
 same extent (bit for bit), same pixels lit, f64 sums in another order (raytracer.py:1042-1049, 1053-1098)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,16 @@ import scenes
 from test_gpu_fused_detector import same_image, image_scene
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["line buffers", "plain tile kernel"], autouse=True)
+def tile_kernel(request, monkeypatch):
+    """Every case with both forms of the tile kernel's first pass: `fuse_tiles_lb_kernel` (one detector, images of up to
+    361 tiles: records leave the CU as whole 384-byte segments) and `fuse_tiles_kernel` (OT_TILE_LINEBUF=0)."""
+    if request.param == "plain tile kernel":
+        monkeypatch.setenv("OT_TILE_LINEBUF", "0")
+    else:
+        monkeypatch.delenv("OT_TILE_LINEBUF", raising=False)
 
 
 class one_pass_from:

@@ -13,6 +13,16 @@ import scenes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["line buffers", "plain tile kernel"], autouse=True)
+def tile_kernel(request, monkeypatch):
+    """Every case with both forms of the tile kernel's first pass: `fuse_tiles_lb_kernel` (one detector, images of up to
+    361 tiles: records leave the CU as whole 384-byte segments) and `fuse_tiles_kernel` (OT_TILE_LINEBUF=0)."""
+    if request.param == "plain tile kernel":
+        monkeypatch.setenv("OT_TILE_LINEBUF", "0")
+    else:
+        monkeypatch.delenv("OT_TILE_LINEBUF", raising=False)
+
+
 class pinned:
     """OT_RENDER_PATH = direct | tiles for the calls inside (None: the probe decides)."""
 
