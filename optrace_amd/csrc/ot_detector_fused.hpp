@@ -548,7 +548,9 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
 //     the new fill): a tile that receives more than a segment per sub-block (point-like images) simply streams.
 // One 1024-thread workgroup per CU (the buffers of 361 tiles are 139 KB), two rays per thread and sub-block.
 #define OT_LB_BR 1024
+#ifndef OT_LB_RPT
 #define OT_LB_RPT 2
+#endif
 #define OT_LB_MAXK 361
 #define OT_LB_SEG_BYTES 384
 
