@@ -59,9 +59,12 @@ def test_tiles_fit_the_windows_of_any_larger_extent(limit):
 def test_degenerate_sample_extents_are_declined():
     for e0 in ([1.0, 1.0, -2.0, 3.0], [0.0, 4.0, 2.0, 2.0], [0.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 4.5]):
         assert ot.Raytracer._auto_grid(np.array(e0), None, None, MARGINS) is None
-    # a square: 50 % margin per side would take 33 x 33 tiles, more than the 1024 of the tile kernel's faster form; 30 % fits
+    # a square: 5 % margin per side = 19 x 19 tiles, the most the tile kernel with line buffers takes (csrc: OT_LB_MAXK)
     grid, tw, th = ot.Raytracer._auto_grid(np.array([-1.0, 1.0, -1.0, 1.0]), None, None, MARGINS)
-    assert (grid[4], grid[5]) == (27, 27) and grid[0] == pytest.approx(-1.6) and grid[1] == pytest.approx(-1.6)
+    assert (grid[4], grid[5]) == (19, 19) and grid[0] == pytest.approx(-1.1) and grid[1] == pytest.approx(-1.1)
+    # without that entry: 50 % would take 33 x 33 tiles, more than the 1024 of the plain kernel's faster form; 30 % fits
+    grid, _, _ = ot.Raytracer._auto_grid(np.array([-1.0, 1.0, -1.0, 1.0]), None, None, ((0.5, 1024), (0.3, 1024)))
+    assert (grid[4], grid[5]) == (27, 27) and grid[0] == pytest.approx(-1.6)
     assert tw == pytest.approx(60 * 2.0 / 945) and th == tw
 
 
