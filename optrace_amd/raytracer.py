@@ -50,7 +50,7 @@ class Raytracer(Group):
     COMPACT_HITS_FROM: int = 1 << 21
     """`detector_image` with an automatic extent: from this many rays on the hit list between hit search and binning
     holds the valid hits only (`ot_detector_req.fill`)."""
-    AUTO_ONE_PASS_FROM: int = 1 << 25
+    AUTO_ONE_PASS_FROM: int = 1 << 24
     """... and from this many rays on, where the detector allows it, the sections are read once and the hits sorted on a
     provisional tile grid laid over the extent of a sample: every AUTO_SAMPLE_STRIDE-th wave of 64 rays
     (`_auto_image_one_pass`)."""
