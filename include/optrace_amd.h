@@ -437,7 +437,10 @@ int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_t count, co
  * misc.binning_indices_2d and the XYZW histogram update without the hit positions ever being written to memory.
  * Per request: hist (Ny, Nx, 4) f64 device, ADDED to; extent = image extent after RenderImage.__fix_extent;
  * crop4 = the user extent hits are restricted to (HOST f64[4]) or NULL; ill_count as in ot_detector_hits.
- * Same sums as ot_detector_hits_multi + ot_render_accumulate, in another order. */
+ * Same sums as ot_detector_hits_multi + ot_render_accumulate, in another order.
+ * Environment (tests, profiling): OT_RENDER_PATH = direct | tiles pins the binning path (default: a probe of 4096 rays
+ * decides); OT_TILE_LINEBUF = 0 takes the plain tile kernel where the one with per-tile line buffers in LDS would run
+ * (one detector, image of at most 361 tiles of 64 x 64 pixels; also for ot_detector_image_auto_begin). */
 typedef struct ot_detector_image_req {
     const ot_surface* detector;
     int32_t projection;   /* OT_PROJ_*                                              */
