@@ -13,13 +13,15 @@ import numpy as np
 import optrace_amd as ot
 import scenes
 
+import os
+N_CHOICES = [int(v) for v in os.environ.get("SOAK_N", "30000,200000,700001,2000000").split(",")]  # ray counts to draw from
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 applied = declined = bad = 0
 for case in range(cases):
     sides = [float(rng.uniform(0.5, 5.0)), float(rng.uniform(0.5, 5.0))]
     z_det = float(rng.uniform(20, 39))
-    n = int(rng.choice([30_000, 200_000, 700_001, 2_000_000]))
+    n = int(rng.choice(N_CHOICES))
     kind = rng.choice(["rect", "circle", "sphere"])
     limit = None if rng.random() < 0.7 else float(rng.uniform(1, 20))
     stride = int(rng.choice([1, 16, 128, 2048]))
