@@ -1659,6 +1659,8 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     };
     const size_t o_dets = carve(sizeof(FuseOne) * n_reqs);
     const size_t o_flags = carve(sizeof(int) * 4 * n_reqs);  // per detector: spread, -, overflow, pad
+    const size_t o_pcnt = carve(sizeof(int) * 2 * n_reqs);   // probe: distinct pixels, workgroups done
+    const size_t o_pset = carve(sizeof(int) * OT_TILE_PROBE_SET * (size_t)n_reqs);  // probe: pixel sets
     std::vector<size_t> o_ctile(n_reqs), o_cfill(n_reqs), o_rec(n_reqs);
     for (int k = 0; k < n_reqs; k++) {
         FuseOne& f = host[k];
@@ -1729,7 +1731,6 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     if (err == hipSuccess) err = hipMemcpyAsync(ws + o_dets, host.data(), sizeof(FuseOne) * n_reqs, hipMemcpyHostToDevice, st);
     const FuseOne* dd = (const FuseOne*)(ws + o_dets);
     static thread_local bool lds_set[64] = {false};
-    const int lds_probe = OT_TILE_PROBE_SET * (int)sizeof(int);
     const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
     if (err == hipSuccess && dev >= 0 && dev < 64 && !lds_set[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)fuse_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
@@ -1743,10 +1744,16 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
                 for (int k = 0; k < n_reqs; k++) hf[4 * k] = host[k].tiles_ok;
                 err = hipMemcpyAsync(flags, hf.data(), sizeof(int) * 4 * n_reqs, hipMemcpyHostToDevice, st);
                 (void)hipStreamSynchronize(st);  // hf goes out of scope
-            } else if (numeric) {
-                hipLaunchKernelGGL(fuse_probe_kernel<true>, dim3(n_reqs), dim3(1024), lds_probe, st, *rays, first, count, dd);
             } else {
-                hipLaunchKernelGGL(fuse_probe_kernel<false>, dim3(n_reqs), dim3(1024), lds_probe, st, *rays, first, count, dd);
+                int* pcnt = (int*)(ws + o_pcnt);
+                int* pset = (int*)(ws + o_pset);
+                err = hipMemsetAsync(pcnt, 0, sizeof(int) * 2 * n_reqs, st);
+                if (err == hipSuccess) err = hipMemsetAsync(pset, 0xff, sizeof(int) * OT_TILE_PROBE_SET * (size_t)n_reqs, st);
+                const dim3 pg(n_reqs, OT_TILE_PROBE / OT_FUSE_PROBE_WG);
+                if (numeric)
+                    hipLaunchKernelGGL(fuse_probe_kernel<true>, pg, dim3(OT_FUSE_PROBE_WG), 0, st, *rays, first, count, dd, pset, pcnt);
+                else
+                    hipLaunchKernelGGL(fuse_probe_kernel<false>, pg, dim3(OT_FUSE_PROBE_WG), 0, st, *rays, first, count, dd, pset, pcnt);
             }
         }
         const unsigned blocks = (unsigned)std::min<int64_t>(cus, (count + 1023) / 1024);
