@@ -1543,6 +1543,16 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
 }
 
 // ---- detector image in one pass (ot_detector_fused.hpp) ------------------------------------------------------
+// a small record to device memory through the kernel arguments (no staging copy, nothing for the host to wait for)
+template <class T>
+__global__ void put_kernel(T v, T* dst) {
+    if (threadIdx.x == 0) *dst = v;
+}
+
+struct FuseIndexAll {
+    FuseIndex v[OT_DET_MAX];
+};
+
 static int cu_count();
 
 // one detector, an image of few tiles: the tile kernel with line buffers (OT_TILE_LINEBUF=0 in the environment: the plain one)
@@ -1699,13 +1709,18 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         numeric = numeric || !(f.det.kind == OT_SURF_CONIC || f.det.flat);
         general = general || !(f.det.kind == OT_SURF_CONIC || f.det.flat) || (q.projection != OT_PROJ_NONE && q.projection != OT_PROJ_ORTHOGRAPHIC);
     }
-    const size_t o_tn = carve(sizeof(unsigned int) * Kmax);
-    const size_t o_ts = carve(sizeof(unsigned int) * (Kmax + 1));
-    const size_t o_list = carve(sizeof(unsigned int) * capmax);
-    const size_t o_ws = carve(sizeof(unsigned int) * (Kmax + 1));
+    // second pass (chunks grouped by tile, accumulation, reduction): every detector its own index and slabs, so that one launch
+    // per step serves them all (six positions of an iterative render: 400 accumulation workgroups each, 1.6 rounds over 256 CUs
+    // when launched one after the other)
+    const int n_idx = KT ? n_reqs : 0;
+    const size_t o_ixs = carve(sizeof(FuseIndexAll));
+    const size_t o_tn = carve(sizeof(unsigned int) * Kmax * (size_t)n_idx);
+    const size_t o_ts = carve(sizeof(unsigned int) * (Kmax + 1) * (size_t)n_idx);
+    const size_t o_list = carve(sizeof(unsigned int) * (size_t)capmax * n_idx);
+    const size_t o_ws = carve(sizeof(unsigned int) * (Kmax + 1) * (size_t)n_idx);
     // one slab per accumulation workgroup: a tile with n chunks takes ceil(n / OT_FUSE_CPW) of them
     const unsigned n_slabs = (unsigned)((capmax + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)Kmax;
-    const size_t o_slabs = carve(KT ? sizeof(double) * OT_TILE_PX * 4 * (size_t)n_slabs : 0);
+    const size_t o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)n_slabs * n_idx);
     char* ws = workspace(OT_WS_FUSED, off, st);
     if (!ws) {
         if (!KT) return fail(OT_ERR_HIP, "ot_detector_images: no scratch memory");
@@ -1734,6 +1749,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
     if (err == hipSuccess && dev >= 0 && dev < 64 && !lds_set[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)fuse_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
+        HIP_TRY(hipFuncSetAttribute((const void*)fuse_accum_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
         lds_set[dev] = true;
     }
     if (int rc = fuse_tiles_allow_lds(dev)) return rc;
@@ -1787,26 +1803,32 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         }
 #undef OT_LAUNCH_FUSE
         err = hipGetLastError();
-        // tile path, detector by detector: chunks grouped by tile, LDS accumulation, slabs summed into the image
-        for (int k = 0; k < n_reqs && err == hipSuccess && KT; k++) {
-            const FuseOne& f = host[k];
-            if (!f.tiles_ok) continue;
-            FuseIndex ix;
-            ix.tile_n = (unsigned int*)(ws + o_tn);
-            ix.tstart = (unsigned int*)(ws + o_ts);
-            ix.wstart = (unsigned int*)(ws + o_ws);
-            ix.n_slabs = (unsigned)((f.cap + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)f.K;
-            ix.list = (unsigned int*)(ws + o_list);
-            ix.slabs = (double*)(ws + o_slabs);
-            err = hipMemsetAsync(ix.tile_n, 0, sizeof(unsigned int) * f.K, st);
-            if (err != hipSuccess) break;
-            const unsigned gc = (f.cap + 1024 * OT_FUSE_IDX_PER - 1) / (1024 * OT_FUSE_IDX_PER);
-            hipLaunchKernelGGL(fuse_chunk_hist_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
-            hipLaunchKernelGGL(fuse_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, f, ix);
-            hipLaunchKernelGGL(fuse_chunk_place_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
-            hipLaunchKernelGGL(fuse_accum_kernel, dim3(ix.n_slabs), dim3(1024), lds_accum, st, f, ix, table);
-            hipLaunchKernelGGL(fuse_reduce_kernel, dim3(OT_TILE_PX / 256, (unsigned)f.K), dim3(256), 0, st, f, ix);
-            err = hipGetLastError();
+        // tile path, all detectors per launch: chunks grouped by tile, LDS accumulation, slabs summed into the images
+        if (err == hipSuccess && KT) {
+            FuseIndexAll ixs;
+            std::memset(&ixs, 0, sizeof(ixs));
+            for (int k = 0; k < n_reqs; k++) {
+                FuseIndex& ix = ixs.v[k];
+                ix.tile_n = (unsigned int*)(ws + o_tn) + (size_t)Kmax * k;
+                ix.tstart = (unsigned int*)(ws + o_ts) + (size_t)(Kmax + 1) * k;
+                ix.wstart = (unsigned int*)(ws + o_ws) + (size_t)(Kmax + 1) * k;
+                ix.n_slabs = n_slabs;
+                ix.list = (unsigned int*)(ws + o_list) + (size_t)capmax * k;
+                ix.slabs = (double*)(ws + o_slabs) + (size_t)OT_TILE_PX * 4 * n_slabs * k;
+            }
+            err = hipMemsetAsync(ws + o_tn, 0, sizeof(unsigned int) * Kmax * (size_t)n_reqs, st);
+            if (err == hipSuccess) {
+                hipLaunchKernelGGL(put_kernel<FuseIndexAll>, dim3(1), dim3(64), 0, st, ixs, (FuseIndexAll*)(ws + o_ixs));
+                const FuseIndex* dix = (const FuseIndex*)(ws + o_ixs);
+                const unsigned gc = (capmax + 1024 * OT_FUSE_IDX_PER - 1) / (1024 * OT_FUSE_IDX_PER);
+                const unsigned nd = (unsigned)n_reqs;
+                hipLaunchKernelGGL(fuse_chunk_hist_multi_kernel, dim3(gc, 1, nd), dim3(1024), 0, st, dd, dix);
+                hipLaunchKernelGGL(fuse_chunk_scan_multi_kernel, dim3(1, 1, nd), dim3(1024), 0, st, dd, dix);
+                hipLaunchKernelGGL(fuse_chunk_place_multi_kernel, dim3(gc, 1, nd), dim3(1024), 0, st, dd, dix);
+                hipLaunchKernelGGL(fuse_accum_multi_kernel, dim3(n_slabs, 1, nd), dim3(1024), lds_accum, st, dd, dix, table);
+                hipLaunchKernelGGL(fuse_reduce_multi_kernel, dim3(OT_TILE_PX / 256, (unsigned)Kmax, nd), dim3(256), 0, st, dd, dix);
+                err = hipGetLastError();
+            }
         }
     }
     HIP_TRY(err);
@@ -1824,12 +1846,6 @@ struct AutoHead {
         end = o_slots + align_up(sizeof(unsigned long long) * 4 * OT_EXT_SLOTS);
     }
 };
-
-// a small record to device memory through the kernel arguments (no staging copy, nothing for the host to wait for)
-template <class T>
-__global__ void put_kernel(T v, T* dst) {
-    if (threadIdx.x == 0) *dst = v;
-}
 
 struct ot_auto_image {
     FuseOne f;  // host copy; the image grid (a, hist) is filled in by finish

@@ -802,10 +802,10 @@ struct FuseIndex {
 
 // chunks per tile: LDS histogram per workgroup (16 chunk numbers per thread), one global add per tile and workgroup
 #define OT_FUSE_IDX_PER 16
-__global__ __launch_bounds__(1024) void fuse_chunk_hist_kernel(FuseOne F, FuseIndex ix) {
+OT_DEV void fuse_chunk_hist_body(const FuseOne& F, const FuseIndex& ix, const unsigned int bx, const unsigned int by) {
     if (!F.spread[0]) return;
     const unsigned int n = F.cap;
-    const unsigned int c0 = blockIdx.x * (1024 * OT_FUSE_IDX_PER);
+    const unsigned int c0 = bx * (1024 * OT_FUSE_IDX_PER);
     if (c0 >= n) return;
     __shared__ unsigned int h[OT_TILE_MAX];
     for (int i = threadIdx.x; i < F.K; i += blockDim.x) h[i] = 0u;
@@ -821,8 +821,15 @@ __global__ __launch_bounds__(1024) void fuse_chunk_hist_kernel(FuseOne F, FuseIn
     for (int i = threadIdx.x; i < F.K; i += blockDim.x)
         if (h[i]) atomicAdd(&ix.tile_n[i], h[i]);
 }
+__global__ __launch_bounds__(1024) void fuse_chunk_hist_kernel(FuseOne F, FuseIndex ix) {
+    fuse_chunk_hist_body(F, ix, blockIdx.x, blockIdx.y);
+}
+// several detectors in one launch (blockIdx.z), their records in device memory
+__global__ __launch_bounds__(1024) void fuse_chunk_hist_multi_kernel(const FuseOne* __restrict__ dets, const FuseIndex* __restrict__ ixs) {
+    fuse_chunk_hist_body(dets[blockIdx.z], ixs[blockIdx.z], blockIdx.x, blockIdx.y);
+}
 
-__global__ __launch_bounds__(1024) void fuse_chunk_scan_kernel(FuseOne F, FuseIndex ix) {
+OT_DEV void fuse_chunk_scan_body(const FuseOne& F, const FuseIndex& ix, const unsigned int bx, const unsigned int by) {
     if (!F.spread[0]) return;
     // exclusive scans of the chunk counts (tstart) and of the workgroups they take (wstart) over K <= 2048 tiles: two
     // tiles per thread, wave scans by shuffles, the 16 wave totals through LDS
@@ -849,12 +856,19 @@ __global__ __launch_bounds__(1024) void fuse_chunk_scan_kernel(FuseOne F, FuseIn
     if (i0 < F.K) ix.tile_n[i0] = 0u;  // becomes the placement cursor
     if (i1 < F.K) ix.tile_n[i1] = 0u;
 }
+__global__ __launch_bounds__(1024) void fuse_chunk_scan_kernel(FuseOne F, FuseIndex ix) {
+    fuse_chunk_scan_body(F, ix, blockIdx.x, blockIdx.y);
+}
+// several detectors in one launch (blockIdx.z), their records in device memory
+__global__ __launch_bounds__(1024) void fuse_chunk_scan_multi_kernel(const FuseOne* __restrict__ dets, const FuseIndex* __restrict__ ixs) {
+    fuse_chunk_scan_body(dets[blockIdx.z], ixs[blockIdx.z], blockIdx.x, blockIdx.y);
+}
 
 // the workgroup's chunks of a tile get consecutive places behind one global reservation per tile
-__global__ __launch_bounds__(1024) void fuse_chunk_place_kernel(FuseOne F, FuseIndex ix) {
+OT_DEV void fuse_chunk_place_body(const FuseOne& F, const FuseIndex& ix, const unsigned int bx, const unsigned int by) {
     if (!F.spread[0]) return;
     const unsigned int n = F.cap;
-    const unsigned int c0 = blockIdx.x * (1024 * OT_FUSE_IDX_PER);
+    const unsigned int c0 = bx * (1024 * OT_FUSE_IDX_PER);
     if (c0 >= n) return;
     __shared__ unsigned int h[OT_TILE_MAX];
     for (int i = threadIdx.x; i < F.K; i += blockDim.x) h[i] = 0u;
@@ -878,19 +892,26 @@ __global__ __launch_bounds__(1024) void fuse_chunk_place_kernel(FuseOne F, FuseI
     for (int k = 0; k < OT_FUSE_IDX_PER; k++)
         if (tl[k] != OT_FUSE_NONE) ix.list[h[tl[k]] + rank[k]] = c0 + k * 1024 + threadIdx.x;
 }
+__global__ __launch_bounds__(1024) void fuse_chunk_place_kernel(FuseOne F, FuseIndex ix) {
+    fuse_chunk_place_body(F, ix, blockIdx.x, blockIdx.y);
+}
+// several detectors in one launch (blockIdx.z), their records in device memory
+__global__ __launch_bounds__(1024) void fuse_chunk_place_multi_kernel(const FuseOne* __restrict__ dets, const FuseIndex* __restrict__ ixs) {
+    fuse_chunk_place_body(dets[blockIdx.z], ixs[blockIdx.z], blockIdx.x, blockIdx.y);
+}
 
 // Accumulation, one workgroup per OT_FUSE_CPW chunks of a tile (wstart): the hits of an image are rarely spread evenly
 // -- C4's picture covers a fifth of the detector, 42 of 225 tiles hold every record -- and a fixed number of workgroups
 // per tile left most CUs idle behind the few heavy tiles (1.7 of 4 waves per SIMD resident on average).  Workgroup b
 // finds its tile by bisection of wstart in LDS, adds its chunks into an LDS tile and writes slab b.
-__global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex ix, const double* __restrict__ table) {
+OT_DEV void fuse_accum_body(const FuseOne& F, const FuseIndex& ix, const double* __restrict__ table, const unsigned int bx, const unsigned int by) {
     if (!F.spread[0]) return;
     extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 3 observer table]; the tile part first holds wstart
     double* tile = lds;
     double* obs = lds + OT_TILE_PX * 4;
     unsigned int* ws = (unsigned int*)lds;
     const int K = F.K;
-    const unsigned int b = blockIdx.x;
+    const unsigned int b = bx;
     if (b >= ix.wstart[K]) return;  // (the grid is sized for the worst case: most workgroups leave here, before the table)
     for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
     __syncthreads();
@@ -958,14 +979,22 @@ __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex i
     double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
     for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) slab[i] = tile[i];
 }
+__global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex ix, const double* __restrict__ table) {
+    fuse_accum_body(F, ix, table, blockIdx.x, blockIdx.y);
+}
+// several detectors in one launch (blockIdx.z), their records in device memory
+__global__ __launch_bounds__(1024) void fuse_accum_multi_kernel(const FuseOne* __restrict__ dets, const FuseIndex* __restrict__ ixs, const double* __restrict__ table) {
+    fuse_accum_body(dets[blockIdx.z], ixs[blockIdx.z], table, blockIdx.x, blockIdx.y);
+}
 
 // grid (16, K): thread = one pixel of tile blockIdx.y, all four planes
-__global__ __launch_bounds__(256) void fuse_reduce_kernel(FuseOne F, FuseIndex ix) {
+OT_DEV void fuse_reduce_body(const FuseOne& F, const FuseIndex& ix, const unsigned int bx, const unsigned int by) {
     if (!F.spread[0]) return;
-    const int tl = blockIdx.y;
+    const int tl = by;
+    if (tl >= F.K) return;  // (a launch for several detectors has the tile count of the largest image)
     const unsigned int s_first = ix.wstart[tl], s_end = ix.wstart[tl + 1];
     if (s_end == s_first) return;
-    const int local = blockIdx.x * blockDim.x + threadIdx.x;
+    const int local = bx * blockDim.x + threadIdx.x;
     const int px = (tl % F.tx) * OT_TILE_W + (local & (OT_TILE_W - 1));
     const int py = (tl / F.tx) * OT_TILE_W + (local >> 6);
     if (px >= F.a.Nx || py >= F.a.Ny) return;
@@ -982,6 +1011,13 @@ __global__ __launch_bounds__(256) void fuse_reduce_kernel(FuseOne F, FuseIndex i
     hg[1] += s1;
     hg[2] += s2;
     hg[3] += s3;
+}
+__global__ __launch_bounds__(256) void fuse_reduce_kernel(FuseOne F, FuseIndex ix) {
+    fuse_reduce_body(F, ix, blockIdx.x, blockIdx.y);
+}
+// several detectors in one launch (blockIdx.z), their records in device memory
+__global__ __launch_bounds__(256) void fuse_reduce_multi_kernel(const FuseOne* __restrict__ dets, const FuseIndex* __restrict__ ixs) {
+    fuse_reduce_body(dets[blockIdx.z], ixs[blockIdx.z], blockIdx.x, blockIdx.y);
 }
 
 // ---- automatic extent in one pass over the ray sections ---------------------------------------------------------
