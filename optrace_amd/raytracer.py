@@ -57,6 +57,11 @@ class Raytracer(Group):
     AUTO_SAMPLE_STRIDE: int = 128
     AUTO_MARGINS: tuple = ((0.05, 361), (0.02, 361), (0.5, 1024), (0.3, 1024), (0.15, 1024), (0.3, 2048), (0.15, 2048), (0.05, 2048))
     """(margin around the sample's extent as a fraction of its sides, most tiles) in order of preference."""
+    ITER_EXTENT_RAYS: int = 1_000_000
+    """`iterative_render` with automatic extents: the extents are those of the hits of the reference's FIRST ITERATION, 1 M
+    rays (ITER_RAYS_STEP, raytracer.py:40, 1212-1262); everything after is cropped to them.  A chunk here is tens of
+    millions of rays: an evenly spread sample of about this many of the first chunk's rays plays the first iteration's part
+    (every k-th wave of 64 rays, `ot_detector_extent_sample`), the rest of the chunk is cropped like the later ones."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
     """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are
     19 M rays of a 15-surface scene with polarisation or 93 M rays of a two-surface scene without."""
@@ -530,11 +535,12 @@ class Raytracer(Group):
                     img._apply_rayleigh_filter()
         return images
 
-    def _auto_extents(self, specs: list, agree=None) -> list:
+    def _auto_extents(self, specs: list, agree=None, sample_rays: int = None) -> list:
         """Automatic extents (raytracer.py:1042-1049) of the specs without a user extent, from an extent-only pass over
         the ray sections (no hit list: `detector.detector_extents`, up to 8 detectors per pass).  `agree`: callable
         mapping the (n, 4) array of raw extents (+-inf where no ray hits) to the one every rank uses
-        (distributed.py); an extent no ray reaches collapses to the detector centre.  -> specs with "auto_extent" set."""
+        (distributed.py); an extent no ray reaches collapses to the detector centre.  `sample_rays`: the extents of
+        about that many evenly spread rays instead of all (ITER_EXTENT_RAYS).  -> specs with "auto_extent" set."""
         todo = [n for n, sp in enumerate(specs) if sp.get("extent") is None]
         if not todo:
             return specs
@@ -542,7 +548,13 @@ class Raytracer(Group):
         raw = np.empty((len(todo), 4), dtype=np.float64)
         groups: dict = {}
         for m, n in enumerate(todo):
-            groups.setdefault((reqs[n]["Ns"], reqs[n]["Ne"]), []).append(m)
+            rq = reqs[n]
+            count, proj = rq["Ne"] - rq["Ns"], _capi.PROJECTIONS[rq["projection"]]
+            if sample_rays and count >= 2 * sample_rays and _detector.auto_image_supported(rq["surf_desc"], proj):
+                raw[m] = _detector.detector_extent_sample(self.rays, rq["Ns"], count, rq["surf_desc"], proj,
+                                                          count // sample_rays)
+                continue
+            groups.setdefault((rq["Ns"], rq["Ne"]), []).append(m)
         for (Ns, Ne), ms in groups.items():
             for b in range(0, len(ms), 8):
                 part = ms[b:b + 8]
@@ -936,7 +948,7 @@ class Raytracer(Group):
                     direct = 0 < i and rays_step == step0
                     into = [images[j]._dev if direct else None for j in group]
                     if not all(extentc[j] is not None for j in group):  # first chunk: extents from their own pass
-                        specs = self._auto_extents(specs, agree=_agree_extents)
+                        specs = self._auto_extents(specs, agree=_agree_extents, sample_rays=self.ITER_EXTENT_RAYS)
                     imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, _dont_filter=True)
                     for g, j in enumerate(group):
                         img = imgs[g]

@@ -240,3 +240,26 @@ def test_kept_scratch_grows_and_can_be_handed_back():
     same_image(a1, a2, tol=1e-12)
     same_image(b1, b2, tol=1e-12)
     same_image(b1a, b2a, tol=1e-12)
+
+
+def test_iterative_render_extents_come_from_a_sample_like_the_first_iteration():
+    """Automatic extents of `iterative_render` are those of the reference's first iteration of 1 M rays, everything else is
+    cropped to them (raytracer.py:1212, 1262).  A chunk here is much larger: an evenly spread sample of ITER_EXTENT_RAYS of its
+    rays fixes the extents.  The sample's extent lies inside the whole chunk's, nearly all the power stays, and the image is
+    the one a caller gets who passes that extent himself."""
+    RT = image_scene(N=1000)
+    old = ot.Raytracer.ITER_EXTENT_RAYS
+    try:
+        with ot.global_options.no_warnings():
+            ot.Raytracer.ITER_EXTENT_RAYS = 1 << 60  # every ray of the first chunk
+            full = RT.iterative_render(600_000)[0]
+            ot.Raytracer.ITER_EXTENT_RAYS = 20_000
+            samp = RT.iterative_render(600_000)[0]
+            given = RT.iterative_render(600_000, extent=[float(v) for v in samp._extent0])[0]
+    finally:
+        ot.Raytracer.ITER_EXTENT_RAYS = old
+    ef, es = full._extent0, samp._extent0
+    assert ef[0] <= es[0] and es[1] <= ef[1] and ef[2] <= es[2] and es[3] <= ef[3]
+    assert not np.array_equal(ef, es), "30 rays in 600 000 reach further than the 20 000 sampled ones"
+    assert 0.99 * full.power() < samp.power() <= full.power()
+    same_image(samp, given)
