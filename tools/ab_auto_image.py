@@ -64,12 +64,12 @@ def run(name, RT, N):
           f"shape={A.shape}  same extent={same_extent}  same pixels lit={lit}  max rel diff={diff:.2e}", flush=True)
 
 
-which = sys.argv[2:] if len(sys.argv) > 2 else []
 with ot.global_options.no_warnings():
     import os
     sel = os.environ.get("AB_CONFIGS", "C4,C5,C2").split(",")
     if os.environ.get("AB_MARGINS"):
-        ot.Raytracer.AUTO_MARGINS = eval(os.environ["AB_MARGINS"])
+        import ast
+        ot.Raytracer.AUTO_MARGINS = ast.literal_eval(os.environ["AB_MARGINS"])
     if "C4" in sel:
         run("C4", bc.c4(ot), 200_000_000)
         torch.cuda.empty_cache()
