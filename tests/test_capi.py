@@ -83,3 +83,23 @@ def test_product_package_does_not_reference_the_oracle():
         if path.suffix in (".py", ".hip", ".hpp", ".h", ".inc") and path.is_file():
             text = path.read_text()
             assert "liboracle" not in text and "oracle_bridge" not in text and "orc_" not in text, path
+
+
+def test_automatic_extent_entry_points_check_their_arguments_before_anything_else():
+    """`ot_detector_extent_sample` / `ot_detector_image_auto_*` (include/optrace_amd.h): null arguments are refused with
+    OT_ERR_INVALID before a device is looked for; cancelling nothing is harmless; a handle comes back null on failure."""
+    lib = _capi.load_library()  # (bound signatures: ot_last_error returns bytes)
+    st = C.c_void_p()
+    assert lib.ot_detector_extent_sample(None, 0, 1, None, 0, 128, None, st) == -1  # OT_ERR_INVALID
+    assert b"null argument" in lib.ot_last_error()
+    handle = C.c_void_p(12345)
+    rc = lib.ot_detector_image_auto_begin(None, 0, 1, None, 0, None, None, None, None, C.byref(handle), st)
+    assert rc == -1 and not handle.value
+    assert lib.ot_detector_image_auto_finish(None, None, 1, 1, None, st) == -1
+    lib.ot_detector_image_auto_cancel(None)
+    # a ray storage without buffers
+    rays = _capi.Rays()
+    sd = _capi.Surface()
+    ext = (C.c_double * 4)()
+    assert lib.ot_detector_extent_sample(C.byref(rays), 0, 1, C.byref(sd), 0, 128, ext, st) == -1
+    assert b"null buffers" in lib.ot_last_error()
