@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-pol", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--skip-configs", action="store_true", help="skip the `configs` block (the other BASELINE configs "
+                                                                "and config 4's sharded render, after the timed region)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: collectives on "
                                                       "host copies, also picked when ranks have to share a device)")
     return ap.parse_args()
@@ -76,6 +78,7 @@ def spawn_ranks(args) -> int:
            "--rays", str(args.rays), "--backend", backend, "--cpu-seconds", str(args.cpu_seconds)]
     cmd += ["--no-pol"] if args.no_pol else []
     cmd += ["--skip-cpu"] if args.skip_cpu else []
+    cmd += ["--skip-configs"] if args.skip_configs else []
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
@@ -164,6 +167,179 @@ def secondary_no_pol(ot, scenes, lib, N, steps):
     b = N * (nt * 36 + 28)
     return {"value": N * (nt - 2) / t, "ms_per_step": 1e3 * t, "roofline_frac": b / t / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": b}
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def _release(torch, lib):
+    """Between two configurations: the library's kept scratch and torch's cached blocks go back to the driver."""
+    import gc
+    from optrace_amd import _capi
+    gc.collect()
+    _capi.check(lib.ot_scratch_trim())
+    torch.cuda.empty_cache()
+
+
+def _wall_ms(torch, f, reps=5):
+    """Median wall time of f() in ms, synchronised on both sides, after one untimed call."""
+    f()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        f()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return _median(ts)
+
+
+def measure_config(ot, torch, lib, build, N, user_extent=None, positions=None):
+    """One BASELINE configuration at its full ray count on this GPU, after the timed region:
+    `trace_ms` = duration of the trace kernel from the library's HIP events (median of 5 after a short settle),
+    `roofline_frac` = SURVEY 8(d) bytes of `RayStorage` / trace_ms / 8 TB/s; `detector_image_ms` (wall time of the call,
+    median of 5) with an automatic and with a given extent, `frac` against N * 56 B + Ny * Nx * 32 B; with `positions`
+    `iterative_render_ms` for those detector positions (config 4: N rays in storage-sized chunks, one trace per chunk)."""
+    from optrace_amd import _capi
+    with ot.global_options.no_warnings():
+        RT = build(ot)
+        RT.trace(min(N, 100_000))
+        _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 1))
+        RT._kernel_ms_log = log = []
+        for _ in range(12 if N <= 10_000_000 else 3):  # settle: the clocks under this load
+            RT.trace(N)
+        del log[:]
+        walls = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            RT.trace(N)
+            torch.cuda.synchronize()
+            walls.append(1e3 * (time.perf_counter() - t0))
+        trace_ms, wall_ms = _median(log), _median(walls)
+        RT._kernel_ms_log = None
+        nt = RT.rays.Nt
+        M = nt - 2
+        b = N * (nt * (36 if RT.no_pol else 48) + 28)
+        out = {"rays": N, "surfaces": M, "sections": nt, "pol": not RT.no_pol, "trace_ms": trace_ms,
+               "trace_call_ms": wall_ms, "algorithmic_bytes": b, "roofline_frac": b / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "ray_surface_intersections_per_s": N * M / (trace_ms * 1e-3)}
+        if RT.detectors:
+            def det_entry(ms, img):
+                Ny, Nx = img._dev.shape[:2]
+                bd = N * 56 + Ny * Nx * 32
+                return {"ms": ms, "image": [int(Ny), int(Nx)], "frac": bd / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "rays_per_s": N / (ms * 1e-3)}
+            img = RT.detector_image(_keep_on_device=True)
+            ext = [float(v) for v in (user_extent if user_extent is not None else img._extent0)]
+            ms = _wall_ms(torch, lambda: RT.detector_image(_keep_on_device=True))
+            out["detector_image_auto"] = det_entry(ms, img)
+            img = RT.detector_image(extent=ext, _keep_on_device=True)
+            ms = _wall_ms(torch, lambda: RT.detector_image(extent=ext, _keep_on_device=True))
+            out["detector_image_user"] = det_entry(ms, img)
+            out["detector_image_user"]["extent"] = ext
+            del img
+        if positions is not None:
+            exts = [list(user_extent)] * len(positions)
+            RT.iterative_render(N, pos=positions, extent=exts)  # untimed: allocator pools at this chunk size
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                RT.iterative_render(N, pos=positions, extent=exts)
+                torch.cuda.synchronize()
+                ts.append(1e3 * (time.perf_counter() - t0))
+            out["iterative_render"] = {"ms": _median(ts), "positions": len(positions), "extent": "user",
+                                       "rays_per_s": N / (_median(ts) * 1e-3)}
+        _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 0))
+    del RT
+    _release(torch, lib)
+    return out
+
+
+def configs_block(ot, torch, lib, scenes):
+    """The BASELINE configurations bench.py's headline does not time (C1 at 1e7 rays, C3, C4, C5) and the aspheric
+    double Gauss (A1), one after the other on this GPU, every storage released before the next is built."""
+    table = [
+        ("C1_single_lens_1e7", lambda o: scenes.c1_single_lens(o, seed=1), 10_000_000, None, None),
+        ("C3_arizona_eye_rgb_5e7", scenes.c3_arizona_eye_rgb, 50_000_000, None, None),
+        ("C4_image_render_2e8", scenes.c4_image_render, 200_000_000, [-8., 8., -8., 8.], scenes.C4_POSITIONS),
+        ("C5_hurb_slit_lens_1e8", lambda o: scenes.hurb_slit_lens(o, seed=51), 100_000_000, None, None),
+        ("A1_double_gauss_aspheric_1e7", lambda o: scenes.double_gauss(o, seed=1, aspheric=True), 10_000_000,
+         [-45., 45., -45., 45.], None),
+    ]
+    out = {}
+    for name, build, N, ext, positions in table:
+        t0 = time.perf_counter()
+        try:
+            out[name] = measure_config(ot, torch, lib, build, N, ext, positions)
+        except Exception as err:  # an out-of-memory box must not take the headline line with it
+            out[name] = {"error": f"{type(err).__name__}: {err}"[:300]}
+            _release(torch, lib)
+        out[name]["block_s"] = time.perf_counter() - t0
+    return out
+
+
+def c4_sharded_block(ot, torch, lib, scenes, dist, use_dist, backend, dev, world, steps=3):
+    """BASELINE config 4 AS STATED: image_render_many_rays.py, 2e8 rays sharded over the ranks, six detector positions,
+    one RCCL reduce of the six stacked histograms -- `distributed.sharded_iterative_render` (every rank traces its shard
+    once, in storage-sized chunks, and bins each chunk into all positions in one pass over the sections).  Strong
+    scaling: the 2e8 rays are the job's.  -> dict on every rank (the caller prints rank 0's)."""
+    from optrace_amd import _capi
+    from optrace_amd import distributed as D
+    N = 200_000_000
+    pos = scenes.C4_POSITIONS
+    ext = [[-8., 8., -8., 8.]] * len(pos)
+    on_host = use_dist and backend != "nccl"
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with ot.global_options.no_warnings():
+        RT = scenes.c4_image_render(ot)
+        RT.trace(100_000)
+        _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 1))
+        D.sharded_iterative_render(RT, N, pos=pos, extent=ext, base_seed=1)  # untimed: tables, allocator pools, communicator
+        RT._kernel_ms_log = log = []
+        ts = []
+        for k in range(steps):
+            sync()
+            t0 = time.perf_counter()
+            imgs = D.sharded_iterative_render(RT, N, pos=pos, extent=ext, base_seed=100 + 10 * k)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        sync()
+        trace_ms = sum(log) / steps  # this rank's trace kernels per render (all its chunks)
+        RT._kernel_ms_log = None
+        # the exchange alone: the six stacked histograms once more (values irrelevant)
+        stack = torch.stack([im._dev for im in imgs])
+        tr = []
+        for _ in range(3):
+            sync()
+            t1 = time.perf_counter()
+            D.allreduce_image(stack)
+            torch.cuda.synchronize()
+            tr.append(1e3 * (time.perf_counter() - t1))
+        power = [float(im.power()) for im in imgs]
+        shapes = [list(im._dev.shape) for im in imgs]
+        _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 0))
+    t = torch.tensor([_median(ts), trace_ms, -trace_ms, _median(tr)], dtype=torch.float64, device="cpu" if on_host else dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu().tolist()
+    del RT, imgs, stack
+    _release(torch, lib)
+    return {"workload": "image_render_many_rays.py geometry, 2e8 rays sharded over the ranks, six detector positions "
+                        "(user extents), distributed.sharded_iterative_render", "rays_total": N, "n_gpus": world,
+            "scaling": "strong", "positions": len(pos), "c4_sharded_ms": 1e3 * t[0], "rays_per_s": N / t[0],
+            "trace_ms_per_rank_min_max": [-t[2], t[1]], "histogram_allreduce_ms": t[3],
+            "histogram_bytes": int(len(pos) * shapes[0][0] * shapes[0][1] * 32), "image_shapes": shapes,
+            "image_power": power, "backend": backend if use_dist else None}
 
 
 def committed_profile(name: str, pol: bool, N: int):
@@ -319,6 +495,19 @@ def main():
     if world == 1 and not args.no_pol:  # same scene without polarisation tracking, outside the timed region
         other = secondary_no_pol(ot, scenes, lib, N, args.steps)
 
+    # ---- the other BASELINE configurations, after the timed region and with the headline's storage released ----
+    cpu = None
+    if rank == 0 and not args.skip_cpu and world == 1:  # CPU leg on rank 0 at N = 1 only (reads the first sections of the
+        cpu = cpu_baseline(RT, scene, args.cpu_seconds)  # headline's storage: before that is released)
+    cfgs = sharded = None
+    if not args.skip_configs:
+        del img, hist
+        RT.rays.__init__()
+        _release(torch, lib)
+        if world == 1:
+            cfgs = configs_block(ot, torch, lib, scenes)
+        sharded = c4_sharded_block(ot, torch, lib, scenes, dist if use_dist else None, use_dist, backend, dev, world)
+
     if rank == 0:
         pol = not args.no_pol
         bytes_per_ray = nt * (48 if pol else 36) + 28  # compulsory RayStorage traffic of trace()
@@ -372,10 +561,14 @@ def main():
             "detector": {"rays_per_s": N / t_det, "ms": 1e3 * t_det, "allreduce_ms": 1e3 * t_red,
                          "image_power_all_ranks": total_power},
         }
+        if cfgs is not None:
+            out["configs"] = cfgs
+        if sharded is not None:
+            out["c4_sharded"] = sharded
         if other is not None:
             out["no_pol"] = other  # BASELINE config C2 is quoted with polarisation on and off: the other setting
-        if not args.skip_cpu and world == 1:  # CPU leg on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(RT, scene, args.cpu_seconds)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
             out["cpu_baseline"]["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["value_one_core"]
         print(json.dumps(out), flush=True)
     if use_dist:

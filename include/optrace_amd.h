@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 6
+#define OT_ABI_VERSION 7
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -474,9 +474,10 @@ int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const 
  *                                  ot_render_accumulate (sums in another order).  Frees the handle, also on failure.
  *   ot_detector_image_auto_cancel  frees the handle without an image.
  *
- * extent4 / result6: device-visible host memory (pinned, mapped) or device memory.  Both calls that report wait for the
- * stream before they return.  Between begin and finish the calling thread must not start another automatic image on the
- * same stream (the records live in the kept scratch block of that thread and stream, see ot_scratch_trim). */
+ * extent4 / result6: device-visible host memory (pinned, mapped) or device memory (every entry is written by a kernel).
+ * Both calls that report wait for the stream before they return.  The records of an image live in a scratch block the
+ * handle LEASES from begin until finish / cancel: automatic images may be open side by side (also on one stream, each
+ * gets a block of its own), ot_scratch_trim leaves an open image alone.  finish must be given the stream of begin. */
 typedef struct ot_auto_image ot_auto_image;
 int ot_detector_extent_sample(const ot_rays* rays, int64_t first, int64_t count, const ot_surface* detector,
                               int32_t projection, int32_t stride, double* extent4, void* stream);
@@ -487,11 +488,17 @@ int ot_detector_image_auto_finish(ot_auto_image* image, const double extent[4], 
                                   void* stream);
 void ot_detector_image_auto_cancel(ot_auto_image* image);
 
-/* The binning paths keep their scratch (up to ~25 B per ray and image) between calls: one block per calling thread,
- * device, stream and purpose, grown on demand (calls on one stream run in order, so a block serves call after call).
- * ot_scratch_trim waits for the device and returns all of it to the driver (for a caller whose own allocator needs
- * the room). */
+/* The binning paths keep their scratch (up to ~25 B per ray and image) between calls: blocks keyed by device, stream
+ * and purpose, grown on demand (calls on one stream run in order, so a block serves call after call), not tied to the
+ * thread that created them.  A call leases its block until its last launch is enqueued; a block on lease is neither
+ * handed to another caller nor freed.  The pool keeps at most a cap of bytes (64 GB; OT_SCRATCH_CAP_GB in the
+ * environment, or ot_scratch_set_cap): beyond it, and when an allocation fails, idle blocks go least recently used
+ * first.  ot_scratch_trim waits for the device and returns every IDLE block to the driver (for a caller whose own
+ * allocator needs the room); ot_scratch_stats reports bytes kept, blocks and blocks on lease.  All three are
+ * thread-safe. */
 int ot_scratch_trim(void);
+int ot_scratch_set_cap(int64_t bytes);
+int ot_scratch_stats(int64_t* kept_bytes, int32_t* blocks, int32_t* leased);
 
 /* SphericalSurface.sphere_projection (spherical_surface.py:36-97): p (n,3) F-order -> out (n,3) F-order */
 int ot_sphere_projection(const ot_surface* surf, int32_t projection, int64_t n, const double* p, double* out,

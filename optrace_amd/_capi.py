@@ -152,6 +152,8 @@ SIGNATURES = {
     "ot_detector_image_auto_finish": (C.c_int, [vp, C.POINTER(C.c_double), i32, i32, vp, vp]),
     "ot_detector_image_auto_cancel": (None, [vp]),
     "ot_scratch_trim": (C.c_int, []),
+    "ot_scratch_set_cap": (C.c_int, [i64]),
+    "ot_scratch_stats": (C.c_int, [C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
     "ot_sphere_projection": (C.c_int, [C.POINTER(Surface), i32, i64, vp, vp, vp]),
     "ot_image_convert": (C.c_int, [vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]),
     "ot_image_convolve": (C.c_int, [vp, i32, i32, vp, i32, vp, vp]),
@@ -171,7 +173,7 @@ SIGNATURES = {
 
 FOCUS_WS = 16  # OT_FOCUS_WS
 HIT_PIECES = 1024  # OT_HIT_PIECES
-ABI_VERSION = 6  # OT_ABI_VERSION
+ABI_VERSION = 7  # OT_ABI_VERSION
 ERR_UNSUPPORTED = -3  # OT_ERR_UNSUPPORTED
 
 _lib = None

@@ -50,6 +50,18 @@ def from_f_order(t: torch.Tensor, n: int, ncomp: int) -> np.ndarray:
     return t.cpu().numpy().reshape(ncomp, n).T
 
 
+def alloc_retry(make):
+    """make() -> device tensor(s).  The library keeps its binning scratch between calls in a pool of its own
+    (csrc/ot_scratch.hpp) that torch's allocator cannot see: when a torch allocation runs out of memory the idle part of
+    that pool and torch's cached blocks go back to the driver and the allocation is tried once more."""
+    try:
+        return make()
+    except torch.OutOfMemoryError:
+        _capi.check(_capi.load_library().ot_scratch_trim())
+        torch.cuda.empty_cache()
+        return make()
+
+
 _mailbox: dict = {}
 
 

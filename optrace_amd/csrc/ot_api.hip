@@ -20,6 +20,7 @@
 #include "ot_image.hpp"
 #include "ot_render_tiles.hpp"
 #include "ot_scene.hpp"
+#include "ot_scratch.hpp"
 #include "ot_selftest.hpp"
 #include "ot_spectrum.hpp"
 #include "ot_trace.hpp"
@@ -1232,6 +1233,9 @@ extern "C" int ot_refraction_index(const ot_medium* medium, const double* table_
 }
 
 // ---- detector + render -------------------------------------------------------------------------------------
+enum { OT_WS_RENDER = 0, OT_WS_FUSED = 1, OT_WS_FUSED_HITS = 2, OT_WS_AUTO = 3, OT_WS_DET = 4 };
+static ot_scratch::Lease workspace(int purpose, size_t bytes, hipStream_t st);
+
 extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_req* reqs,
                                       int32_t n_reqs, void* stream) {
     if (!rays || !reqs || n_reqs < 1) return fail(OT_ERR_INVALID, "ot_detector_hits: null argument");
@@ -1260,25 +1264,14 @@ extern "C" int ot_detector_hits_multi(const ot_rays* rays, int64_t first, int64_
         n_ext += reqs[k].extent4 != nullptr;
     }
     if (count == 0) return OT_OK;
-    // scratch: the detector records, then the extent slot tables -- a few KB, kept per thread and stream for the life of
-    // the process (launches on one stream run in order, so the block can serve call after call).  It used to come from
-    // the stream-ordered pool; that cost 0.2 ms per call, and 7-58 ms whenever the driver was still busy with memory a
-    // large free had returned to it (profiles/r3/readback_after_free.txt).
+    // scratch: the detector records, then the extent slot tables -- a few KB from the kept pool (it used to come from the
+    // stream-ordered pool; that cost 0.2 ms per call, and 7-58 ms whenever the driver was still busy with memory a large free
+    // had returned to it, profiles/r3/readback_after_free.txt)
     const size_t o_slots = align_up(sizeof(DetOne) * OT_DET_MAX);
     const size_t total = o_slots + sizeof(unsigned long long) * 4 * OT_EXT_SLOTS * (size_t)OT_DET_MAX;
-    char* scratch = nullptr;
-    {
-        struct Block { int dev; hipStream_t st; char* p; };
-        static thread_local std::vector<Block> blocks;
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        for (auto& b : blocks)
-            if (b.dev == dev && b.st == st) scratch = b.p;
-        if (!scratch) {
-            HIP_TRY(hipMalloc((void**)&scratch, total));
-            blocks.push_back({dev, st, scratch});
-        }
-    }
+    const ot_scratch::Lease lease = workspace(OT_WS_DET, total, st);
+    if (!lease) return fail(OT_ERR_HIP, "ot_detector_hits: no scratch memory");
+    char* scratch = lease.p();
     unsigned long long* slots = (unsigned long long*)(scratch + o_slots);
     int e = 0;
     for (int k = 0; k < n_reqs; k++) {
@@ -1362,64 +1355,57 @@ extern "C" int ot_sphere_projection(const ot_surface* surf, int32_t projection, 
     return OT_OK;
 }
 
-// Scratch of the binning paths (hit records, slabs: up to ~25 B per ray and image).  One block per (thread, device,
-// stream, purpose), kept between calls and grown on demand: launches of a stream run in order, so the block of a purpose can
-// serve call after call without a free in between.  It used to come from the stream-ordered pool (hipMallocAsync /
-// hipFreeAsync per call, the pool told to keep 16 GB): that cost ~0.2 ms per call from the second call on and stalled for
-// 7-58 ms while the driver was digesting a large free (profiles/r3/readback_after_free.txt).  torch's allocator, which
-// owns the ray storage, cannot see this memory: ot_scratch_trim() hands all of it back on request.
-#include <mutex>
-enum { OT_WS_RENDER = 0, OT_WS_FUSED = 1, OT_WS_FUSED_HITS = 2, OT_WS_AUTO = 3 };
-struct WorkBlock {
-    std::thread::id tid;
-    int dev, purpose;
-    hipStream_t st;
-    char* p;
-    size_t bytes;
-};
-static std::mutex g_ws_mutex;
-static std::vector<WorkBlock> g_ws;
-
-// -> block of at least `bytes`, or nullptr (out of memory: the callers fall back to paths without scratch)
-static char* workspace(int purpose, size_t bytes, hipStream_t st) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    WorkBlock* b = nullptr;
-    for (auto& w : g_ws)
-        if (w.tid == std::this_thread::get_id() && w.dev == dev && w.purpose == purpose && w.st == st) b = &w;
-    if (b && b->bytes >= bytes) return b->p;
-    if (b) {  // grow: hipFree waits for the work that may still use the old block
-        (void)hipFree(b->p);
-        b->p = nullptr;
-        b->bytes = 0;
-    } else {
-        g_ws.push_back({std::this_thread::get_id(), dev, purpose, st, nullptr, 0});
-        b = &g_ws.back();
-    }
-    const size_t want = bytes + bytes / 8;  // a little room: chunks of slightly different size do not reallocate
-    char* p = nullptr;
-    if (hipMalloc((void**)&p, want) != hipSuccess || !p) {
+// Scratch of the binning paths (hit records, slabs: up to ~25 B per ray and image): ot_scratch.hpp.  One pool per process,
+// blocks keyed by (device, stream, purpose), LEASED for the launches of a call (an automatic image keeps its lease from begin
+// to finish / cancel), kept between calls, capped (OT_SCRATCH_CAP_GB in the environment or ot_scratch_set_cap; 64 GB of the
+// 288), idle blocks freed least recently used first.  torch's allocator, which owns the ray storage, cannot see this memory:
+// ot_scratch_trim() hands the idle part back on request.
+static void* ws_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess || !p) {
         (void)hipGetLastError();
-        if (hipMalloc((void**)&p, bytes) != hipSuccess || !p) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        b->bytes = bytes;
-    } else {
-        b->bytes = want;
+        return nullptr;
     }
-    b->p = p;
     return p;
+}
+static void ws_release(void* p) { (void)hipFree(p); }  // (waits for the work that may still use p)
+static void ws_sync() { (void)hipDeviceSynchronize(); }
+static ot_scratch::Pool& scratch_pool() {
+    static ot_scratch::Pool pool({ws_alloc, ws_release, ws_sync}, [] {
+        const char* v = std::getenv("OT_SCRATCH_CAP_GB");
+        const double gb = v ? std::atof(v) : 64.0;
+        return (size_t)((gb > 0.0 ? gb : 64.0) * 1e9);
+    }());
+    return pool;
+}
+
+// -> lease on a block of at least `bytes` for this device, stream and purpose; empty when out of memory (the callers fall
+// back to paths without scratch)
+static ot_scratch::Lease workspace(int purpose, size_t bytes, hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return {};
+    return ot_scratch::Lease(scratch_pool(), dev, purpose, (void*)st, bytes);
 }
 
 extern "C" int ot_scratch_trim(void) {
     if (int rc = require_device()) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    for (auto& w : g_ws)
-        if (w.p) (void)hipFree(w.p);
-    g_ws.clear();
+    scratch_pool().trim();
+    return OT_OK;
+}
+
+extern "C" int ot_scratch_set_cap(int64_t bytes) {
+    if (bytes < 0) return fail(OT_ERR_INVALID, "ot_scratch_set_cap: negative cap");
+    scratch_pool().set_cap((size_t)bytes);
+    return OT_OK;
+}
+
+extern "C" int ot_scratch_stats(int64_t* kept_bytes, int32_t* blocks, int32_t* leased) {
+    size_t kept = 0;
+    int nb = 0, busy = 0;
+    scratch_pool().stats(&kept, &nb, &busy);
+    if (kept_bytes) *kept_bytes = (int64_t)kept;
+    if (blocks) *blocks = nb;
+    if (leased) *leased = busy;
     return OT_OK;
 }
 
@@ -1503,7 +1489,8 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
     const size_t o_cstart = carve(sizeof(int) * (t.K + 1));
     const size_t o_rec = carve(sizeof(TileRec) * (size_t)n);
     const size_t o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)t.max_chunks);
-    char* ws = workspace(OT_WS_RENDER, off, st);
+    const ot_scratch::Lease lease = workspace(OT_WS_RENDER, off, st);
+    char* ws = lease.p();
     if (!ws) {
         // no room for the hit records (12 B per hit): the direct kernel needs no scratch
         hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, n, px, py, w, wl, a, table, hist, (const int*)nullptr, fill);
@@ -1606,7 +1593,8 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         if (closed && plain) continue;
         // this request alone through ot_detector_hits + ot_render_accumulate, the others through the fused kernels
         const size_t o_hw = align_up(sizeof(double) * 2 * (size_t)count);
-        char* tmp = workspace(OT_WS_FUSED_HITS, o_hw + sizeof(float) * (size_t)count, st);
+        const ot_scratch::Lease hits = workspace(OT_WS_FUSED_HITS, o_hw + sizeof(float) * (size_t)count, st);
+        char* tmp = hits.p();
         if (!tmp) return fail(OT_ERR_HIP, "ot_detector_images: no memory for the hit list");
         ot_detector_req dq;
         dq.detector = q.detector;
@@ -1721,14 +1709,16 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     // one slab per accumulation workgroup: a tile with n chunks takes ceil(n / OT_FUSE_CPW) of them
     const unsigned n_slabs = (unsigned)((capmax + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)Kmax;
     const size_t o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)n_slabs * n_idx);
-    char* ws = workspace(OT_WS_FUSED, off, st);
+    ot_scratch::Lease lease = workspace(OT_WS_FUSED, off, st);
+    char* ws = lease.p();
     if (!ws) {
         if (!KT) return fail(OT_ERR_HIP, "ot_detector_images: no scratch memory");
         // no room for the records: bin directly (needs the flags and the detector table only)
         KT = 0;
         for (auto& f : host) f.tiles_ok = 0;
         off = o_flags + sizeof(int) * 4 * n_reqs + 256;
-        ws = workspace(OT_WS_FUSED, off, st);
+        lease = workspace(OT_WS_FUSED, off, st);
+        ws = lease.p();
         if (!ws) return fail(OT_ERR_HIP, "ot_detector_images: no scratch memory");
     }
     int* flags = (int*)(ws + o_flags);
@@ -1849,6 +1839,7 @@ struct AutoHead {
 
 struct ot_auto_image {
     FuseOne f;  // host copy; the image grid (a, hist) is filled in by finish
+    ot_scratch::Lease lease;  // the records: leased until finish / cancel (neither reused nor trimmed in between)
     char* ws;
     size_t o_tn, o_ts, o_list, o_ws, o_slabs;
     unsigned n_slabs;
@@ -1885,7 +1876,8 @@ extern "C" int ot_detector_extent_sample(const ot_rays* rays, int64_t first, int
     LeafSurface ls;
     if (int rc = ls.init(detector, st)) return rc;
     const AutoHead h;
-    char* ws = workspace(OT_WS_AUTO, h.end, st);
+    const ot_scratch::Lease lease = workspace(OT_WS_AUTO, h.end, st);
+    char* ws = lease.p();
     if (!ws) return fail(OT_ERR_HIP, "ot_detector_extent_sample: no scratch memory");
     FuseOne f;
     auto_fill_detector(f, ls, detector, projection);
@@ -1900,7 +1892,7 @@ extern "C" int ot_detector_extent_sample(const ot_rays* rays, int64_t first, int
     hipLaunchKernelGGL(spec_sample_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, part, (uint32_t)count,
                        (const FuseOne*)(ws + h.o_dets), (uint32_t)stride);
     hipLaunchKernelGGL(spec_result_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)f.g.ext_slots,
-                       (const unsigned int*)nullptr, extent4);
+                       (const unsigned int*)nullptr, 0u, extent4);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // the caller reads extent4 next (and the detector's tables may go)
     return OT_OK;
@@ -1963,7 +1955,8 @@ extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, 
     im->o_ws = carve(sizeof(unsigned int) * (f.K + 1));
     im->n_slabs = (unsigned)((f.cap + OT_FUSE_CPW - 1) / OT_FUSE_CPW) + (unsigned)f.K;
     im->o_slabs = carve(sizeof(double) * OT_TILE_PX * 4 * (size_t)im->n_slabs);
-    char* ws = workspace(OT_WS_AUTO, off, st);
+    im->lease = workspace(OT_WS_AUTO, off, st);
+    char* ws = im->lease.p();
     if (!ws) return fail(OT_ERR_UNSUPPORTED, "ot_detector_image_auto_begin: no memory for the records (take the hit-list path)");
     im->ws = ws;
     im->st = st;
@@ -1997,11 +1990,10 @@ extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, 
         hipLaunchKernelGGL((fuse_tiles_kernel<false, 1, 1, true>), dim3(n_wg), dim3(OT_FUSE_BR), lds_tiles, st, part, (uint32_t)count,
                            dd, 1, f.K, (uint32_t)piece);
     hipLaunchKernelGGL(spec_result_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)f.g.ext_slots,
-                       (const unsigned int*)f.g.esc_n, result6);
+                       (const unsigned int*)f.g.esc_n, f.g.esc_cap, result6);
     HIP_TRY(hipGetLastError());
-    // the caller needs the extent before it can go on: wait here (also: the detector's tables may go, result6[5] is ours)
+    // the caller needs the extent before it can go on: wait here (also: the detector's tables may go)
     HIP_TRY(hipStreamSynchronize(st));
-    result6[5] = (double)f.g.esc_cap;
     *out = im.release();
     return OT_OK;
 }
@@ -2016,8 +2008,7 @@ extern "C" int ot_detector_image_auto_finish(ot_auto_image* im_raw, const double
     if ((int64_t)Nx * Ny > (1ll << 27)) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: image too large");
     hipStream_t st = (hipStream_t)stream;
     if (st != im->st) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: not the stream of ot_detector_image_auto_begin");
-    // (the scratch block of begin is still ours: a block changes only through calls of this thread on this stream)
-    if (workspace(OT_WS_AUTO, 1, st) != im->ws) return fail(OT_ERR_INVALID, "ot_detector_image_auto_finish: the scratch of this image was reused");
+    // (the scratch block of begin is still ours: the handle holds its lease)
     const double* table = observer_table_device();
     if (!table) return fail(OT_ERR_HIP, "could not upload the CIE observer table");
     FuseOne& f = im->f;

@@ -1070,7 +1070,8 @@ __global__ __launch_bounds__(256) void spec_sample_kernel(ot_rays R, uint32_t co
 
 // out[0..3] = extent of the slot tables (+-inf where no hit); with esc_n: out[4] = hits that asked for the escape list
 __global__ __launch_bounds__(64) void spec_result_kernel(const unsigned long long* __restrict__ slots,
-                                                         const unsigned int* __restrict__ esc_n, double* __restrict__ out) {
+                                                         const unsigned int* __restrict__ esc_n, unsigned int esc_cap,
+                                                         double* __restrict__ out) {
     const int k = threadIdx.x;  // one slot table per lane (OT_EXT_SLOTS = 64), then a wave reduction
     const double inf = __builtin_inf();
     double e[4];
@@ -1083,6 +1084,7 @@ __global__ __launch_bounds__(64) void spec_result_kernel(const unsigned long lon
     e[0] = wave_min(e[0]), e[1] = wave_max(e[1]), e[2] = wave_min(e[2]), e[3] = wave_max(e[3]);
     if (k < 4) out[k] = e[k];
     if (k == 4 && esc_n) out[4] = (double)esc_n[0];
+    if (k == 5 && esc_n) out[5] = (double)esc_cap;  // (on the device: result6 may be device memory)
 }
 
 // fuse_accum_kernel for SpecRec chunks: LDS window of tile t = final pixels [ox, ox + 64) x [oy, oy + 64)

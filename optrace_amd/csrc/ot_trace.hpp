@@ -351,10 +351,17 @@ OT_DEV void store_section_next(PlaneBases& b, uint32_t o8, uint32_t o4, const V3
 //      formula per ray-surface and covers "Function" media exactly.
 // `local` = index of the ray in this launch (R's pointers start at the launch's first ray), `ray` = its index in the
 // whole bundle (random-number keys, injected HURB normals).
-template <bool POL, int SPEC, int FEAT, class SC>
+// TAIL (render-only chunks of iterative_render, trace_tail_kernel): no section is stored; `tail` receives the start of the
+// LAST section (position and weight at section nt - 2), the caller takes its end from `r` -- all that a detector behind
+// the last surface needs of a ray (raytracer.py:929-985).
+struct TailState {
+    V3 p;
+    float w;
+};
+template <bool POL, int SPEC, int FEAT, bool TAIL = false, class SC>
 OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, RayState& r,
                       const double* __restrict__ hurb_normals, uint64_t seed, unsigned int* msgs, const double* ltab,
-                      int lj, double* patch_lds) {
+                      int lj, double* patch_lds, TailState* tail = nullptr) {
     constexpr bool TAB = (SPEC == 1);
     constexpr bool FULL = (FEAT & 1) != 0;  // HURB -- and, at hit level 0, ideal lenses and filters
     constexpr int LEVEL = FEAT / 2;         // hit level (ot_device.hpp): closed form / + Illinois search / + spline surfaces
@@ -380,14 +387,21 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
     bool ok = true;
     r.n_cur = (SPEC == 2) ? lrow[(3 * sc.n_steps) * OT_MAX_LINES] : medium_n<TAB>(media[sc.n0], pool, r.wl);
 #if OT_RUNNING_BASES
-    PlaneBases planes = plane_bases<POL>(R);
-    store_section_next<POL>(planes, o8, o4, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+    PlaneBases planes = {};
+    if (!TAIL) {
+        planes = plane_bases<POL>(R);
+        store_section_next<POL>(planes, o8, o4, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+    }
 #else
-    store_section<POL>(R, o8, o4, 0, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+    if (!TAIL) store_section<POL>(R, o8, o4, 0, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
 #endif
 
     for (int i = 0; i < sc.n_steps; i++) {  // i = index of the section the ray starts this step in
         auto& st = steps[i];
+        if (TAIL && i + 1 == sc.n_steps) {  // the last section starts here
+            tail->p = r.p;
+            tail->w = r.w;
+        }
         auto& sf = surfaces[st.surf];
         const int kind = st.kind;
         V3 pn = r.p;
@@ -468,14 +482,16 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
         if (i + 1 == sc.n_steps)
 #endif
 #if OT_RUNNING_BASES
-        store_section_next<POL>(planes, o8, o4, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+        if (!TAIL) store_section_next<POL>(planes, o8, o4, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
 #else
-        store_section<POL>(R, o8, o4, i + 1, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
+        if (!TAIL) store_section<POL>(R, o8, o4, i + 1, r.p, r.w, r.n_cur, r.polx, r.poly, r.polz);
 #endif
     }
-    const int64_t N = R.N;
-    store_f64(R.s, o8, r.s.x);
-    store_f64(R.s + N, o8, r.s.y);
-    store_f64(R.s + 2 * N, o8, r.s.z);
+    if (!TAIL) {
+        const int64_t N = R.N;
+        store_f64(R.s, o8, r.s.x);
+        store_f64(R.s + N, o8, r.s.y);
+        store_f64(R.s + 2 * N, o8, r.s.z);
+    }
     return ok;
 }

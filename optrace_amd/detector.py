@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._device import require_device, stream_ptr, ptr, to_dev, f_order_flat, from_f_order, mailbox, sync_stream
+from ._device import require_device, stream_ptr, ptr, to_dev, f_order_flat, from_f_order, mailbox, sync_stream, alloc_retry
 
 
 def detector_hits_multi(rays, first: int, count: int, requests: list):
@@ -39,10 +39,12 @@ def detector_hits_multi(rays, first: int, count: int, requests: list):
         compact = bool(rq.get("compact", False)) and not want_z
         cap = _capi.HIT_PIECES * int(lib.ot_hit_piece_len(int(count))) if compact else count  # entries per plane
         no_pos = compact and bool(rq.get("weights_only", False))  # (detector spectrum: weights and wavelengths alone)
-        ph = None if no_pos else torch.empty((3 if want_z else 2) * cap, dtype=torch.float64, device=dev)
-        hw = torch.empty(cap, dtype=torch.float32, device=dev)
-        wl_c = torch.empty(cap, dtype=torch.float32, device=dev) if compact else None
-        fill = torch.zeros(_capi.HIT_PIECES, dtype=torch.int32, device=dev) if compact else None
+        # (hit lists are the large allocations of this stage: out of memory -> the library's kept scratch goes back first)
+        ph, hw, wl_c, fill = alloc_retry(lambda: (
+            None if no_pos else torch.empty((3 if want_z else 2) * cap, dtype=torch.float64, device=dev),
+            torch.empty(cap, dtype=torch.float32, device=dev),
+            torch.empty(cap, dtype=torch.float32, device=dev) if compact else None,
+            torch.zeros(_capi.HIT_PIECES, dtype=torch.int32, device=dev) if compact else None))
         ext = None
         if rq["want_extent"]:
             ext = 2 * n + 4 * k  # word offset in the mailbox

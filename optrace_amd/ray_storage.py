@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from .base import BaseClass
-from ._device import require_device, stream_ptr
+from ._device import require_device, stream_ptr, alloc_retry
 from ._warn import warning
 from . import misc
 
@@ -141,13 +141,7 @@ class RayStorage(BaseClass):
                     "wl": torch.empty(Np, dtype=torch.float32, device=dev),
                     "pol": None if no_pol else torch.empty(3 * nt * Np, dtype=torch.float32, device=dev),
                 }
-            try:
-                d["_dev"] = alloc()
-            except torch.OutOfMemoryError:
-                # the library keeps its binning scratch between calls (ot_api.hip::workspace): torch's allocator cannot see it
-                _capi.check(_capi.load_library().ot_scratch_trim())
-                torch.cuda.empty_cache()
-                d["_dev"] = alloc()
+            d["_dev"] = alloc_retry(alloc)  # (out of memory: the library's kept binning scratch goes back first)
             d["_rays_c"] = None
         d["_N"], d["_Np"], d["_nt"] = N, Np, nt
         d["_host"] = {}

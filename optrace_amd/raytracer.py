@@ -31,7 +31,7 @@ from .render_image import RenderImage
 from .spectrum import LightSpectrum
 from .geometry.ray_source import RaySource
 from .scene import CompiledScene, tracing_elements
-from ._device import require_device, stream_ptr, ptr
+from ._device import require_device, stream_ptr, ptr, alloc_retry
 from ._warn import warning
 from . import detector as _detector
 from . import checks as _checks
@@ -92,13 +92,14 @@ class Raytracer(Group):
         self._source_cache = None  # (key, SourceTable): device copy of the source records, reused while unchanged
         self._fast = None  # what the last full trace established, valid while base.mutation_epoch() stands still
         self._msgs_host = None
+        self._kernel_ms_log = None  # a list: every trace appends its kernel's duration (HIP events of the library; bench.py)
         super().__init__(None, n0, **kwargs)
         self._new_lock = True
 
     # bookkeeping of the tracer itself: writing these is not a scene change (base.mutation_epoch)
     _INTERNAL = frozenset(("_msgs", "_last_trace_snapshot", "_scene", "_scene_handle", "_scene_key", "_checked_key",
                            "_rays_known_current", "_source_cache", "geometry_error", "fault_pos", "_fast",
-                           "_msgs_host", "_lock", "_new_lock"))
+                           "_msgs_host", "_kernel_ms_log", "_lock", "_new_lock"))
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key in self._INTERNAL:
@@ -373,6 +374,10 @@ class Raytracer(Group):
             msgs_h = msgs.cpu().numpy()  # (synchronises the stream)
 
         rays_obj.lock()
+        if self._kernel_ms_log is not None:  # (the caller switched the scene's event pair on: ot_scene_set_timing)
+            ms = C.c_double()
+            _capi.check(lib.ot_scene_last_trace_ms(self._scene_handle, C.byref(ms)))
+            self._kernel_ms_log.append(ms.value)
         if msgs_h[-1]:
             raise TimeoutError("Timeout after 200 iterations in hit finding. Try retracing.")
         self._msgs = msgs_h[:-1].reshape(len(self.INFOS), nt).astype(int)
@@ -516,7 +521,7 @@ class Raytracer(Group):
                     raise ValueError("histogram to accumulate into has the wrong shape")
                 hist = tgt.view(-1)
             else:
-                hist = torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=dev)
+                hist = alloc_retry(lambda: torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=dev))
             img._dev = hist.view(Ny, Nx, 4)
             img._host = None
             images.append(img)
@@ -683,7 +688,7 @@ class Raytracer(Group):
         if tw * Nx / img.s[0] > 61 or th * Ny / img.s[1] > 61:  # a tile would not fit its window (ratio snapped further)
             auto.cancel()
             return None
-        hist = torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=require_device())
+        hist = alloc_retry(lambda: torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=require_device()))
         auto.finish(img.extent, Nx, Ny, hist)
         img._dev = hist.view(Ny, Nx, 4)
         img._host = None

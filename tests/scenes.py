@@ -526,3 +526,34 @@ def synthetic_gray_image():
     g = ((x + 2 * y) % 7) / 6.0
     g[4:6, 4:6] = 0.0
     return g
+
+
+def c3_arizona_eye_rgb(ot, seed=31, **rt_args):
+    """BASELINE.json configs[2] / C3 at full size: examples/arizona_eye_model.py:15-57 -- an RGB image source (a synthetic
+    256 x 256 card here, no image files travel) converging onto the Arizona eye model (adaptation 1 / 0.6 D, pupil 4 mm);
+    continuous spectra of the sRGB primaries, aspheric / conic surfaces, spherical retina detector."""
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:256, 0:256]
+    rgb = np.stack([(xx // 32 + yy // 32) % 2 * 0.8 + 0.1, xx / 255., yy / 255.], axis=2) * rng.uniform(0.9, 1, (256, 256, 1))
+    RT = ot.Raytracer(outline=[-10, 10, -10, 10, -610, 28], seed=seed, **rt_args)
+    RT.add(ot.RaySource(ot.RGBImage(rgb, [8.39, 8.39]), divergence="Isotropic", div_angle=0.25,
+                        orientation="Converging", conv_pos=[0, 0, 0], pos=[0, 0, -600]))
+    RT.add(ot.presets.geometry.arizona_eye(adaptation=1 / 0.6, pupil=4))
+    return RT
+
+
+C4_POSITIONS = [[0, 0, z] for z in (30., 32., 34., 36., 38., 39.5)]
+"""image_render_many_rays.py:39-41 renders its detector at several positions: a sweep through the image plane"""
+
+
+def c4_image_render(ot, seed=41, **rt_args):
+    """BASELINE.json configs[3] / C4: examples/image_render_many_rays.py:11-41 -- RGB image source -> biconvex lens ->
+    square detector, no_pol."""
+    RT = ot.Raytracer(outline=[-8, 8, -8, 8, 0, 40], no_pol=True, seed=seed, **rt_args)
+    RT.add(ot.RaySource(ot.RGBImage(synthetic_rgb_image(), [4, 3]), divergence="Isotropic",
+                        div_angle=np.rad2deg(np.arctan(3 / 12) * 1.2), s=[0, 0, 1], pos=[0, 0, 0],
+                        orientation="Converging", conv_pos=[0, 0, 12]))
+    RT.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1, pos=[0, 0, 12],
+                   n=ot.RefractionIndex("Abbe", n=1.5, V=40)))
+    RT.add(ot.Detector(ot.RectangularSurface(dim=[16, 16]), pos=[0, 0, 36]))
+    return RT

@@ -14,26 +14,7 @@ import optrace_amd as ot
 import scenes
 
 
-def c3(ot_):
-    rng = np.random.default_rng(7)
-    yy, xx = np.mgrid[0:256, 0:256]
-    rgb = np.stack([(xx // 32 + yy // 32) % 2 * 0.8 + 0.1, xx / 255., yy / 255.], axis=2) * rng.uniform(0.9, 1, (256, 256, 1))
-    RT = ot_.Raytracer(outline=[-10, 10, -10, 10, -610, 28], seed=31)
-    RT.add(ot_.RaySource(ot_.RGBImage(rgb, [8.39, 8.39]), divergence="Isotropic", div_angle=0.25,
-                         orientation="Converging", conv_pos=[0, 0, 0], pos=[0, 0, -600]))
-    RT.add(ot_.presets.geometry.arizona_eye(adaptation=1 / 0.6, pupil=4))
-    return RT
-
-
-def c4(ot_):
-    RT = ot_.Raytracer(outline=[-8, 8, -8, 8, 0, 40], no_pol=True, seed=41)
-    RT.add(ot_.RaySource(ot_.RGBImage(scenes.synthetic_rgb_image(), [4, 3]), divergence="Isotropic",
-                         div_angle=np.rad2deg(np.arctan(3 / 12) * 1.2), s=[0, 0, 1], pos=[0, 0, 0],
-                         orientation="Converging", conv_pos=[0, 0, 12]))
-    RT.add(ot_.Lens(ot_.SphericalSurface(r=3, R=8), ot_.SphericalSurface(r=3, R=-8), de=0.1, pos=[0, 0, 12],
-                    n=ot_.RefractionIndex("Abbe", n=1.5, V=40)))
-    RT.add(ot_.Detector(ot_.RectangularSurface(dim=[16, 16]), pos=[0, 0, 36]))
-    return RT
+c3, c4 = scenes.c3_arizona_eye_rgb, scenes.c4_image_render  # (the builders live with the other scenes)
 
 
 CONFIGS = {
