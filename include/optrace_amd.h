@@ -353,6 +353,27 @@ int ot_generate_and_trace_host(const ot_scene* scene, const ot_sources* src,
                                const ot_source_range* ranges, int32_t n_ranges, uint64_t seed,
                                const ot_rays* rays, int64_t* msgs_host, void* stream);
 
+/* Render-only chunk of Raytracer.iterative_render (raytracer.py:1235-1267: the images of all chunks are summed, only
+ * the LAST chunk's rays stay in the tracer): n_rays rays are generated and traced as by ot_generate_and_trace_host,
+ * but no section is stored.  Every ray that is still alive behind the last surface leaves its last section -- the
+ * positions at sections nt-2 and nt-1, the weight at nt-2, the wavelength: what a detector behind the last surface
+ * reads of a ray (raytracer.py:929-985) -- in `tail`, a ray storage with TWO sections (tail->nt == 2; p (N, 2, 3), w
+ * (N, 2): section 1 is written as 0, every ray ends absorbed --, wl (N); s, n, pol unused, may be NULL) of
+ * N = tail->N >= ot_tail_capacity(n_rays) slots, N a multiple of 65536.  The living rays are gathered wave by wave
+ * into 1024 interleaved pieces (fill: device uint32[1024], scratch of the call); result2 (device-visible HOST memory,
+ * int64[2]) receives the number of leading slots in use (a multiple of 65536; slots in it without a ray carry weight
+ * 0) and the number of living rays.  The detector entry points (ot_detector_images, ot_detector_hits_multi,
+ * ot_detector_extent_sample, ot_detector_image_auto_*) take `tail` with count = result2[0] like any other storage;
+ * they give the images of the stored path for every detector that lies behind the last tracing surface.  The order
+ * of the rays is not the order of generation (no per-source ranges).  msgs_host as for
+ * ot_generate_and_trace_host.  Scenes whose surfaces need the numeric hit search: OT_ERR_UNSUPPORTED
+ * (ot_scene_tail_supported tells beforehand). */
+int64_t ot_tail_capacity(int64_t n_rays);
+int ot_scene_tail_supported(const ot_scene* scene);
+int ot_generate_and_trace_tail(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,
+                               int32_t n_ranges, uint64_t seed, int64_t n_rays, const ot_rays* tail, uint32_t* fill,
+                               int64_t* result2, int64_t* msgs_host, void* stream);
+
 /* Measurement aid (the reference times `RT.trace` with perf_counter, tests/benchmark.py:81-86): with timing
  * on, every tracing launch of this scene records one HIP event right before and one right after the tracing
  * kernel on the launch stream; ot_scene_last_trace_ms waits for the later one and returns the kernel's

@@ -135,6 +135,9 @@ SIGNATURES = {
     "ot_trace": (C.c_int, [vp, C.POINTER(Rays), vp, u64, vp, vp]),
     "ot_generate_and_trace": (C.c_int, [vp, vp, C.POINTER(SourceRange), i32, u64, C.POINTER(Rays), vp, vp]),
     "ot_generate_and_trace_host": (C.c_int, [vp, vp, C.POINTER(SourceRange), i32, u64, C.POINTER(Rays), vp, vp]),
+    "ot_tail_capacity": (i64, [i64]),
+    "ot_scene_tail_supported": (C.c_int, [vp]),
+    "ot_generate_and_trace_tail": (C.c_int, [vp, vp, C.POINTER(SourceRange), i32, u64, i64, C.POINTER(Rays), vp, vp, vp, vp]),
     "ot_scene_set_timing": (C.c_int, [vp, i32]),
     "ot_scene_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "ot_surface_find_hit": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp, vp, vp]),

@@ -1034,14 +1034,22 @@ extern "C" int ot_rays_generate(const ot_sources* src, const ot_source_range* ra
 
 // msgs: device counters the launch ADDS to, or nullptr: the counters of this launch alone go to the scene's pinned
 // host buffer (created on first use)
+// tail: render-only launch (trace_tail_kernel) of n_tail rays -- `rays` is not used then
 static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const RangeArgs* rg, const ot_rays* rays,
-                        const double* hurb_normals, uint64_t seed, int64_t* msgs, void* stream) {
+                        const double* hurb_normals, uint64_t seed, int64_t* msgs, void* stream, const TailOut* tail = nullptr,
+                        int64_t n_tail = 0) {
     ot_scene* sc = const_cast<ot_scene*>(sc_c);
     if (!sc) return fail(OT_ERR_INVALID, "ot_trace: null argument");
     bool pol = !sc->h.no_pol;
-    if (int rc = check_rays(rays, pol)) return rc;
-    if (rays->nt != sc->h.nt) return fail(OT_ERR_INVALID, "ray storage has " + std::to_string(rays->nt) +
-                                                             " sections, the scene needs " + std::to_string(sc->h.nt));
+    ot_rays tail_rays = {};
+    if (tail) {
+        tail_rays.N = n_tail;
+        rays = &tail_rays;
+    } else {
+        if (int rc = check_rays(rays, pol)) return rc;
+        if (rays->nt != sc->h.nt) return fail(OT_ERR_INVALID, "ray storage has " + std::to_string(rays->nt) +
+                                                                 " sections, the scene needs " + std::to_string(sc->h.nt));
+    }
     const int n_cnt = OT_N_INFOS * sc->h.nt + 1;
     if (!msgs && !sc->pin_msgs) {
         HIP_TRY(hipHostMalloc((void**)&sc->pin_msgs, sizeof(unsigned long long) * (size_t)n_cnt,
@@ -1088,8 +1096,10 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
         L.st = st;
         L.sc = sc->d;
         L.part = *rays;
-        L.part.p += base; L.part.s += base; L.part.w += base; L.part.n += base; L.part.wl += base;
-        if (L.part.pol) L.part.pol += base;
+        if (!tail) {
+            L.part.p += base; L.part.s += base; L.part.w += base; L.part.n += base; L.part.wl += base;
+            if (L.part.pol) L.part.pol += base;
+        }
         L.sd = sd;
         L.rg = &r;
         L.hurb_normals = hurb_normals;
@@ -1099,6 +1109,11 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
         L.pol = pol;
         L.gen = src != nullptr;
         L.spec = (src && lines) ? 2 : (tab ? 1 : 0);
+        if (tail) {  // (ot_generate_and_trace_tail has checked the feature level)
+            if (feat == OT_FEAT(OT_HIT_CLOSED, 0)) launch_trace_tail_feat<OT_FEAT(OT_HIT_CLOSED, 0)>(L, *tail);
+            else launch_trace_tail_feat<OT_FEAT(OT_HIT_CLOSED, 1)>(L, *tail);
+            continue;
+        }
         switch (feat) {
             case OT_FEAT(OT_HIT_CLOSED, 0): launch_trace_feat<OT_FEAT(OT_HIT_CLOSED, 0)>(L); break;
             case OT_FEAT(OT_HIT_CLOSED, 1): launch_trace_feat<OT_FEAT(OT_HIT_CLOSED, 1)>(L); break;
@@ -1146,6 +1161,88 @@ extern "C" int ot_generate_and_trace_host(const ot_scene* scene, const ot_source
     if (int rc = make_ranges(ranges, n_ranges, src, rays->N, &rg)) return rc;
     if (int rc = launch_trace(scene, src, rg, rays, nullptr, seed, nullptr, stream)) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::memcpy(msgs_host, scene->pin_msgs, sizeof(int64_t) * (size_t)(OT_N_INFOS * scene->h.nt + 1));
+    return OT_OK;
+}
+
+// One workgroup per piece: rows in use = ceil(max fill / 64); the slots of this piece between its fill and the end of the
+// last row in use get weight 0 and finite positions.  Workgroup 0 reports result2 = {slots in use, living rays}.
+__global__ __launch_bounds__(256) void tail_seal_kernel(TailOut T, long long* __restrict__ result2) {
+    __shared__ unsigned int s_max[256];
+    __shared__ unsigned long long s_sum[256];
+    unsigned int mx = 0;
+    unsigned long long sum = 0;
+    for (int k = threadIdx.x; k < OT_TAIL_PIECES; k += 256) {
+        const unsigned int f = T.fill[k];
+        mx = f > mx ? f : mx;
+        sum += f;
+    }
+    s_max[threadIdx.x] = mx;
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s_max[threadIdx.x] = s_max[threadIdx.x] > s_max[threadIdx.x + o] ? s_max[threadIdx.x] : s_max[threadIdx.x + o];
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    const unsigned int rows = (s_max[0] + 63u) >> 6;
+    const unsigned int piece = blockIdx.x;
+    const int64_t N = T.cap;
+    for (unsigned int q = T.fill[piece] + threadIdx.x; q < rows * 64u; q += 256) {
+        const int64_t slot = (((int64_t)(q >> 6) * OT_TAIL_PIECES + piece) << 6) + (q & 63u);
+        for (int c = 0; c < 6; c++) T.p[slot + c * N] = 0.0;
+        T.w[slot] = 0.f;
+        T.w[N + slot] = 0.f;
+        T.wl[slot] = 0.f;
+    }
+    if (piece == 0 && threadIdx.x == 0) {
+        result2[0] = (long long)rows * 64 * OT_TAIL_PIECES;
+        result2[1] = (long long)s_sum[0];
+    }
+}
+
+// Render-only chunk of Raytracer.iterative_render (raytracer.py:1235-1267: only the last chunk's rays are kept): n_rays
+// rays are generated and traced without storing a section; the last section of every ray that is alive behind the last
+// surface goes to the compact two-section storage `tail` (ot_trace_kernel.hpp::trace_tail_kernel).  Synchronous like
+// ot_generate_and_trace_host.
+extern "C" int64_t ot_tail_capacity(int64_t n_rays) {
+    if (n_rays < 0) return 0;
+    const int64_t waves = (n_rays + 63) / 64;
+    return 65536 * std::max<int64_t>(1, (waves + OT_TAIL_PIECES - 1) / OT_TAIL_PIECES);
+}
+
+extern "C" int ot_scene_tail_supported(const ot_scene* scene) {
+    return scene && scene->hit_level == OT_HIT_CLOSED ? 1 : 0;
+}
+
+extern "C" int ot_generate_and_trace_tail(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,
+                                          int32_t n_ranges, uint64_t seed, int64_t n_rays, const ot_rays* tail,
+                                          uint32_t* fill, int64_t* result2, int64_t* msgs_host, void* stream) {
+    if (!scene || !src || !tail || !fill || !result2 || !msgs_host)
+        return fail(OT_ERR_INVALID, "ot_generate_and_trace_tail: null argument");
+    if (n_rays < 1) return fail(OT_ERR_INVALID, "ot_generate_and_trace_tail: no rays");
+    if (scene->hit_level != OT_HIT_CLOSED)
+        return fail(OT_ERR_UNSUPPORTED, "ot_generate_and_trace_tail: scenes with a numeric hit search take ot_generate_and_trace");
+    if (tail->nt != 2 || !tail->p || !tail->w || !tail->wl)
+        return fail(OT_ERR_INVALID, "ot_generate_and_trace_tail: the tail storage has two sections and needs p, w and wl");
+    if (tail->N < ot_tail_capacity(n_rays) || tail->N % 65536)
+        return fail(OT_ERR_INVALID, "ot_generate_and_trace_tail: tail storage smaller than ot_tail_capacity(n_rays)");
+    const RangeArgs* rg = nullptr;
+    if (int rc = make_ranges(ranges, n_ranges, src, n_rays, &rg)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    TailOut T;
+    T.p = tail->p;
+    T.w = tail->w;
+    T.wl = tail->wl;
+    T.fill = fill;
+    T.cap = tail->N;
+    HIP_TRY(hipMemsetAsync(fill, 0, sizeof(uint32_t) * OT_TAIL_PIECES, st));
+    if (int rc = launch_trace(scene, src, rg, nullptr, nullptr, seed, nullptr, stream, &T, n_rays)) return rc;
+    hipLaunchKernelGGL(tail_seal_kernel, dim3(OT_TAIL_PIECES), dim3(256), 0, st, T, (long long*)result2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
     std::memcpy(msgs_host, scene->pin_msgs, sizeof(int64_t) * (size_t)(OT_N_INFOS * scene->h.nt + 1));
     return OT_OK;
 }

@@ -372,7 +372,9 @@ OT_DEV bool trace_ray(SC& sc, const ot_rays& R, uint32_t local, uint64_t ray, Ra
     constexpr bool IDEAL_FILTER = FULL || LEVEL >= OT_HIT_ILLINOIS;
     constexpr bool NUMERIC = LEVEL >= OT_HIT_ILLINOIS;
     constexpr bool SPLINE = LEVEL >= OT_HIT_SPLINE;
-    // lj = line index of this ray (SPEC == 2), straight from the generator
+    // lj = line index of this ray (SPEC == 2): found by the kernel by comparing the generated wavelength with the <= 8
+    // entries of the line table in LDS (trace_kernel; seven LDS compares per ray, measured against carrying the index out of
+    // generate_ray: no difference)
     const double* lrow = ltab + OT_MAX_LINES + lj;  // row 0 of this lane's column
     const uint32_t o8 = local * 8u, o4 = local * 4u;
     // numeric surfaces: this lane's coefficient patch in LDS (ot_spline.hpp::PatchCache)

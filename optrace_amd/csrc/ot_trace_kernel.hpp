@@ -162,9 +162,12 @@ OT_DEV bool generate_lane(const RangeArgs& rg, const SourceDev* __restrict__ sou
 // Raytracer.trace: optional on-the-fly generation, then all steps.  One ray per lane, 256-thread workgroups
 // (4 wave64); template switches select a kernel that only contains what the scene needs:
 //   POL  polarisation tracked          GEN  rays generated in registers (no section-0 round trip)
-//   TAB  tabulated media/filters or injected HURB normals (per-lane global loads inside the loop)
-//   FEAT 0: conic / flat surfaces and plain apertures only (82 VGPRs)   1: + ideal lenses, filters, HURB (127)
-//        2: + surfaces that need the numeric hit search: aspheres, tilted, spline surfaces (206)
+//   SPEC 0 dispersion formulas only   1 + tabulated media / filters or injected HURB normals (per-lane global loads inside the
+//        loop)   2 discrete spectra: n, n1 / n2 and filter transmissions per line, staged in LDS
+//   FEAT = OT_FEAT(hit level, full), six levels (below): hit level 0 flat and conic surfaces, 1 + aspheres and tilted
+//        surfaces (Illinois search on closed-form sags), 2 + spline surfaces; full = HURB (at hit level 0 also ideal lenses and
+//        filters).  Registers / waves per SIMD of every variant: profiles/r3/resource_usage.txt (level 0: 60-92 / 5-8, the
+//        bench kernel <true, true, 2, 0> 74 / 6; level 5: 205-212 / 2)
 // Event counters go wave -> LDS (per workgroup) -> one of OT_CNT_SLOTS global slot tables (blockIdx % slots) ->
 // reduce_counters_kernel, so that no two workgroups hammer the same address (see count_event).
 // The launch covers the rays [ray_base, ray_base + count) of the bundle; R's pointers are advanced to ray_base by
@@ -242,6 +245,110 @@ __global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT, SPEC, POL)) void trace_ke
         if (cnt[k]) atomicAdd(&slot[k], cnt[k]);
 }
 
+// ---- render-only tracing: the living rays' LAST SECTION instead of every section -------------------------------------
+// `iterative_render` keeps the rays of its last chunk only (raytracer.py:1235-1267): every chunk before it exists to be
+// binned.  A detector behind the last surface sees a ray through its last section alone -- positions at sections nt - 2 and
+// nt - 1, the weight at nt - 2, the wavelength (raytracer.py:929-985) -- and only if the ray is still alive there.  This kernel
+// is trace_kernel with on-device generation and without ANY section store; at the end every wave writes that 56-byte record
+// for its living rays into a compact two-section ray storage (`TailOut`: the layout of ot_rays with nt = 2), which the
+// detector kernels read like any other storage.  C4 (2 surfaces, no_pol): 20 B per traced ray instead of 172 B written, and
+// the detector passes read 20 B instead of 56 B per traced ray.
+// Compaction as for the compact hit lists (ot_api.hip::ot_detector_hits_multi): wave k takes `cnt` slots of piece k mod 1024
+// with ONE returning atomic on that piece's fill count (waves in flight spread over all counters).  The pieces are
+// interleaved in rows of 64 entries -- slot q of piece p lives at ((q >> 6) * 1024 + p) * 64 + (q & 63) -- and fill at the same
+// rate, so the storage is dense up to the fullest piece's row; tail_seal_kernel clears the ragged end (weight 0) and reports
+// the number of slots in use.
+#define OT_TAIL_PIECES 1024
+struct TailOut {
+    double* p;           // (cap, 2, 3) f64, F order like ot_rays.p with nt = 2
+    float* w;            // (cap, 2) f32; section 1 = 0
+    float* wl;           // (cap) f32
+    unsigned int* fill;  // [OT_TAIL_PIECES] slots taken per piece
+    int64_t cap;         // plane stride = 65536 * rows
+};
+
+template <bool POL, int SPEC, int FEAT>
+__global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT, SPEC, POL)) void trace_tail_kernel(
+    const SceneDev* __restrict__ scp, TailOut T, const SourceDev* __restrict__ sources, RangeArgs rg, uint64_t seed,
+    unsigned int* __restrict__ slots, int64_t ray_base, uint32_t count) {
+    extern __shared__ double lds[];  // as in trace_kernel
+    auto& sc = *as_const(scp);
+    const int n_tab = (SPEC == 2) ? (3 * sc.n_steps + 2) * OT_MAX_LINES : 0;
+    double* ltab = lds;
+    unsigned int* cnt = (unsigned int*)(lds + n_tab);
+    const int n_cnt = OT_N_INFOS * sc.nt + 1;
+    for (int k = threadIdx.x; k < n_cnt; k += blockDim.x) cnt[k] = 0u;
+    if (SPEC == 2)
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) ltab[k] = sc.line_tab[k];
+    __syncthreads();
+
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ray = ray_base + (int64_t)local;
+    bool have = local < count;
+    RayState r;
+    TailState tail;
+    tail.w = 0.f;
+    tail.p = {0.0, 0.0, 0.0};
+    r.p = {0.0, 0.0, 0.0};
+    r.wl = 0.f;
+    if (have) {
+        NewRay nr;
+        have = generate_lane<(SPEC != 2)>(rg, sources, ray, seed, !POL, nr);
+        if (have) {
+            r.p = nr.p;
+            r.s = nr.s;
+            r.w = nr.w;
+            r.wl = nr.wl;
+            r.polx = (float)nr.polx;
+            r.poly = (float)nr.poly;
+            r.polz = (float)nr.polz;
+        }
+    }
+    count_event(cnt, sc.nt, OT_INFO_HURB_NEG_DIR, 0, have && !(r.s.z > 0));
+    if (have) {
+        int lj = 0;
+        if (SPEC == 2) {
+            for (int j = 1; j < sc.n_lines; j++)
+                if ((float)ltab[j] == r.wl) lj = j;
+        }
+        const ot_rays none = {};
+        bool ok = trace_ray<POL, SPEC, FEAT, true>(sc, none, local, (uint64_t)ray, r, (const double*)nullptr, seed, cnt, ltab, lj,
+                                                   (double*)nullptr, &tail);
+        if (!ok) cnt[n_cnt - 1] = 1u;
+    }
+    // the living rays of this wave, compacted
+    const bool alive = have && tail.w > 0.f;
+    const unsigned long long m = __ballot(alive);
+    if (m) {
+        const unsigned int n_alive = (unsigned int)__popcll(m);
+        const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+        const uint64_t wave = ((uint64_t)ray_base >> 6) + (local >> 6);
+        const unsigned int piece = (unsigned int)(wave & (OT_TAIL_PIECES - 1));
+        unsigned int q0 = 0;
+        if (rank == 0 && alive) q0 = atomicAdd(&T.fill[piece], n_alive);  // (the first living lane)
+        q0 = __shfl(q0, __ffsll((long long)m) - 1);
+        if (alive) {
+            const unsigned int q = q0 + rank;
+            const int64_t slot = (((int64_t)(q >> 6) * OT_TAIL_PIECES + piece) << 6) + (q & 63u);
+            const int64_t N = T.cap;
+            double* px = T.p + slot;  // element (ray, section, component) at ray + N * (section + 2 * component)
+            px[0] = tail.p.x;
+            px[N] = r.p.x;
+            px[2 * N] = tail.p.y;
+            px[3 * N] = r.p.y;
+            px[4 * N] = tail.p.z;
+            px[5 * N] = r.p.z;
+            T.w[slot] = tail.w;
+            T.w[N + slot] = 0.f;  // every ray ends absorbed (the end aperture): the weight of its last section
+            T.wl[slot] = r.wl;
+        }
+    }
+    __syncthreads();
+    unsigned int* slot_tab = slots + (size_t)(blockIdx.x % OT_CNT_SLOTS) * n_cnt;
+    for (int k = threadIdx.x; k < n_cnt; k += blockDim.x)
+        if (cnt[k]) atomicAdd(&slot_tab[k], cnt[k]);
+}
+
 // Feature levels of the kernel variants.  Bit 0 ("full"): HURB, and at hit level 0 ideal lenses and filters as well (the
 // higher hit levels always carry those two, see trace_ray).  Upper part = hit level:
 //   OT_HIT_CLOSED   flat and conic surfaces (closed-form hit)
@@ -272,6 +379,21 @@ struct TraceLaunch {
 // defined in ot_trace_f<FEAT>.hip through OT_DEFINE_TRACE_LAUNCHER
 template <int FEAT>
 void launch_trace_feat(const TraceLaunch& L);
+// render-only variants (generation on the device, no injected HURB normals): defined in ot_trace_t<FEAT>.hip
+template <int FEAT>
+void launch_trace_tail_feat(const TraceLaunch& L, const TailOut& T);
+
+#define OT_DEFINE_TRACE_TAIL_LAUNCHER(FEAT)                                                                             \
+    template <>                                                                                                         \
+    void launch_trace_tail_feat<FEAT>(const TraceLaunch& L, const TailOut& T) {                                         \
+        const dim3 block(256);                                                                                          \
+        auto go = [&](auto kern) {                                                                                      \
+            hipLaunchKernelGGL(kern, L.grid, block, L.lds, L.st, L.sc, T, L.sd, *L.rg, L.seed, L.slots, L.base, L.count); \
+        };                                                                                                              \
+        if (L.spec == 2) { if (L.pol) go(trace_tail_kernel<true, 2, FEAT>); else go(trace_tail_kernel<false, 2, FEAT>); } \
+        else if (L.spec == 1) { if (L.pol) go(trace_tail_kernel<true, 1, FEAT>); else go(trace_tail_kernel<false, 1, FEAT>); } \
+        else { if (L.pol) go(trace_tail_kernel<true, 0, FEAT>); else go(trace_tail_kernel<false, 0, FEAT>); }           \
+    }
 
 #define OT_DEFINE_TRACE_LAUNCHER(FEAT)                                                                                  \
     template <>                                                                                                         \

@@ -17,6 +17,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ._device import require_device
+
 
 def world() -> tuple[int, int]:
     """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
@@ -184,10 +186,10 @@ def sharded_iterative_render(RT, N: int, detector_index=0, limit=None, projectio
         images = RT.iterative_render(n_local, detector_index=detector_index, limit=limit,
                                      projection_method=projection_method, pos=pos, extent=extent,
                                      _power_scale=n_local / N, _finish=False,
-                                     _agree_extents=lambda raw: allreduce_extents(raw, device=RT.rays._dev["p"].device))
+                                     _agree_extents=lambda raw: allreduce_extents(raw, device=require_device()))
     finally:
         RT.seed = seed0
-    dev = RT.rays._dev["p"].device
+    dev = require_device()
     if ws > 1:
         shapes = {tuple(img._dev.shape) for img in images}
         if len(shapes) == 1 and len(images) > 1:  # the usual case: one exchange for all positions

@@ -56,6 +56,51 @@ class SourceTable:
             self.handle = C.c_void_p()
 
 
+class TailStorage:
+    """Render-only chunks of `Raytracer.iterative_render` (raytracer.py:1235-1267 keeps the rays of the last chunk only):
+    the LAST SECTION of every ray that is alive behind the last surface -- positions at sections nt - 2 and nt - 1, the
+    weight at nt - 2, the wavelength --, gathered by `ot_generate_and_trace_tail` into a compact device storage with the
+    layout of a two-section `RayStorage` (include/optrace_amd.h).  The detector entry points read it like any other
+    storage (`_rays_struct`, `N` slots in use; slots without a ray carry weight 0); the order of the rays is not the
+    order of generation and there are no per-source ranges."""
+
+    def __init__(self) -> None:
+        self._dev = None   # name -> flat device tensor
+        self._cap = 0      # plane stride (slots)
+        self._rays_c = None
+        self.N = 0         # leading slots in use after the last trace
+        self.alive = 0     # living rays among them
+        self.traced = 0    # rays the last trace generated
+
+    def ensure(self, cap: int) -> None:
+        """Buffers for `cap` slots (ot_tail_capacity of the chunk); kept while large enough."""
+        dev = require_device()
+        if self._dev is not None and self._cap >= cap and self._dev["p"].device == dev:
+            return
+        self._dev = self._rays_c = None
+        self._dev = alloc_retry(lambda: {
+            "p": torch.empty(6 * cap, dtype=torch.float64, device=dev),
+            "w": torch.empty(2 * cap, dtype=torch.float32, device=dev),  # (section 1 is written as 0 for every slot in use)
+            "wl": torch.empty(cap, dtype=torch.float32, device=dev),
+            "fill": torch.zeros(1024, dtype=torch.int32, device=dev),
+        })
+        self._cap = int(cap)
+
+    def _rays_struct(self) -> _capi.Rays:
+        if self._rays_c is None:
+            d = self._dev
+            r = _capi.Rays()
+            r.N, r.nt = self._cap, 2
+            r.p, r.w, r.wl = d["p"].data_ptr(), d["w"].data_ptr(), d["wl"].data_ptr()
+            r.s = r.n = r.pol = None
+            self._rays_c = r
+        return self._rays_c
+
+    def release(self) -> None:
+        self._dev = self._rays_c = None
+        self._cap = self.N = self.alive = 0
+
+
 class RayStorage(BaseClass):
 
     _tracked = False  # a result container: filling it must not look like a scene change
@@ -88,8 +133,11 @@ class RayStorage(BaseClass):
 
     # ---- allocation (ray_storage.py:35-90) ---------------------------------------------------------
     def init(self, ray_source_list: list, N: int, nt: int, no_pol: bool, _single_power: float = None,
-             _N_list=None, _rng=None, _power_scale: float = 1.0, _split=None, _keep_ranges: bool = False) -> None:
-        """`_power_scale`: the share of the sources' power this storage carries (one rank's shard of a sharded trace);
+             _N_list=None, _rng=None, _power_scale: float = 1.0, _split=None, _keep_ranges: bool = False,
+             _alloc: bool = True) -> None:
+        """`_alloc=False`: the split, the ranges and the source powers only, no section buffers (the book-keeping of a
+        render-only trace, `TailStorage`).
+        `_power_scale`: the share of the sources' power this storage carries (one rank's shard of a sharded trace);
         `_split`: (N_list, dN, p) precomputed by `split_rays` for exactly these sources and N; `_keep_ranges`: the
         caller knows the sources did not change since the previous init (the range records are reused if the split is
         the same deterministic one)."""
@@ -122,6 +170,10 @@ class RayStorage(BaseClass):
         d["_split_key"] = split_key
 
         N, nt = int(N), int(nt)
+        if not _alloc:
+            d["_dev"], d["_rays_c"], d["_host"] = {}, None, {}
+            d["_N"], d["_Np"], d["_nt"] = N, N, nt
+            return
         Np = -(-N // self.PAD_TO) * self.PAD_TO if N >= self.PAD_FROM else N
         old = self._dev
         reuse = bool(old and self._N == N and self._Np == Np and self._nt == nt and (old["pol"] is None) == bool(no_pol)

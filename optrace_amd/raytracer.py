@@ -25,13 +25,13 @@ from .base import check_type
 from .geometry.elements import Group, Aperture, Detector
 from .geometry.surfaces import Surface, Point, Line, SphericalSurface, RingSurface, SlitSurface
 from .options import global_options
-from .ray_storage import RayStorage
+from .ray_storage import RayStorage, TailStorage
 from .refraction_index import RefractionIndex
 from .render_image import RenderImage
 from .spectrum import LightSpectrum
 from .geometry.ray_source import RaySource
 from .scene import CompiledScene, tracing_elements
-from ._device import require_device, stream_ptr, ptr, alloc_retry
+from ._device import require_device, stream_ptr, ptr, alloc_retry, mailbox
 from ._warn import warning
 from . import detector as _detector
 from . import checks as _checks
@@ -61,7 +61,17 @@ class Raytracer(Group):
     """`iterative_render` with automatic extents: the extents are those of the hits of the reference's FIRST ITERATION, 1 M
     rays (ITER_RAYS_STEP, raytracer.py:40, 1212-1262); everything after is cropped to them.  A chunk here is tens of
     millions of rays: an evenly spread sample of about this many of the first chunk's rays plays the first iteration's part
-    (every k-th wave of 64 rays, `ot_detector_extent_sample`), the rest of the chunk is cropped like the later ones."""
+    (every k-th wave of 64 rays, `ot_detector_extent_sample`), the rest of the chunk is cropped to that extent like the
+    later ones (`_render_detectors` passes the automatic extent as the crop)."""
+    ITER_RENDER_ONLY: bool = True
+    """`iterative_render`: every chunk but the last is traced render-only -- no section is stored, the last section of
+    every ray alive behind the last surface goes to a compact `TailStorage` (56 B per LIVING ray instead of 36-48 B per
+    ray and section), which the detector passes read -- wherever that gives the stored path's images: scenes of flat and
+    conic surfaces (ot_scene_tail_supported), no orientation="Function" source, every detector position behind the last
+    tracing surface.  False: every chunk through the ray storage."""
+    ITER_LAST_RAYS: int = 1 << 22
+    """... and the last chunk, whose rays stay in `self.rays` afterwards like the reference's last iteration of 1 M
+    (raytracer.py:1235-1267), then has this many rays."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
     """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are
     19 M rays of a 15-surface scene with polarisation or 93 M rays of a two-surface scene without."""
@@ -93,13 +103,14 @@ class Raytracer(Group):
         self._fast = None  # what the last full trace established, valid while base.mutation_epoch() stands still
         self._msgs_host = None
         self._kernel_ms_log = None  # a list: every trace appends its kernel's duration (HIP events of the library; bench.py)
+        self._tail_book = None      # RayStorage without buffers: split, ranges and powers of render-only traces
         super().__init__(None, n0, **kwargs)
         self._new_lock = True
 
     # bookkeeping of the tracer itself: writing these is not a scene change (base.mutation_epoch)
     _INTERNAL = frozenset(("_msgs", "_last_trace_snapshot", "_scene", "_scene_handle", "_scene_key", "_checked_key",
                            "_rays_known_current", "_source_cache", "geometry_error", "fault_pos", "_fast",
-                           "_msgs_host", "_kernel_ms_log", "_lock", "_new_lock"))
+                           "_msgs_host", "_kernel_ms_log", "_tail_book", "_lock", "_new_lock"))
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key in self._INTERNAL:
@@ -282,7 +293,7 @@ class Raytracer(Group):
                 tuple(map(id, self.ray_sources)))
 
     def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None, _N_list=None,
-              _chunk: int = 0, _power_scale: float = 1.0) -> None:
+              _chunk: int = 0, _power_scale: float = 1.0, _tail: TailStorage = None) -> None:
         """Trace N rays through the current geometry.
 
         Geometry errors are reported as warnings and set `geometry_error` instead of raising, like the
@@ -290,6 +301,9 @@ class Raytracer(Group):
         (2*n_hurb, N) inject recorded inputs for parity tests; normally rays are generated inside the
         tracing kernel and the remainder of the per-source split is drawn at random like the reference does.
         `_power_scale`: share of the source powers these rays carry (a rank's shard, distributed.py).
+        `_tail`: render-only trace (`iterative_render`, every chunk but the last): no section is stored and `self.rays`
+        stays as it is; the last section of every ray still alive behind the last surface goes to that `TailStorage`
+        (`ot_generate_and_trace_tail`).  Counters and warnings as for a stored trace.
 
         The reference re-reads the whole object graph on every call (raytracer.py:246-278).  Here everything
         derived from it -- geometry checks, the compiled scene, the source table, the snapshot -- is kept while
@@ -297,6 +311,8 @@ class Raytracer(Group):
         an unchanged scene is recognised by one integer comparison, the identities of the list members and the bytes of
         the few small arrays that are still writeable (large ones are read-only or switch the shortcut off).
         """
+        if _tail is not None and _initial_rays is not None:
+            raise ValueError("a render-only trace generates its rays on the device")
         fast = self._fast
         if (fast is not None and fast[0] == _base.mutation_epoch() and fast[1] == self._structure()
                 and not self.geometry_error and all(a.tobytes() == b for a, b in fast[5])):
@@ -324,7 +340,7 @@ class Raytracer(Group):
         dev = require_device()
 
         nt = scene.nt
-        if self.rays.storage_size(N, nt, self.no_pol) > self.MAX_RAY_STORAGE_RAM:
+        if _tail is None and self.rays.storage_size(N, nt, self.no_pol) > self.MAX_RAY_STORAGE_RAM:
             raise RuntimeError(f"More than {self.MAX_RAY_STORAGE_RAM*1e-9:.1f} GB RAM requested. Either decrease"
                                " the number of rays, surfaces or do an iterative render. If your system can handle"
                                " more RAM usage, increase the Raytracer.MAX_RAY_STORAGE_RAM parameter.")
@@ -336,10 +352,14 @@ class Raytracer(Group):
         if self.seed is not None and split[1]:
             rng = np.random.RandomState((int(self.seed) + 1000003 * int(_chunk)) % 2 ** 32)
         rays_obj = self.rays
+        if _tail is not None:  # the split, the ranges and the powers live in a storage object without buffers
+            if self._tail_book is None:
+                self._tail_book = RayStorage()
+            rays_obj = self._tail_book
         # unchanged sources and the same deterministic split as last time: the same range records
         rays_obj.init(self.ray_sources, N, nt, self.no_pol, _N_list=_N_list, _rng=rng, _power_scale=_power_scale,
-                      _split=split, _keep_ranges=fast is not None)
-        rays = rays_obj._rays_struct()
+                      _split=split, _keep_ranges=fast is not None, _alloc=_tail is None)
+        rays = rays_obj._rays_struct() if _tail is None else None
         # a seeded tracer repeats itself call for call; the chunks of one iterative render must differ
         seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.seed is None else int(self.seed) + 1000003 * int(_chunk)
 
@@ -359,8 +379,16 @@ class Raytracer(Group):
                 tab = cache[1]
             rng_c = rays_obj._source_ranges()
             # one synchronous call: launch, wait, counters in host memory (no device-to-host copy)
-            _capi.check(lib.ot_generate_and_trace_host(self._scene_handle, tab.handle, rng_c, len(rng_c), seed,
-                                                       C.byref(rays), msgs_h.ctypes.data, stream_ptr()))
+            if _tail is not None:
+                _tail.ensure(int(lib.ot_tail_capacity(N)))
+                mb_t, mb = mailbox()
+                _capi.check(lib.ot_generate_and_trace_tail(self._scene_handle, tab.handle, rng_c, len(rng_c), seed, N,
+                                                           C.byref(_tail._rays_struct()), ptr(_tail._dev["fill"]),
+                                                           C.c_void_p(mb_t.data_ptr()), msgs_h.ctypes.data, stream_ptr()))
+                _tail.N, _tail.alive, _tail.traced = int(mb[0]), int(mb[1]), N
+            else:
+                _capi.check(lib.ot_generate_and_trace_host(self._scene_handle, tab.handle, rng_c, len(rng_c), seed,
+                                                           C.byref(rays), msgs_h.ctypes.data, stream_ptr()))
         else:
             rays_obj.set_initial_rays(*_initial_rays)
             hn = None
@@ -373,7 +401,8 @@ class Raytracer(Group):
             _capi.check(lib.ot_trace(self._scene_handle, C.byref(rays), ptr(hn), seed, ptr(msgs), stream_ptr()))
             msgs_h = msgs.cpu().numpy()  # (synchronises the stream)
 
-        rays_obj.lock()
+        if _tail is None:
+            rays_obj.lock()
         if self._kernel_ms_log is not None:  # (the caller switched the scene's event pair on: ot_scene_set_timing)
             ms = C.c_double()
             _capi.check(lib.ot_scene_last_trace_ms(self._scene_handle, C.byref(ms)))
@@ -385,8 +414,9 @@ class Raytracer(Group):
             self._msgs[self.INFOS.HURB_NEG_DIR, 0] = 0
             raise RuntimeError("All ray divergences s need to be in positive z-divergence")
         self._show_messages(N)
-        snap["Rays"] = [rays_obj.N, rays_obj.Nt, rays_obj.no_pol]
-        self._last_trace_snapshot = snap
+        if _tail is None:  # (a render-only trace leaves `self.rays` and what is known about them alone)
+            snap["Rays"] = [rays_obj.N, rays_obj.Nt, rays_obj.no_pol]
+            self._last_trace_snapshot = snap
         if fast is None and not writeable and _initial_rays is None and not rays_obj._has_function_orientation:
             # read the counter last: objects this call created itself (the end aperture of the element list) count too
             self._fast = (_base.mutation_epoch(), self._structure(), snap, scene, splits, watch)
@@ -422,18 +452,21 @@ class Raytracer(Group):
                     f"numerical hit finding at detector {detector_index}. "
                     "Where and whether they intersect might be wrong.")
 
-    def _detector_requests(self, specs: list) -> list:
+    def _detector_requests(self, specs: list, rays=None) -> list:
         """Checks of `_hit_detector` (raytracer.py:897-920) and, per spec, everything the device calls need:
-        dicts with Ns, Ne (ray range), surf_desc, projection (name), crop (user extent or None), desc, centre."""
+        dicts with Ns, Ne (ray range), surf_desc, projection (name), crop (user extent or None), desc, centre.
+        `rays`: a `TailStorage` to take the rays from instead of `self.rays` (all its slots, no per-source ranges)."""
         if not self.detectors:
             raise RuntimeError("Detector Missing")
-        self._need_rays()
+        if rays is None:
+            self._need_rays()
         ranges = []
         for sp in specs:  # all indices first: nothing is moved or launched for a bad request
-            ranges.append(self._ray_range(sp.get("source_index")))
+            ranges.append(self._ray_range(sp.get("source_index")) if rays is None else (0, int(rays.N)))
             if not 0 <= sp.get("detector_index", 0) < len(self.detectors):
                 raise IndexError("Invalid detector_index.")
-        self._need_current()
+        if rays is None:
+            self._need_current()
 
         out = []
         for sp, (Ns, Ne) in zip(specs, ranges):
@@ -496,22 +529,29 @@ class Raytracer(Group):
                     out[n] = (ph, hw, wl, extent_out, rq["projection"], ill_count, rq["desc"])
         return out
 
-    def _render_detectors(self, specs: list, limits: list, into: list = None, **kwargs) -> list:
+    def _render_detectors(self, specs: list, limits: list, into: list = None, rays=None, **kwargs) -> list:
         """Detector images whose extents are known beforehand (every spec carries a user extent, or the automatic
         one of `_auto_extents` as "auto_extent"): hit search and
         binning in ONE pass over the ray sections (`ot_detector_images`), up to 8 images per pass; the hit positions
         are never written to memory.  into: per spec a (Ny, Nx, 4) device histogram to add to, or None.
+        `rays`: a `TailStorage` (render-only chunk) instead of `self.rays`.
         -> RenderImages (raytracer.py:1053-1098 for each spec)."""
-        reqs = self._detector_requests(specs)
+        reqs = self._detector_requests(specs, rays)
+        src_rays = self.rays if rays is None else rays
         images, calls = [], {}
         dev = require_device()
         for n, (sp, rq, limit) in enumerate(zip(specs, reqs, limits)):
             label = rq["desc"]
             if sp.get("source_index") is not None:
                 label = f"Rays from RS{sp['source_index']} at {label}"
-            # the image extent: the user extent hits are cropped to, or an automatic one (`_auto_extents`: no crop)
-            img = RenderImage(extent=rq["crop"] if rq["crop"] is not None else sp["auto_extent"],
-                              projection=rq["projection"], long_desc=label)
+            # the image extent: the user extent, or an automatic one (`_auto_extents`); the hits are cropped to it either
+            # way.  An automatic extent of ALL the hits loses none by that; one taken from a sample of the rays or agreed with
+            # other ranks then treats the first chunk of an iterative render like the later ones, which are cropped to this
+            # very extent (`_extent0`, raytracer.py:1262) -- without the crop the margin `_fix_extent` adds around it (and the
+            # band a line-like image is widened to) would collect hits of the first chunk only
+            if rq["crop"] is None:
+                rq["crop"] = np.asarray(sp["auto_extent"], dtype=np.float64)
+            img = RenderImage(extent=rq["crop"], projection=rq["projection"], long_desc=label)
             img._limit = limit
             img._fix_extent()
             Nx, Ny = img._pixel_counts()
@@ -531,7 +571,9 @@ class Raytracer(Group):
         for (Ns, Ne), part_all in calls.items():
             for b in range(0, len(part_all), 8):
                 part = part_all[b:b + 8]
-                ills = _detector.detector_images(self.rays, Ns, Ne - Ns, [r for _, r in part])
+                if Ne <= Ns:  # (a render-only chunk none of whose rays survived)
+                    continue
+                ills = _detector.detector_images(src_rays, Ns, Ne - Ns, [r for _, r in part])
                 for (n, _), ill_count in zip(part, ills):
                     self._warn_ill(ill_count, specs[n].get("detector_index", 0))
         if not kwargs.get("_dont_filter", False):
@@ -540,7 +582,7 @@ class Raytracer(Group):
                     img._apply_rayleigh_filter()
         return images
 
-    def _auto_extents(self, specs: list, agree=None, sample_rays: int = None) -> list:
+    def _auto_extents(self, specs: list, agree=None, sample_rays: int = None, rays=None) -> list:
         """Automatic extents (raytracer.py:1042-1049) of the specs without a user extent, from an extent-only pass over
         the ray sections (no hit list: `detector.detector_extents`, up to 8 detectors per pass).  `agree`: callable
         mapping the (n, 4) array of raw extents (+-inf where no ray hits) to the one every rank uses
@@ -549,21 +591,29 @@ class Raytracer(Group):
         todo = [n for n, sp in enumerate(specs) if sp.get("extent") is None]
         if not todo:
             return specs
-        reqs = self._detector_requests(specs)
+        reqs = self._detector_requests(specs, rays)
+        src_rays = self.rays if rays is None else rays
+        # (a render-only chunk holds the living rays of `traced` generated ones: the sample keeps the stride that
+        # `sample_rays` of the GENERATED rays would have)
+        traced = None if rays is None else int(rays.traced)
         raw = np.empty((len(todo), 4), dtype=np.float64)
+        raw[:] = [np.inf, -np.inf, np.inf, -np.inf]
         groups: dict = {}
         for m, n in enumerate(todo):
             rq = reqs[n]
             count, proj = rq["Ne"] - rq["Ns"], _capi.PROJECTIONS[rq["projection"]]
-            if sample_rays and count >= 2 * sample_rays and _detector.auto_image_supported(rq["surf_desc"], proj):
-                raw[m] = _detector.detector_extent_sample(self.rays, rq["Ns"], count, rq["surf_desc"], proj,
-                                                          count // sample_rays)
+            if count < 1:
+                continue
+            n_gen = count if traced is None else traced
+            if sample_rays and n_gen >= 2 * sample_rays and _detector.auto_image_supported(rq["surf_desc"], proj):
+                raw[m] = _detector.detector_extent_sample(src_rays, rq["Ns"], count, rq["surf_desc"], proj,
+                                                          n_gen // sample_rays)
                 continue
             groups.setdefault((rq["Ns"], rq["Ne"]), []).append(m)
         for (Ns, Ne), ms in groups.items():
             for b in range(0, len(ms), 8):
                 part = ms[b:b + 8]
-                res = _detector.detector_extents(self.rays, Ns, Ne - Ns, [
+                res = _detector.detector_extents(src_rays, Ns, Ne - Ns, [
                     dict(surf_desc=reqs[todo[m]]["surf_desc"], projection=_capi.PROJECTIONS[reqs[todo[m]]["projection"]])
                     for m in part])
                 for m, (ext4, _) in zip(part, res):
@@ -873,6 +923,24 @@ class Raytracer(Group):
         return res, {"pos": pos, "bounds": bounds, "z": r, "cost": vals, "N": N_use}
 
     # ---- iterative rendering (raytracer.py:1134-1279) -------------------------------------------------------
+    def _render_only_applies(self, detector_index: list, pos: list) -> bool:
+        """May the chunks of an iterative render be traced without storing their sections (`ITER_RENDER_ONLY`)?  A
+        detector sees a ray through the section that crosses it (raytracer.py:929-985); behind the last tracing surface
+        that is the ray's last section, which is all a render-only trace keeps."""
+        if any(rs.orientation == "Function" for rs in self.ray_sources):  # (their generation needs a position pre-pass)
+            return False
+        self._compile()
+        if not _capi.load_library().ot_scene_tail_supported(self._scene_handle):
+            return False
+        z_last = max([surf.z_max for surf in self.tracing_surfaces] + [rs.extent[5] for rs in self.ray_sources])
+        for k, p in zip(detector_index, pos):
+            if not 0 <= k < len(self.detectors):  # (reported by the detector pass, after the trace like the reference)
+                return False
+            surf = self.detectors[k].surface
+            if float(p[2]) + (surf.z_min - surf.pos[2]) <= z_last + self.N_EPS:
+                return False
+        return True
+
     def iterative_render(self, N, detector_index=0, limit=None, projection_method="Equidistant", pos=None,
                          extent=None, _power_scale: float = 1.0, _agree_extents=None, _finish: bool = True) -> list:
         """Render detector images from N rays traced in chunks of ITER_RAYS_STEP; images of all chunks
@@ -907,8 +975,25 @@ class Raytracer(Group):
         extentc = per_image(extent, "extent", isinstance(extent, list) and not isinstance(extent[0], (int, float)))
 
         n_sec = len(self.tracing_surfaces) + 2
-        rays_step = self.ITER_RAYS_STEP  # None: sized by storage, below
-        if rays_step is None:
+        if self._pretrace_check(min(N, 1000)):
+            raise RuntimeError("Geometry checks failed. Tracing aborted. Check the warnings.")
+        # Only the rays of the LAST chunk stay in the tracer (raytracer.py:1235-1267).  Every chunk before it is traced
+        # render-only where the scene and the detector positions allow it: no section is stored, the living rays' last
+        # sections go to a compact storage the detector passes read (`trace(_tail=...)`, TailStorage)
+        render_only = self.ITER_RENDER_ONLY and self._render_only_applies(detector_index, pos)
+        rays_step = self.ITER_RAYS_STEP  # None: sized by storage
+        if rays_step is not None:  # the reference's rule (raytracer.py:1216-1217, 1238-1239)
+            iterations = max(N // rays_step, 1)
+            chunks = [rays_step] * (iterations - 1) + [N - (iterations - 1) * rays_step]
+        elif render_only and N > self.ITER_LAST_RAYS:
+            # one stored chunk of ITER_LAST_RAYS at the end; before it render-only chunks as large as ITER_STORAGE_BYTES
+            # of tail storage (60 B per ray at most) and one launch (2^28 rays) allow
+            rest = N - self.ITER_LAST_RAYS
+            most = min(1 << 28, self.ITER_STORAGE_BYTES // 60) // 1024 * 1024
+            k = -(-rest // most)
+            step = -(-(-(-rest // k)) // 1024) * 1024
+            chunks = [step] * (k - 1) + [rest - (k - 1) * step] + [self.ITER_LAST_RAYS]
+        else:
             # chunk = what ITER_STORAGE_BYTES of ray storage hold (the reference's 1 M rays are sized for a few GB of
             # host RAM, raytracer.py:40); chunks of equal size, at least 1 M rays
             step_max = max(1_000_000, self.rays.max_rays_for_size(self.ITER_STORAGE_BYTES, n_sec, self.no_pol))
@@ -919,23 +1004,18 @@ class Raytracer(Group):
                 # every wave's store straddles a line it shares with its neighbour (C4: 66 666 667 rays traced in 4.8
                 # ms, 66 666 688 in 3.4 ms); the last chunk takes what is left
                 rays_step = -(-rays_step // 1024) * 1024
-        else:
-            iterations = max(N // rays_step, 1)
-        step0 = rays_step
+            chunks = [rays_step] * (iterations - 1) + [N - (iterations - 1) * rays_step]
         images: list = []
-
-        if self._pretrace_check(rays_step):
-            raise RuntimeError("Geometry checks failed. Tracing aborted. Check the warnings.")
+        tail = TailStorage() if render_only and len(chunks) > 1 else None
 
         nt = n_sec
         msgs_cum = np.zeros((len(self.INFOS), n_sec), dtype=int)
-        scale0, scaled = 1.0, False
+        n0, scaled = chunks[0], False  # images hold chunks of n0 rays each, unscaled, until `scaled`
 
-        for i in range(iterations):  # one chunk of rays per iteration (raytracer.py:1235-1267)
-            if i == iterations - 1:
-                rays_step += int(N - iterations * rays_step)
+        for i, n_i in enumerate(chunks):  # one chunk of rays per iteration (raytracer.py:1235-1267)
+            src = tail if (tail is not None and i < len(chunks) - 1) else None
             with global_options.no_warnings():
-                self.trace(N=rays_step, _chunk=i, _power_scale=_power_scale)
+                self.trace(N=n_i, _chunk=i, _power_scale=_power_scale, _tail=src)
                 msgs_cum += self._msgs
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
@@ -943,33 +1023,36 @@ class Raytracer(Group):
                 # the caller, or fixed by the first chunk, raytracer.py:1262) hit search and binning are one pass as
                 # well (`ot_detector_images`); otherwise the hit lists (20 B per ray and position, `ot_detector_hits_multi`)
                 # are binned and released before the next group is searched
+                # chunks of the first chunk's size are binned straight into its image (their common factor n0 / N is
+                # applied once at the end); a chunk of another size gets its own histogram and is added with its own
+                # factor (raytracer.py:1247-1267: per-chunk scaling), as is every chunk after it
+                direct = 0 < i and n_i == n0 and not scaled
+                if 0 < i and not direct and not scaled:
+                    for img in images:
+                        img._dev *= n0 / N
+                    scaled = True
                 for j0 in range(0, len(pos), 8):
                     group = list(range(j0, min(j0 + 8, len(pos))))
                     specs = [dict(detector_index=detector_index[j], extent=extentc[j],
                                   projection_method=projection_method[j], pos=pos[j]) for j in group]
-                    # chunks of equal size are binned straight into the image of the first chunk (their common
-                    # factor rays_step / N is applied once at the end); an odd-sized last chunk gets its own
-                    # histogram and is added with its own factor (raytracer.py:1247-1267: per-chunk scaling)
-                    direct = 0 < i and rays_step == step0
                     into = [images[j]._dev if direct else None for j in group]
                     if not all(extentc[j] is not None for j in group):  # first chunk: extents from their own pass
-                        specs = self._auto_extents(specs, agree=_agree_extents, sample_rays=self.ITER_EXTENT_RAYS)
-                    imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, _dont_filter=True)
+                        specs = self._auto_extents(specs, agree=_agree_extents, sample_rays=self.ITER_EXTENT_RAYS, rays=src)
+                    imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, rays=src, _dont_filter=True)
                     for g, j in enumerate(group):
                         img = imgs[g]
                         if i == 0:
                             images.append(img)
                             extentc[j] = img._extent0
-                            scale0 = rays_step / N
                         elif not direct:
-                            images[j]._dev *= scale0
-                            images[j]._dev += img._dev * (rays_step / N)
-                            scaled = True
+                            images[j]._dev.add_(img._dev, alpha=n_i / N)
             finally:
                 self._rays_known_current = False
         if not scaled:
             for img in images:
-                img._dev *= scale0
+                img._dev *= n0 / N
+        if tail is not None:
+            tail.release()
 
         self._msgs = msgs_cum
         if not _finish:  # distributed.sharded_iterative_render: histograms still on the device, summed over the ranks first

@@ -178,9 +178,10 @@ def test_iterative_render_against_reference_images(name, path):
         return orig(N, _initial_rays=init, _hurb_normals=hn, _N_list=g["N_list"])
 
     RT.trace = inject
-    old = ot.Raytracer.ITER_RAYS_STEP
+    old = ot.Raytracer.ITER_RAYS_STEP, ot.Raytracer.ITER_RENDER_ONLY
     ot.Raytracer.ITER_RAYS_STEP = n
-    try:
+    ot.Raytracer.ITER_RENDER_ONLY = False  # recorded rays go through the ray storage (a render-only trace generates its own:
+    try:                                   # tests/test_gpu_render_only.py holds that form to this one, record by record)
         with forced(render_path=path), ot.global_options.no_warnings():
             for di, det in enumerate(RT.detectors):
                 for proj in projections(det)[:2]:
@@ -193,5 +194,5 @@ def test_iterative_render_against_reference_images(name, path):
                     for k, img in enumerate(imgs):
                         check_against_fixture(img, g, f"det{di}/{proj}", f"{name} det{di} {proj} position {k}")
     finally:
-        ot.Raytracer.ITER_RAYS_STEP = old
+        ot.Raytracer.ITER_RAYS_STEP, ot.Raytracer.ITER_RENDER_ONLY = old
         del RT.trace

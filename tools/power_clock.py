@@ -113,8 +113,6 @@ def main():
     if not srcs and not smi_name:
         print("NO power / clock telemetry is readable on this box (no amdgpu hwmon files, no amd-smi / rocm-smi): "
               "the counter-derived clock (tools/clock_probe.sh) is the only evidence.")
-    if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        return
 
     for name, lib in arms:
         env = dict(os.environ, OPTRACE_AMD_LIB=str((ROOT / lib).resolve()))

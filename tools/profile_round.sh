@@ -7,10 +7,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profile
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --skip-cpu > "$OUT/bench_stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu > "$OUT/bench_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu > "$OUT/bench_write.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/sq" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu > "$OUT/bench_sq.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --skip-cpu --skip-configs > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu --skip-configs > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu --skip-configs > "$OUT/bench_write.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/sq" -- python3 "$R/bench.py" --steps 3 --warmup 1 --skip-cpu --skip-configs > "$OUT/bench_sq.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/detector" -- python3 "$R/tools/bench_detector.py" > "$OUT/detector.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys
@@ -25,14 +25,18 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 4) for r in rows]
 # launch order of bench.py: 1 small set-up trace, S settle traces (set-up, untimed: `settle_launches` of the JSON line),
 # W warm-up traces, K timed traces (Raytracer.trace), then raw back-to-back launches and one more trace for the detector image
-line = [l for l in open(os.path.join(out, "bench_stats.log")) if l.startswith("{")]
+log = open(os.path.join(out, "bench_stats.log")).read().splitlines()
+line = [l for l in log if l.startswith("{")]
+if not line:  # bench.py failed under the profiler: say so instead of dying on an index
+    sys.exit("no JSON line in bench_stats.log; its tail:\n" + "\n".join(log[-15:]))
 bl = json.loads(line[-1])
 i0 = 1 + int(bl.get("settle_launches", 0)) + int(bl["warmup"])
+assert i0 + int(bl["steps"]) <= len(ms), f"{len(ms)} traced launches of {main[:40]}, the timed window ends at {i0 + int(bl['steps'])}"
 timed = ms[i0:i0 + int(bl["steps"])]
 json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu   (1 set-up + settle + warm-up + timed Raytracer.trace calls, then raw launches + 1; counts in bench_line)",
            "timed_launch_index_range": [i0, i0 + int(bl["steps"])],
            "kernel": rows[0]["Kernel_Name"][:40], "launch_ms": ms, "timed_mean_ms": sum(timed) / len(timed),
-           "bench_line": json.loads(line[-1]) if line else None}, open(os.path.join(out, "trace_kernel_launches.json"), "w"), indent=1)
+           "bench_line": bl}, open(os.path.join(out, "trace_kernel_launches.json"), "w"), indent=1)
 pmc = {"rays": 10000000, "pol": True, "unit": "KB per launch",
        "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --skip-cpu"}
 for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
