@@ -1881,6 +1881,16 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
                                    dd, KT, (uint32_t)piece);
         } else if (n_reqs == 1) {
             if (small_k) OT_LAUNCH_FUSE(false, 1, 2); else OT_LAUNCH_FUSE(false, 1, 1);
+        } else if (rays->nt == 2) {  // two sections (a tail storage): every hit from the prefetched pair, no section search
+#define OT_LAUNCH_FUSE_PAIR(ND)                                                                                           \
+    do {                                                                                                                  \
+        hipLaunchKernelGGL((fuse_direct_kernel<false, ND>), dim3(blocks), dim3(1024), 0, st, *rays, first, count, dd, n_reqs, table); \
+        if (KT)                                                                                                           \
+            hipLaunchKernelGGL((fuse_tiles_kernel<false, ND, 1, false, true>), dim3(n_wg), dim3(OT_FUSE_BR), lds_tiles, st, part, \
+                               (uint32_t)count, dd, n_reqs, KT, (uint32_t)piece);                                          \
+    } while (0)
+            if (n_reqs <= 2) OT_LAUNCH_FUSE_PAIR(2); else if (n_reqs <= 4) OT_LAUNCH_FUSE_PAIR(4); else OT_LAUNCH_FUSE_PAIR(8);
+#undef OT_LAUNCH_FUSE_PAIR
         } else if (n_reqs <= 2) {
             OT_LAUNCH_FUSE(false, 2, 1);
         } else if (n_reqs <= 4) {

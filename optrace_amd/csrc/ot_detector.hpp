@@ -196,6 +196,30 @@ OT_DEV bool detector_hit_last(DET& D, int nt, bool active, const SectionPair& sp
     return true;
 }
 
+// A storage of TWO sections (the tail storage of render-only traces, ot_trace_kernel.hpp::trace_tail_kernel): everything
+// detector_hit can find out it finds in the prefetched pair -- its section search has one section to choose, its loop one
+// round (raytracer.py:929-985 with nt = 2) -- so the hit is settled without a load and without the search code: the ray
+// ends before the detector (np.all(~bh_zmin & ~bh_zmax)) or starts behind it (np.all(bh_zmin & bh_zmax)): no hit; otherwise
+// the intersection with the one section, void if it lies behind the section's end.  Detectors with a closed-form hit (flat,
+// conic), no sphere projection.  Same values as detector_hit<false, false> on such a storage.
+template <class DET>
+OT_DEV void detector_hit_pair(DET& D, bool active, const SectionPair& sp, const V3& sdir, V3& ph, float& w, bool& valid) {
+    const auto& det = D.det;
+    valid = false;
+    w = 0.f;
+    ph = {0.0, 0.0, 0.0};
+    if (!active) return;
+    const bool ends_before = !(sp.zl >= det.z_min) && !(sp.zl >= det.z_max);
+    const bool starts_behind = sp.zl >= det.z_min && sp.zq >= det.z_min && sp.zq >= det.z_max;
+    if (ends_before || starts_behind) return;
+    const V3 p = {sp.xq, sp.yq, sp.zq};
+    bool ish, ill;
+    find_hit<OT_HIT_CLOSED>(det, p, sdir, ph, ish, ill);
+    w = (ph.z > sp.zl + OT_C_EPS) ? 0.f : sp.wq;  // a hit behind the end of the ray is none (raytracer.py:985)
+    valid = ish && (w > 0);
+    if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
+}
+
 // The hit of one ray on one detector: section search, intersection, projection, user extent.
 // -> valid, ph (projected), w; any_ill / timeout report the numeric hit search.
 // PROJ = false leaves the sphere projections out (their atan / tan polynomials cost ~64 VGPRs of hoisted constants once

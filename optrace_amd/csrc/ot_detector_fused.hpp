@@ -285,7 +285,10 @@ __host__ __device__ static inline size_t fuse_tiles_lds(int KT, int n_det, int r
 
 // SPECX: the speculative-grid form (one detector, closed-form hit): the tile comes from SpecGrid instead of the image's
 // pixel grid, the record is a SpecRec, and the extent of the valid hits is gathered on the way.
-template <bool GENERAL, int NDET, int RPT, bool SPECX = false>
+// PAIR: the storage has two sections (tail storage): detector_hit_pair settles every ray from the prefetched pair, the
+// section search is not compiled in (with eight detectors unrolled it was most of the kernel: 11 700 instructions, 157 scalar
+// registers spilled into vector lanes).
+template <bool GENERAL, int NDET, int RPT, bool SPECX = false, bool PAIR = false>
 __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint32_t count, const FuseOne* __restrict__ dets,
                                                                 int n_det, int KT, uint32_t piece) {
     // the probe's verdicts, read ONCE: a load of spread[0] inside the loop below is a vector-memory operation like the
@@ -394,12 +397,16 @@ __global__ __launch_bounds__(OT_FUSE_BR) void fuse_tiles_kernel(ot_rays R, uint3
                 bool valid = false, ill = false, to = false;
                 // flat detector behind the last surface (the usual case): no section search; the wave takes the general
                 // path only if one of its lanes needs it
-                bool settled = false;
-                if (!GENERAL) settled = detector_hit_last(F, R.nt, act[j], sp[j], sdir, ph, w, valid);
-                if (GENERAL || __ballot(!settled) != 0ull) {
-                    if (!settled) detector_hit<GENERAL, GENERAL>(R, r, act[j], F, sp[j], sdir, ph, w, valid, ill, to);
+                if constexpr (PAIR) {
+                    detector_hit_pair(F, act[j], sp[j], sdir, ph, w, valid);
+                } else {
+                    bool settled = false;
+                    if (!GENERAL) settled = detector_hit_last(F, R.nt, act[j], sp[j], sdir, ph, w, valid);
+                    if (GENERAL || __ballot(!settled) != 0ull) {
+                        if (!settled) detector_hit<GENERAL, GENERAL>(R, r, act[j], F, sp[j], sdir, ph, w, valid, ill, to);
+                    }
+                    if (GENERAL) fuse_count_ill(F, ill, to);
                 }
-                if (GENERAL) fuse_count_ill(F, ill, to);
                 if (!valid) continue;
                 unsigned int local, tile;
                 if constexpr (SPECX) {

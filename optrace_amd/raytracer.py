@@ -69,9 +69,9 @@ class Raytracer(Group):
     ray and section), which the detector passes read -- wherever that gives the stored path's images: scenes of flat and
     conic surfaces (ot_scene_tail_supported), no orientation="Function" source, every detector position behind the last
     tracing surface.  False: every chunk through the ray storage."""
-    ITER_LAST_RAYS: int = 1 << 22
-    """... and the last chunk, whose rays stay in `self.rays` afterwards like the reference's last iteration of 1 M
-    (raytracer.py:1235-1267), then has this many rays."""
+    ITER_LAST_RAYS: int = 1 << 20
+    """... and the last chunk, whose rays stay in `self.rays` afterwards like those of the reference's last iteration
+    (ITER_RAYS_STEP = 1 M there, raytracer.py:40, 1235-1267), then has this many rays."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
     """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are
     19 M rays of a 15-surface scene with polarisation or 93 M rays of a two-surface scene without."""

@@ -235,3 +235,21 @@ def test_first_chunk_is_cropped_to_the_sampled_extent_like_the_later_ones(render
     assert (e0[1] - e0[0]) > 20 * (e0[3] - e0[2]) or (e0[3] - e0[2]) > 20 * (e0[1] - e0[0]), "a line-like image"
     same_image(auto, given)
     assert auto.power() < full.power(), "the sample's extent is smaller: some hits of every chunk fall outside"
+
+
+@pytest.mark.parametrize("proj", ["Orthographic", "Equidistant"])
+def test_render_only_with_a_spherical_detector(proj):
+    """Curved detectors behind the last surface: without a sphere projection (Orthographic) the two-section storage goes
+    through the pair-only tile kernel (`detector_hit_pair`), with one (Equidistant) through the hit-list chain -- both must
+    give the stored path's images, also where the ray ends inside the detector's z range."""
+    with ot.global_options.no_warnings():
+        out = {}
+        for mode in (True, False):
+            RT = scenes.c4_image_render(ot, seed=8)
+            RT.add(ot.Detector(ot.SphericalSurface(r=7.5, R=-30), pos=[0, 0, 34]))
+            pos = [[0, 0, 33.], [0, 0, 35.5], [0, 0, 39.2]]  # the last one: the outline (z = 40) cuts through the sphere's sag
+            with settings(ITER_RAYS_STEP=500_000, ITER_RENDER_ONLY=mode, ITER_EXTENT_RAYS=1 << 60):
+                out[mode] = RT.iterative_render(1_500_000, detector_index=1, pos=pos, projection_method=proj,
+                                                extent=[[-6., 6., -6., 6.], None, None] if proj == "Orthographic" else None)
+    for x, y in zip(out[True], out[False]):
+        same_image(x, y)
