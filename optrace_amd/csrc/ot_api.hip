@@ -625,6 +625,7 @@ extern "C" int ot_sources_create(const ot_source* sources, int32_t n_sources, ot
         d.axis_sin = std::sin(d.div_axis);
         d.px_w = (s.img_w > 0) ? s.dim[0] / (double)s.img_w : 0.0;  // ray_source.py:252-253
         d.px_h = (s.img_h > 0) ? s.dim[1] / (double)s.img_h : 0.0;
+        d.inv_img_w = (s.img_w > 0) ? 1.0 / (double)s.img_w : 0.0;
         d.wl = s.wl; d.wl0 = s.wl0; d.wl1 = s.wl1; d.mu = s.mu; d.sig = s.sig;
         d.power = s.power;
         if (s.spectrum == OT_SPEC_GAUSSIAN) {  // light_spectrum.py:117-118

@@ -126,6 +126,18 @@ OT_DEV double dither(const GenCtx& g, int k) {
     return (k < 4) ? ((double)g.ra[k] + 0.5) * 0x1.0p-32 : 0.5;
 }
 
+// stratum index + dither in one fused multiply-add: (k + u) with u = bits * 2^-16 or 2^-32 in [0, 1) (the dither only places
+// the sample inside its stratum: no centring, two instructions less per sample than `(double)k + dither(g, slot)`)
+OT_DEV double stratum_plus_dither(const GenCtx& g, int slot, double k) {
+    if (slot >= 4 && slot < 8) return g.has_b ? __builtin_fma((double)g.rb[slot - 4], 0x1.0p-32, k) : k + 0.5;
+    if (g.image) {
+        const int j = (slot < 4) ? slot : slot - 4;
+        const uint32_t wv = g.ra[j >> 1];
+        return __builtin_fma((double)((j & 1) ? (wv >> 16) : (wv & 0xffffu)), 0x1.0p-16, k);
+    }
+    return (slot < 4) ? __builtin_fma((double)g.ra[slot], 0x1.0p-32, k) : k + 0.5;
+}
+
 // stream -> which dither value(s) it uses (consecutive pairs for the 2-D samplers).  The slots are grouped so
 // that a source only pays for the Philox blocks it needs: block A (u0-u3) serves every source -- point sources
 // with direction, wavelength and polarisation need nothing else --, block B (u4-u7) extended emitters and 2-D
@@ -175,9 +187,14 @@ OT_DEV void fill_dither_for(GenCtx& g, SRC& src) {
 // random.stratified_interval_sampling random.py:48-67: one of n strata of [a, b), uniformly dithered
 OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double b) {
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
-    double u0 = dither(g, dither_slot(stream));
     double dba = (b - a) * g.inv_n;
-    return a + ((double)k + u0) * dba;
+    return a + stratum_plus_dither(g, dither_slot(stream), (double)k) * dba;
+}
+
+// the same for a stratum index the caller already has (a second stream tied to another one's permutation, see generate_ray)
+OT_DEV double strat_interval_at(const GenCtx& g, uint32_t k, uint32_t stream, double a, double b) {
+    double dba = (b - a) * g.inv_n;
+    return a + stratum_plus_dither(g, dither_slot(stream), (double)k) * dba;
 }
 
 // random.stratified_rectangle_sampling random.py:8-45: floor(sqrt(n))^2 jittered grid cells, the remaining
@@ -185,6 +202,17 @@ OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double 
 OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, double c, double d, double& x, double& y) {
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
     const int slot = dither_slot(stream);
+    if ((g.n & (g.n - 1u)) == 0u && g.n >= 4u) {
+        // A power-of-two block of 2^m rays (what the host cuts long ranges into): a jittered grid of 2^ceil(m/2) x 2^floor(m/2)
+        // cells takes EVERY sample (the reference's floor(sqrt n)^2 square cells leave n - N2^2 samples unstratified) and a
+        // sample finds its cell with a shift and a mask instead of a division with fix-ups.  (wave-uniform branch)
+        const int m = 31 - __builtin_clz(g.n), mx = (m + 1) >> 1, my = m >> 1;
+        const uint32_t ix = k & ((1u << mx) - 1u), iy = k >> mx;
+        const double sx = __builtin_ldexp(b - a, -mx), sy = __builtin_ldexp(d - c, -my);  // (scalar operands: per wave)
+        x = a + stratum_plus_dither(g, slot, (double)ix) * sx;
+        y = c + stratum_plus_dither(g, slot + 1, (double)iy) * sy;
+        return;
+    }
     double u0 = dither(g, slot), u1 = dither(g, slot + 1);
     const uint32_t N2 = g.n2;
     if (k < N2 * N2) {
@@ -352,7 +380,11 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
 
     // ---- image sources, round trip 1: the pixel range of this ray's stratified uniform variable (ray_source.py:243-245)
     PixelPick pk = {0.0, 0, 0};
-    if (image && npx > 1) pk = pixel_pick_issue(src, g, strat_interval(g, ST_PIXEL, 0.0, src.pix_total));
+    uint32_t k_pixel = 0u;  // the stratum of the pixel variable (RGB images tie the primary's variable to it, below)
+    if (image) {
+        k_pixel = permute_index(g.j, g.n, stream_key(g.seed, g.range, ST_PIXEL));
+        if (npx > 1) pk = pixel_pick_issue(src, g, strat_interval_at(g, k_pixel, ST_PIXEL, 0.0, src.pix_total));
+    }
 
     // ---- wavelength (light_spectrum.py:81-138) ----
     double wl = 0.0;
@@ -388,7 +420,22 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         // a permutation and the grid arithmetic (~45 vector instructions per ray) bought nothing.
         rx = dither(g, dither_slot(ST_PIX_JITTER));
         ry = dither(g, dither_slot(ST_PIX_JITTER) + 1);
-        if (src.shape == OT_SRC_IMAGE_RGB) choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
+        if (src.shape == OT_SRC_IMAGE_RGB) {
+            // The variable that chooses the primary (and, rescaled, places the wavelength inside it): stratified over the
+            // rays of the range like the pixel variable.  Its stratum is the pixel stratum times an odd constant modulo the
+            // block size -- a rank-1 lattice pairing (Korobov): the rays that share a pixel have consecutive pixel strata,
+            // and consecutive multiples of 0.618.. n modulo n are spread evenly over [0, n), so every pixel sees the primaries
+            // and their spectra with LESS noise than under an independent shuffle (the reference stratifies the wavelengths
+            // over the rays of each primary for the same purpose, srgb.py:549-551) -- and the second keyed permutation (16
+            // instructions) becomes a multiplication.  Ragged blocks (no power of two) keep their own permutation.
+            if ((g.n & (g.n - 1u)) == 0u && g.n >= 2u) {
+                const int m = 31 - __builtin_clz(g.n);                  // n = 2^m
+                const uint32_t mult = (0x9E3779B1u >> (32 - m)) | 1u;   // ~ 0.618 n, odd: a bijection of [0, n) (scalar unit)
+                choice = strat_interval_at(g, (k_pixel * mult + stream_key(g.seed, g.range, ST_RGB_CHOICE)) & (g.n - 1u),
+                                           ST_RGB_CHOICE, 0.0, 1.0);
+            } else
+                choice = strat_interval(g, ST_RGB_CHOICE, 0.0, 1.0);
+        }
     }
     // ---- image sources, round trip 2: the records of the first two pixels of the range ----
     PixRec r0 = {0.0, 0.0, 0.0, 0.0}, r1 = r0;
@@ -531,7 +578,11 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
                 wl_x1 = inv[1];
                 wl_f = tm - (double)m;
             }
-            uint32_t PY = P / (uint32_t)src.img_w, PX = P - PY * (uint32_t)src.img_w;
+            // row = P / img_w through the host's reciprocal with an exact fix-up instead of an integer division
+            uint32_t PY = (uint32_t)(((double)P + 0.5) * src.inv_img_w);
+            if (PY * (uint32_t)src.img_w > P) PY--;
+            if ((PY + 1) * (uint32_t)src.img_w <= P) PY++;
+            const uint32_t PX = P - PY * (uint32_t)src.img_w;
             double xs = src.pos[0] - src.dim[0] / 2, ys = src.pos[1] - src.dim[1] / 2;
             p.x = src.px_w * ((double)PX + rx) + xs;
             p.y = src.px_h * ((double)PY + ry) + ys;
@@ -541,16 +592,24 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
 
     // ---- orientation (ray_source.py:264-277) ----
     V3 s_or;
+    V3 fy_conv = {0.0, 0.0, 0.0};
+    bool have_fy = false;  // (wave-uniform: converging orientation)
     if (src.frame_uniform) {  // one base orientation for the whole source (host): constant, or a point source converging
         s_or.x = src.s[0];
         s_or.y = src.s[1];
         s_or.z = src.s[2];
     } else if (src.orientation == OT_OR_CONVERGING) {
-        V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
-        const double il = ot_rcp3(ot_sqrt(d.x * d.x + d.y * d.y + d.z * d.z));
+        // s_or = d / |d|, and its divergence frame straight from d: sy = [1, 0, 0] x s_or / sqrt(1 - s_or_x^2) =
+        // (0, -d_z, d_y) / sqrt(d_y^2 + d_z^2) -- two reciprocal square roots instead of two square roots and two reciprocals
+        const V3 d = {src.conv_pos[0] - p.x, src.conv_pos[1] - p.y, src.conv_pos[2] - p.z};
+        const double m2 = d.y * d.y + d.z * d.z;
+        const double il = ot_rsqrt(d.x * d.x + m2);
         s_or.x = d.x * il;
         s_or.y = d.y * il;
         s_or.z = d.z * il;
+        const double im = ot_rsqrt(m2);
+        fy_conv = {0.0, -d.z * im, d.y * im};
+        have_fy = true;
     } else if (src.orientation == OT_OR_ARRAY && src.s_or) {  // or_func(x, y) evaluated by the caller (:272-274)
         s_or.x = src.s_or[g.j];
         s_or.y = src.s_or[g.j + src.n_or];
@@ -569,8 +628,11 @@ OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
         if (src.frame_uniform) {
             sx = {src.fx[0], src.fx[1], src.fx[2]};
             sy = {src.fy[0], src.fy[1], src.fy[2]};
+        } else if (have_fy) {
+            sy = fy_conv;
+            sx = cross3(s_or, sy);
         } else {
-            double fa = ot_rcp3(ot_sqrt(1 - s_or.x * s_or.x));
+            double fa = ot_rsqrt(1 - s_or.x * s_or.x);
             sy = {0.0, -s_or.z * fa, s_or.y * fa};
             sx = cross3(s_or, sy);
         }

@@ -133,6 +133,7 @@ struct SourceDev {
     double pol_angle, pol_cos, pol_sin;  // constant polarisation angle and its cos / sin
     double axis_cos, axis_sin;          // cos / sin of div_axis (2-D divergence)
     double px_w, px_h;                  // image sources: pixel size dim / (img_w, img_h)
+    double inv_img_w;                   // 1 / img_w (the pixel's row without an integer division)
     double wl, wl0, wl1, mu, sig;
     double gauss_xl, gauss_xr;  // truncated-normal cdf bounds  light_spectrum.py:117-118
     double power;

@@ -64,7 +64,7 @@ def test_trim_leaves_an_open_automatic_image_alone_and_two_may_be_open():
     assert stats(lib) == (0, 0, 0)
 
 
-def test_images_are_bit_equal_before_and_after_a_trim_and_under_a_tiny_cap():
+def test_images_do_not_depend_on_the_pool_trimmed_or_under_a_tiny_cap():
     lib = _capi.load_library()
     with pinned("tiles"), ot.global_options.no_warnings():
         RT = image_scene(N=1_500_000)
@@ -82,9 +82,11 @@ def test_images_are_bit_equal_before_and_after_a_trim_and_under_a_tiny_cap():
             assert stats(lib)[1] <= 2
         finally:
             _capi.check(lib.ot_scratch_set_cap(64_000_000_000))
-    # the same kernels on the same records in the same places: not merely close
-    assert np.array_equal(one._data, two._data) and np.array_equal(one._data, three._data)
-    same_image(auto1, auto2, tol=1e-12)
+    # the same kernels on the same records: equal up to the order in which the LDS atomics of one pixel arrive, which no two
+    # runs share (bit-equality is not on offer with floating-point atomics, trim or no trim)
+    same_image(one, two, tol=1e-13)
+    same_image(one, three, tol=1e-13)
+    same_image(auto1, auto2, tol=1e-13)
 
 
 def test_alloc_retry_trims_the_pool_when_torch_runs_out_of_memory():
