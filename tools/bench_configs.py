@@ -29,6 +29,8 @@ CONFIGS = {
     "A1 double gauss aspheric fronts": (lambda o: scenes.double_gauss(o, seed=1, aspheric=True), 10_000_000),
     "A1n double gauss aspheric no_pol": (lambda o: scenes.double_gauss(o, seed=1, aspheric=True, no_pol=True), 10_000_000),
     "A2 asphere test scene": (lambda o: scenes.asphere_scene(o, seed=3), 10_000_000),
+    # the same with HURB at its slit: feature level 3 (asphere search + HURB in one kernel)
+    "A3 asphere test scene, HURB on": (lambda o: scenes.asphere_scene(o, seed=3, use_hurb=True), 10_000_000),
     "freeform (spline surfaces)": (lambda o: scenes.freeform_scene(o, seed=5), 10_000_000),
     "F2 freeform without the ideal lens": (lambda o: scenes.freeform_scene(o, seed=5, ideal_lens=False), 10_000_000),
 }
