@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 7
+#define OT_ABI_VERSION 8
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -471,6 +471,8 @@ typedef struct ot_detector_image_req {
     double extent[4];     /* image extent [x0, x1, y0, y1]                          */
     double* hist;         /* device (Ny, Nx, 4) f64                                 */
     int64_t* ill_count;   /* device int64[2], added to                              */
+    double weight_scale;  /* every hit's weight times this (f64) before it is added: 1 for a plain image; the chunks of
+                           * an iterative render pass rays_step / N (raytracer.py:1257) and bin straight into one image */
 } ot_detector_image_req;
 int ot_detector_images(const ot_rays* rays, int64_t first, int64_t count, const ot_detector_image_req* reqs,
                        int32_t n_reqs, void* stream);

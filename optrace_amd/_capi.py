@@ -102,7 +102,7 @@ class DetectorReq(C.Structure):
 class DetectorImageReq(C.Structure):
     _fields_ = [("detector", C.c_void_p), ("projection", C.c_int32), ("Nx", C.c_int32), ("Ny", C.c_int32),
                 ("_pad", C.c_int32), ("crop4", C.c_void_p), ("extent", C.c_double * 4), ("hist", C.c_void_p),
-                ("ill_count", C.c_void_p)]
+                ("ill_count", C.c_void_p), ("weight_scale", C.c_double)]
 
 
 class SourceRange(C.Structure):
@@ -176,7 +176,7 @@ SIGNATURES = {
 
 FOCUS_WS = 16  # OT_FOCUS_WS
 HIT_PIECES = 1024  # OT_HIT_PIECES
-ABI_VERSION = 7  # OT_ABI_VERSION
+ABI_VERSION = 8  # OT_ABI_VERSION
 ERR_UNSUPPORTED = -3  # OT_ERR_UNSUPPORTED
 
 _lib = None

@@ -1510,7 +1510,8 @@ extern "C" int ot_scratch_stats(int64_t* kept_bytes, int32_t* blocks, int32_t* l
 #define OT_TILE_MIN_HITS (1ll << 21)  // shorter lists: the direct kernel alone
 
 static int render_accumulate(int64_t n, const unsigned int* fill, const double* px, const double* py, const float* w,
-                             const float* wl, const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream);
+                             const float* wl, const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream,
+                             double weight_scale = 1.0);
 
 extern "C" int ot_render_accumulate(int64_t n, const double* px, const double* py, const float* w, const float* wl,
                                     const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream) {
@@ -1525,7 +1526,8 @@ extern "C" int ot_render_accumulate_compact(int64_t n, const uint32_t* fill, con
 }
 
 static int render_accumulate(int64_t n, const unsigned int* fill, const double* px, const double* py, const float* w,
-                             const float* wl, const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream) {
+                             const float* wl, const double extent[4], int32_t Nx, int32_t Ny, double* hist, void* stream,
+                             double weight_scale) {
     if (n < 0 || !extent || !hist || Nx < 1 || Ny < 1 || (n && (!px || !py || !w || !wl)))
         return fail(OT_ERR_INVALID, "ot_render_accumulate: bad argument");
     if (int rc = require_device()) return rc;
@@ -1539,6 +1541,7 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
     a.fy = (double)Ny / (extent[3] - extent[2]);
     a.Nx = Nx;
     a.Ny = Ny;
+    a.ws = weight_scale;
     const double* table = observer_table_device();
     if (!table) return fail(OT_ERR_HIP, "could not upload the CIE observer table");
     // one 1024-thread workgroup per CU (grid-stride): LDS-privatised histogram, see render_kernel
@@ -1673,6 +1676,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         if (!q.detector || !q.hist || !q.ill_count || q.Nx < 1 || q.Ny < 1) return fail(OT_ERR_INVALID, "ot_detector_images: bad request");
         if (!(q.extent[1] > q.extent[0]) || !(q.extent[3] > q.extent[2])) return fail(OT_ERR_INVALID, "ot_detector_images: empty image extent");
         if ((int64_t)q.Nx * q.Ny > (1ll << 27)) return fail(OT_ERR_INVALID, "ot_detector_images: image too large");
+        if (!std::isfinite(q.weight_scale)) return fail(OT_ERR_INVALID, "ot_detector_images: weight_scale is not finite");
         if (q.projection < OT_PROJ_NONE || q.projection > OT_PROJ_STEREOGRAPHIC) return fail(OT_ERR_INVALID, "unknown projection");
     }
     if (int rc = require_device()) return rc;
@@ -1706,7 +1710,8 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         dq.fill = nullptr;
         dq.ill_count = q.ill_count;
         int rc = ot_detector_hits_multi(rays, first, count, &dq, 1, stream);
-        if (!rc) rc = ot_render_accumulate(count, dq.ph, dq.ph + count, dq.hw, rays->wl + first, q.extent, q.Nx, q.Ny, q.hist, stream);
+        if (!rc) rc = render_accumulate(count, nullptr, dq.ph, dq.ph + count, dq.hw, rays->wl + first, q.extent, q.Nx, q.Ny, q.hist, stream,
+                                        q.weight_scale);
         if (rc) return rc;
         std::vector<ot_detector_image_req> rest;
         for (int j = 0; j < n_reqs; j++)
@@ -1730,7 +1735,9 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     // OT_RENDER_PATH = direct | tiles pins the binning path (tests, profiling); default: by ray count and probe
     const char* pin = std::getenv("OT_RENDER_PATH");
     const bool pin_direct = pin && !std::strcmp(pin, "direct"), pin_tiles = pin && !std::strcmp(pin, "tiles");
-    const bool want_tiles = !pin_direct && (pin_tiles || count >= OT_TILE_MIN_HITS);
+    // (the threshold counts the hits a call may bin: rays x detectors -- the last, short chunk of an iterative render with six
+    // positions then stays on the tile path instead of 6e6 global atomic quadruples)
+    const bool want_tiles = !pin_direct && (pin_tiles || count * (int64_t)n_reqs >= OT_TILE_MIN_HITS);
     if (count >= (1ll << 31)) return fail(OT_ERR_UNSUPPORTED, "ot_detector_images: at most 2^31 - 1 rays per call");
     // tile kernel: two rays per thread and sub-block where the images have at most 1024 tiles (10-bit tile numbers)
     bool small_k = n_reqs == 1;
@@ -1774,6 +1781,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
         f.a.fy = (double)q.Ny / (q.extent[3] - q.extent[2]);
         f.a.Nx = q.Nx;
         f.a.Ny = q.Ny;
+        f.a.ws = q.weight_scale;
         f.tx = (q.Nx + OT_TILE_W - 1) / OT_TILE_W;
         f.K = f.tx * ((q.Ny + OT_TILE_W - 1) / OT_TILE_W);
         f.ill = (unsigned long long*)q.ill_count;
@@ -2128,6 +2136,7 @@ extern "C" int ot_detector_image_auto_finish(ot_auto_image* im_raw, const double
     f.a.fy = (double)Ny / (extent[3] - extent[2]);
     f.a.Nx = Nx;
     f.a.Ny = Ny;
+    f.a.ws = 1.0;
     f.hist = hist;
     char* ws = im->ws;
     FuseIndex ix;

@@ -466,6 +466,7 @@ struct RenderArgs {
     double x0, x1, y0, y1;
     double fx, fy;  // Nx / sx, Ny / sy  (misc.py:75-76)
     int32_t Nx, Ny;
+    double ws;      // every hit's weight times this, in f64, before it is added (1: plain; iterative_render: rays_step / N)
 };
 
 static const double* observer_table_device() {
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* _
         if (pix < 0) continue;
         double xo, yo, zo;
         observer_xyz_at(obs, (double)wl[i], xo, yo, zo);
-        double wm = (double)wi;
+        double wm = (double)wi * a.ws;
         // LDS hash insert: claim or match one of OT_HASH_PROBES consecutive entries
         unsigned int h = ((unsigned int)pix * 2654435761u) >> (32 - 11);  // OT_HASH_N = 2^11
         int slot = -1;

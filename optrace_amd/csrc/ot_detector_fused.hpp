@@ -75,6 +75,7 @@ OT_DEV int fuse_pixel(FT& F, const V3& ph, int32_t& ix, int32_t& iy) {
     a.fy = F.a.fy;
     a.Nx = F.a.Nx;
     a.Ny = F.a.Ny;
+    a.ws = 1.0;
     return hit_pixel(a, ph.x, ph.y, ix, iy);
 }
 
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(1024) void fuse_direct_kernel(ot_rays R, int64_t fi
                 observer_xyz_at(obs, wl, xo, yo, zo);
                 have_obs = true;
             }
-            const double wm = (double)w;
+            const double wm = (double)w * F.a.ws;
             const int key = pix * OT_DET_MAX + d;
             unsigned int h = ((unsigned int)key * 2654435761u) >> (32 - 11);  // OT_HASH_N = 2^11
             int slot = -1;
@@ -961,7 +962,7 @@ OT_DEV void fuse_accum_body(const FuseOne& F, const FuseIndex& ix, const double*
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) {
             if (!ok[k]) continue;
-            const double wm = (double)rec[k].w;
+            const double wm = (double)rec[k].w * F.a.ws;
             double xo, yo, zo;
             observer_xyz_at(obs, (double)rec[k].wl, xo, yo, zo);
             // plane-major tile [channel][pixel]: the lanes of one add then spread over 16 bank pairs; pixel-major
@@ -1147,7 +1148,7 @@ __global__ __launch_bounds__(1024) void spec_accum_kernel(FuseOne F, FuseIndex i
             int32_t px, py;
             const int pix = hit_pixel(F.a, rec[k].x, rec[k].y, px, py);
             if (pix < 0) continue;
-            const double wm = (double)rec[k].w;
+            const double wm = (double)rec[k].w * F.a.ws;
             double xo, yo, zo;
             observer_xyz_at(obs, (double)rec[k].wl, xo, yo, zo);
             const int lx = px - ox, ly = py - oy;
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(256) void spec_escaped_kernel(FuseOne F, const doub
         if (pix < 0) continue;
         double xo, yo, zo;
         observer_xyz_at(table, (double)r.wl, xo, yo, zo);
-        const double wm = (double)r.w;
+        const double wm = (double)r.w * F.a.ws;
         double* hg = F.hist + (int64_t)pix * 4;
         unsafeAtomicAdd(hg + 0, xo * wm);
         unsafeAtomicAdd(hg + 1, yo * wm);

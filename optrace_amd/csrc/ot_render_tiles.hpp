@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void tile_accum_kernel(TileArgs t, const doub
     __syncthreads();
     for (unsigned long long r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
         const TileRec rec = wk.rec[r];
-        const double wm = (double)rec.w;
+        const double wm = (double)rec.w * t.a.ws;
         double xo, yo, zo;
         observer_xyz_at(obs, (double)rec.wl, xo, yo, zo);
         // plane-major tile [channel][pixel]: the lanes of one add spread over 16 bank pairs (with 4 doubles per pixel

@@ -185,7 +185,8 @@ def detector_images(rays, first: int, count: int, requests: list) -> list:
 
     requests: dicts with surf_desc (_capi.Surface), projection (int), crop ([x0, x1, y0, y1]: the user extent hits are
     restricted to, or None), extent (image extent after RenderImage._fix_extent), Nx, Ny, hist (flat f64 device tensor
-    of Ny * Nx * 4 entries that the hits are ADDED to).  At most 8 per call.  -> ill-conditioned count per request."""
+    of Ny * Nx * 4 entries that the hits are ADDED to), weight_scale (optional: every weight times this before it is added).
+    At most 8 per call.  -> ill-conditioned count per request."""
     lib = _capi.load_library()
     dev = require_device()
     n = len(requests)
@@ -204,6 +205,7 @@ def detector_images(rays, first: int, count: int, requests: list) -> list:
         r.crop4 = None if crop4 is None else C.addressof(crop4)
         r.extent[:] = [float(v) for v in rq["extent"]]
         r.hist = rq["hist"].data_ptr()
+        r.weight_scale = float(rq.get("weight_scale", 1.0))
         r.ill_count = ill.data_ptr() + 16 * k
         any_numeric = any_numeric or (sd.kind >= _capi.SURF_ASPHERE and sd.z_min != sd.z_max)
     rs = rays._rays_struct()

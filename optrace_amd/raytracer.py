@@ -529,12 +529,14 @@ class Raytracer(Group):
                     out[n] = (ph, hw, wl, extent_out, rq["projection"], ill_count, rq["desc"])
         return out
 
-    def _render_detectors(self, specs: list, limits: list, into: list = None, rays=None, **kwargs) -> list:
+    def _render_detectors(self, specs: list, limits: list, into: list = None, rays=None, weight_scale: float = 1.0,
+                          **kwargs) -> list:
         """Detector images whose extents are known beforehand (every spec carries a user extent, or the automatic
         one of `_auto_extents` as "auto_extent"): hit search and
         binning in ONE pass over the ray sections (`ot_detector_images`), up to 8 images per pass; the hit positions
         are never written to memory.  into: per spec a (Ny, Nx, 4) device histogram to add to, or None.
-        `rays`: a `TailStorage` (render-only chunk) instead of `self.rays`.
+        `rays`: a `TailStorage` (render-only chunk) instead of `self.rays`; `weight_scale`: every hit's weight times this (in
+        f64) before it is added -- the chunks of an iterative render bin straight into one image with rays_step / N each.
         -> RenderImages (raytracer.py:1053-1098 for each spec)."""
         reqs = self._detector_requests(specs, rays)
         src_rays = self.rays if rays is None else rays
@@ -567,7 +569,7 @@ class Raytracer(Group):
             images.append(img)
             calls.setdefault((rq["Ns"], rq["Ne"]), []).append(
                 (n, dict(surf_desc=rq["surf_desc"], projection=_capi.PROJECTIONS[rq["projection"]], crop=rq["crop"],
-                         extent=img.extent, Nx=Nx, Ny=Ny, hist=hist)))
+                         extent=img.extent, Nx=Nx, Ny=Ny, hist=hist, weight_scale=weight_scale)))
         for (Ns, Ne), part_all in calls.items():
             for b in range(0, len(part_all), 8):
                 part = part_all[b:b + 8]
@@ -1010,7 +1012,6 @@ class Raytracer(Group):
 
         nt = n_sec
         msgs_cum = np.zeros((len(self.INFOS), n_sec), dtype=int)
-        n0, scaled = chunks[0], False  # images hold chunks of n0 rays each, unscaled, until `scaled`
 
         for i, n_i in enumerate(chunks):  # one chunk of rays per iteration (raytracer.py:1235-1267)
             src = tail if (tail is not None and i < len(chunks) - 1) else None
@@ -1019,38 +1020,26 @@ class Raytracer(Group):
                 msgs_cum += self._msgs
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
-                # up to 8 positions are intersected in one pass over the sections.  Once the extents are known (given by
-                # the caller, or fixed by the first chunk, raytracer.py:1262) hit search and binning are one pass as
-                # well (`ot_detector_images`); otherwise the hit lists (20 B per ray and position, `ot_detector_hits_multi`)
-                # are binned and released before the next group is searched
-                # chunks of the first chunk's size are binned straight into its image (their common factor n0 / N is
-                # applied once at the end); a chunk of another size gets its own histogram and is added with its own
-                # factor (raytracer.py:1247-1267: per-chunk scaling), as is every chunk after it
-                direct = 0 < i and n_i == n0 and not scaled
-                if 0 < i and not direct and not scaled:
-                    for img in images:
-                        img._dev *= n0 / N
-                    scaled = True
+                # up to 8 positions are intersected in one pass over the sections, hit search and binning fused
+                # (`ot_detector_images`); the extents are given by the caller or fixed by the first chunk (raytracer.py:1262).
+                # The reference scales every chunk's image by rays_step / N and adds it (raytracer.py:1257-1264); here the
+                # factor rides with the weights into the binning (`weight_scale`, applied in f64), so that every chunk is
+                # binned straight into the one image of its position: no second set of histograms, no passes over them
                 for j0 in range(0, len(pos), 8):
                     group = list(range(j0, min(j0 + 8, len(pos))))
                     specs = [dict(detector_index=detector_index[j], extent=extentc[j],
                                   projection_method=projection_method[j], pos=pos[j]) for j in group]
-                    into = [images[j]._dev if direct else None for j in group]
+                    into = [images[j]._dev if i else None for j in group]
                     if not all(extentc[j] is not None for j in group):  # first chunk: extents from their own pass
                         specs = self._auto_extents(specs, agree=_agree_extents, sample_rays=self.ITER_EXTENT_RAYS, rays=src)
-                    imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, rays=src, _dont_filter=True)
-                    for g, j in enumerate(group):
-                        img = imgs[g]
-                        if i == 0:
-                            images.append(img)
-                            extentc[j] = img._extent0
-                        elif not direct:
-                            images[j]._dev.add_(img._dev, alpha=n_i / N)
+                    imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, rays=src,
+                                                  weight_scale=n_i / N, _dont_filter=True)
+                    if i == 0:
+                        for g, j in enumerate(group):
+                            images.append(imgs[g])
+                            extentc[j] = imgs[g]._extent0
             finally:
                 self._rays_known_current = False
-        if not scaled:
-            for img in images:
-                img._dev *= n0 / N
         if tail is not None:
             tail.release()
 

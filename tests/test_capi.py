@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version(lib):
     lib.ot_abi_version.restype = C.c_int
-    assert lib.ot_abi_version() == _capi.ABI_VERSION == 7
+    assert lib.ot_abi_version() == _capi.ABI_VERSION == 8
 
 
 def test_struct_layout_matches_header(tmp_path):
