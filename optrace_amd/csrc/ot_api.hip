@@ -1747,7 +1747,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     // (every request that reaches this point has a closed-form hit and no sphere projection)
     const bool linebuf = n_reqs == 1 && fuse_use_linebuf(((reqs[0].Nx + OT_TILE_W - 1) / OT_TILE_W) * ((reqs[0].Ny + OT_TILE_W - 1) / OT_TILE_W));
     const int64_t brt = linebuf ? OT_LB_BR * OT_LB_RPT : OT_FUSE_BR * (small_k ? 2 : 1);
-    const unsigned n_wg = (unsigned)std::min<int64_t>((linebuf ? 1 : 2) * (int64_t)cus, (count + brt - 1) / brt);
+    const unsigned n_wg = (unsigned)std::min<int64_t>((linebuf ? 1 : OT_FUSE_WG_PER_CU) * (int64_t)cus, (count + brt - 1) / brt);
     const int64_t piece = ((count + n_wg - 1) / n_wg + brt - 1) / brt * brt;
 
     std::vector<FuseOne> host(n_reqs);
@@ -2032,7 +2032,7 @@ extern "C" int ot_detector_image_auto_begin(const ot_rays* rays, int64_t first, 
     const bool small_k = K <= 1024;  // two rays per thread and sub-block (10-bit tile numbers), as in ot_detector_images
     const bool linebuf = fuse_use_linebuf((int)K);  // few tiles: line buffers, one 1024-thread workgroup per CU
     const int64_t brt = linebuf ? OT_LB_BR * OT_LB_RPT : OT_FUSE_BR * (small_k ? 2 : 1);
-    const unsigned n_wg = (unsigned)std::min<int64_t>((linebuf ? 1 : 2) * (int64_t)cus, (count + brt - 1) / brt);
+    const unsigned n_wg = (unsigned)std::min<int64_t>((linebuf ? 1 : OT_FUSE_WG_PER_CU) * (int64_t)cus, (count + brt - 1) / brt);
     const int64_t piece = ((count + n_wg - 1) / n_wg + brt - 1) / brt * brt;
 
     std::unique_ptr<ot_auto_image> im(new ot_auto_image);

@@ -20,7 +20,12 @@
 #include "ot_render_tiles.hpp"
 
 #define OT_FUSE_CH 256       // records per chunk (3 KB)
+#ifndef OT_FUSE_BR
 #define OT_FUSE_BR 512       // rays per sub-block = threads per workgroup of the tile kernel
+#endif
+#ifndef OT_FUSE_WG_PER_CU
+#define OT_FUSE_WG_PER_CU 2  // ... and its persistent workgroups per CU (A/B: 1024 threads x 1, profiles/r4/tile_kernel_wg_ab.txt)
+#endif
 #define OT_FUSE_CPW 256      // chunks per accumulation workgroup (and slab): 64 records per thread
 #define OT_FUSE_NONE 0xffffffffu
 #define OT_FUSE_LDS_ENTRIES 2400  // (detector, tile) entries a tile-kernel workgroup can keep (20 B each)
