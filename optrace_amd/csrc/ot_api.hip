@@ -1608,7 +1608,7 @@ static int render_accumulate(int64_t n, const unsigned int* fill, const double* 
     wk.rec = (TileRec*)(ws + o_rec);
     wk.slabs = (double*)(ws + o_slabs);
     const int lds_probe = OT_TILE_PROBE_SET * (int)sizeof(int);
-    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
+    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 6) * (int)sizeof(double);  // tile + (value, difference) observer table
     static thread_local bool lds_set[64] = {false};
     if (dev >= 0 && dev < 64 && !lds_set[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)tile_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_probe));
@@ -1842,7 +1842,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
     if (err == hipSuccess) err = hipMemcpyAsync(ws + o_dets, host.data(), sizeof(FuseOne) * n_reqs, hipMemcpyHostToDevice, st);
     const FuseOne* dd = (const FuseOne*)(ws + o_dets);
     static thread_local bool lds_set[64] = {false};
-    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
+    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 6) * (int)sizeof(double);  // tile + (value, difference) observer table
     if (err == hipSuccess && dev >= 0 && dev < 64 && !lds_set[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)fuse_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
         HIP_TRY(hipFuncSetAttribute((const void*)fuse_accum_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));
@@ -2146,7 +2146,7 @@ extern "C" int ot_detector_image_auto_finish(ot_auto_image* im_raw, const double
     ix.n_slabs = im->n_slabs;
     ix.list = (unsigned int*)(ws + im->o_list);
     ix.slabs = (double*)(ws + im->o_slabs);
-    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 3) * (int)sizeof(double);
+    const int lds_accum = (OT_TILE_PX * 4 + OT_OBS_N * 6) * (int)sizeof(double);  // tile + (value, difference) observer table
     static thread_local bool lds_set[64] = {false};
     if (im->dev >= 0 && im->dev < 64 && !lds_set[im->dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)spec_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_accum));

@@ -3,6 +3,7 @@
 // spherical_surface.py:36-97, RenderImage.render render_image.py:361-421 (+ misc.binning_indices_2d
 // misc.py:59-91, color.x/y/z_observer observers.py:14-41).
 #pragma once
+#include <vector>
 #include "ot_device.hpp"
 #include "cie_observer_table.inc"
 
@@ -474,9 +475,19 @@ static const double* observer_table_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!tab[dev]) {
+        // the 471 x 3 table, and behind it the same as (value, difference to the next row) pairs: 471 x 6 (observer_xyz_at6)
+        std::vector<double> both((size_t)OT_OBS_N * 9);
+        const double* src = (const double*)ot_observer_xyz;
+        for (int i = 0; i < OT_OBS_N * 3; i++) both[i] = src[i];
+        double* pairs = both.data() + (size_t)OT_OBS_N * 3;
+        for (int j = 0; j < OT_OBS_N; j++)
+            for (int c = 0; c < 3; c++) {
+                pairs[6 * j + 2 * c] = src[3 * j + c];
+                pairs[6 * j + 2 * c + 1] = (j + 1 < OT_OBS_N) ? (src[3 * (j + 1) + c] - src[3 * j + c]) / 1.0 : 0.0;  // observers.py:14-41
+            }
         double* d = nullptr;
-        if (hipMalloc((void**)&d, sizeof(ot_observer_xyz)) != hipSuccess) return nullptr;
-        if (hipMemcpy(d, ot_observer_xyz, sizeof(ot_observer_xyz), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&d, sizeof(double) * both.size()) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, both.data(), sizeof(double) * both.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
         tab[dev] = d;
     }
     return tab[dev];
@@ -523,6 +534,29 @@ OT_DEV void observer_xyz_at(const double* obs, double l, double& xo, double& yo,
             yo = (f0[4] - f0[1]) / 1.0 * t + f0[1];
             zo = (f0[5] - f0[2]) / 1.0 * t + f0[2];
         }
+    }
+}
+
+// The same from the table of (value, difference) pairs (observer_table_device: 471 x 6 behind the 471 x 3), for the kernels
+// that look a wavelength up per RECORD out of LDS: the three pairs of a row are 48 contiguous, 16-byte aligned bytes -- three
+// 16-byte LDS reads instead of six 8-byte ones with a 24-byte row stride -- and the difference np.interp forms per call
+// ((f[j + 1] - f[j]) / 1.0, the same f64 subtraction) comes ready: identical bits.
+#define OT_OBS6_OFF (OT_OBS_N * 3)
+OT_DEV void observer_xyz_at6(const double* obs6, double l, double& xo, double& yo, double& zo) {
+    xo = yo = zo = 0.0;
+    double u = l - OT_OBS_WL0;
+    if (u >= 0.0 && u <= (double)(OT_OBS_N - 1)) {
+        int j = (int)floor(u);
+        double t = l - (OT_OBS_WL0 + (double)j);
+        if (j >= OT_OBS_N - 1) {  // the last node itself
+            j = OT_OBS_N - 1;
+            t = 0.0;
+        }
+        const double2* r = (const double2*)(obs6 + 6 * j);
+        const double2 a = r[0], b = r[1], c = r[2];
+        xo = a.y * t + a.x;
+        yo = b.y * t + b.x;
+        zo = c.y * t + c.x;
     }
 }
 

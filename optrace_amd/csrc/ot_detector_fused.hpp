@@ -919,7 +919,7 @@ __global__ __launch_bounds__(1024) void fuse_chunk_place_multi_kernel(const Fuse
 // finds its tile by bisection of wstart in LDS, adds its chunks into an LDS tile and writes slab b.
 OT_DEV void fuse_accum_body(const FuseOne& F, const FuseIndex& ix, const double* __restrict__ table, const unsigned int bx, const unsigned int by) {
     if (!F.spread[0]) return;
-    extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 3 observer table]; the tile part first holds wstart
+    extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 6 observer table: (value, difference) pairs]; the tile part first holds wstart
     double* tile = lds;
     double* obs = lds + OT_TILE_PX * 4;
     unsigned int* ws = (unsigned int*)lds;
@@ -940,7 +940,7 @@ OT_DEV void fuse_accum_body(const FuseOne& F, const FuseIndex& ix, const double*
     const unsigned int j_begin = part * OT_FUSE_CPW;
     const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
     for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
-    for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
+    for (int i = threadIdx.x; i < OT_OBS_N * 6; i += blockDim.x) obs[i] = table[OT_OBS6_OFF + i];
     __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
     for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
         const unsigned int c = ix.list[c0 + j_begin + i];
@@ -969,7 +969,7 @@ OT_DEV void fuse_accum_body(const FuseOne& F, const FuseIndex& ix, const double*
             if (!ok[k]) continue;
             const double wm = (double)rec[k].w * F.a.ws;
             double xo, yo, zo;
-            observer_xyz_at(obs, (double)rec[k].wl, xo, yo, zo);
+            observer_xyz_at6(obs, (double)rec[k].wl, xo, yo, zo);
             // plane-major tile [channel][pixel]: the lanes of one add then spread over 16 bank pairs; pixel-major
             // (4 doubles per pixel) would leave them 4 and make every add a 16-way bank conflict
             double* hv = tile + (int)rec[k].px;
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(64) void spec_result_kernel(const unsigned long lon
 
 // fuse_accum_kernel for SpecRec chunks: LDS window of tile t = final pixels [ox, ox + 64) x [oy, oy + 64)
 __global__ __launch_bounds__(1024) void spec_accum_kernel(FuseOne F, FuseIndex ix, const double* __restrict__ table) {
-    extern __shared__ double lds[];  // [TILE_PX * 4 window] [471 * 3 observer table]; the window part first holds wstart
+    extern __shared__ double lds[];  // [TILE_PX * 4 window] [471 * 6 observer table: (value, difference) pairs]; the window part first holds wstart
     double* tile = lds;
     double* obs = lds + OT_TILE_PX * 4;
     unsigned int* ws = (unsigned int*)lds;
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(1024) void spec_accum_kernel(FuseOne F, FuseIndex i
     const unsigned int j_begin = part * OT_FUSE_CPW;
     const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
     for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
-    for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
+    for (int i = threadIdx.x; i < OT_OBS_N * 6; i += blockDim.x) obs[i] = table[OT_OBS6_OFF + i];
     __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
     for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
         const unsigned int c = ix.list[c0 + j_begin + i];
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(1024) void spec_accum_kernel(FuseOne F, FuseIndex i
             if (pix < 0) continue;
             const double wm = (double)rec[k].w * F.a.ws;
             double xo, yo, zo;
-            observer_xyz_at(obs, (double)rec[k].wl, xo, yo, zo);
+            observer_xyz_at6(obs, (double)rec[k].wl, xo, yo, zo);
             const int lx = px - ox, ly = py - oy;
             if ((unsigned)lx < (unsigned)OT_TILE_W && (unsigned)ly < (unsigned)OT_TILE_W) {
                 double* hv = tile + ((ly << 6) | lx);  // plane-major window, see fuse_accum_kernel

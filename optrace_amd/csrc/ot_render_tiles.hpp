@@ -208,11 +208,11 @@ __global__ __launch_bounds__(1024) void tile_accum_kernel(TileArgs t, const doub
     if (!wk.spread[0]) return;
     const int c = blockIdx.x;
     if (c >= wk.chunk_start[t.K]) return;
-    extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 3 observer table]
+    extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 6 observer table: (value, difference) pairs]
     double* tile = lds;
     double* obs = lds + OT_TILE_PX * 4;
     for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
-    for (int i = threadIdx.x; i < OT_OBS_N * 3; i += blockDim.x) obs[i] = table[i];
+    for (int i = threadIdx.x; i < OT_OBS_N * 6; i += blockDim.x) obs[i] = table[OT_OBS6_OFF + i];
     // the tile of this chunk: last tile whose first chunk is <= c
     int lo = 0, hi = t.K - 1;
     while (lo < hi) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void tile_accum_kernel(TileArgs t, const doub
         const TileRec rec = wk.rec[r];
         const double wm = (double)rec.w * t.a.ws;
         double xo, yo, zo;
-        observer_xyz_at(obs, (double)rec.wl, xo, yo, zo);
+        observer_xyz_at6(obs, (double)rec.wl, xo, yo, zo);
         // plane-major tile [channel][pixel]: the lanes of one add spread over 16 bank pairs (with 4 doubles per pixel
         // they share 4, a 16-way bank conflict on every add)
         double* hv = tile + (int)rec.px;
