@@ -26,7 +26,9 @@
 #ifndef OT_FUSE_WG_PER_CU
 #define OT_FUSE_WG_PER_CU 2  // ... and its persistent workgroups per CU (A/B: 1024 threads x 1, profiles/r4/tile_kernel_wg_ab.txt)
 #endif
+#ifndef OT_FUSE_CPW
 #define OT_FUSE_CPW 256      // chunks per accumulation workgroup (and slab): 64 records per thread
+#endif
 #define OT_FUSE_NONE 0xffffffffu
 #define OT_FUSE_LDS_ENTRIES 2400  // (detector, tile) entries a tile-kernel workgroup can keep (20 B each)
 
