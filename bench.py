@@ -200,8 +200,9 @@ def measure_config(ot, torch, lib, build, N, user_extent=None, positions=None):
     """One BASELINE configuration at its full ray count on this GPU, after the timed region:
     `trace_ms` = duration of the trace kernel from the library's HIP events (median of 5 after a short settle),
     `roofline_frac` = SURVEY 8(d) bytes of `RayStorage` / trace_ms / 8 TB/s; `detector_image_ms` (wall time of the call,
-    median of 5) with an automatic and with a given extent, `frac` against N * 56 B + Ny * Nx * 32 B; with `positions`
-    `iterative_render_ms` for those detector positions (config 4: N rays in storage-sized chunks, one trace per chunk)."""
+    median of 5) with an automatic and with a given extent, `frac` against N * 56 B + Ny * Nx * 32 B; `iterative_render` =
+    the chunked render of N rays end to end (one position with the extent found above, or `positions` with `user_extent`:
+    config 4's six)."""
     from optrace_amd import _capi
     with ot.global_options.no_warnings():
         RT = build(ot)
@@ -241,17 +242,18 @@ def measure_config(ot, torch, lib, build, N, user_extent=None, positions=None):
             out["detector_image_user"] = det_entry(ms, img)
             out["detector_image_user"]["extent"] = ext
             del img
-        if positions is not None:
-            exts = [list(user_extent)] * len(positions)
-            RT.iterative_render(N, pos=positions, extent=exts)  # untimed: allocator pools at this chunk size
+        if RT.detectors:  # the chunked render end to end: trace of every chunk (render-only but the last) + binning
+            n_pos = 1 if positions is None else len(positions)
+            kw = dict(extent=ext) if positions is None else dict(pos=positions, extent=[list(user_extent)] * n_pos)
+            RT.iterative_render(N, **kw)  # untimed: allocator pools at this chunk size
             torch.cuda.synchronize()
             ts = []
             for _ in range(3):
                 t0 = time.perf_counter()
-                RT.iterative_render(N, pos=positions, extent=exts)
+                RT.iterative_render(N, **kw)
                 torch.cuda.synchronize()
                 ts.append(1e3 * (time.perf_counter() - t0))
-            out["iterative_render"] = {"ms": _median(ts), "positions": len(positions), "extent": "user",
+            out["iterative_render"] = {"ms": _median(ts), "positions": n_pos, "extent": "user",
                                        "rays_per_s": N / (_median(ts) * 1e-3)}
         _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 0))
     del RT

@@ -20,8 +20,8 @@ build, N = bc.CONFIGS[name]
 with ot.global_options.no_warnings():
     RT = build(ot)
     RT.trace(N)
-    ext = [-8., 8., -8., 8.] if which == "C4" and not AUTO else None
+    ext = None if AUTO else ([-8., 8., -8., 8.] if which == "C4" else ([-45., 45., -45., 45.] if which == "C2" else None))
     for _ in range(reps):
-        img = RT.detector_image(extent=ext) if ext else RT.detector_image()
+        img = RT.detector_image(extent=ext, _keep_on_device=True) if ext else RT.detector_image(_keep_on_device=True)
 torch.cuda.synchronize()
 print(name, N, img.power())
