@@ -62,7 +62,7 @@ SCENES = {
 
 
 @pytest.mark.parametrize("name", list(SCENES))
-@pytest.mark.parametrize("N", [70_001, 1_300_000])
+@pytest.mark.parametrize("N", [1, 63, 65, 70_001, 1_300_000])
 def test_tail_records_are_the_stored_sections_bit_for_bit(name, N):
     """Same seed through `trace(N)` and `trace(N, _tail=...)`: the set of (p[nt-2], p[nt-1], w[nt-2], wl) over the rays alive
     in the last section is identical; every slot in use beyond them carries weight 0; counters equal."""
