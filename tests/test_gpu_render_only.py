@@ -9,12 +9,11 @@ render are the stored path's (same pixels lit, sums to 1e-11: the hits arrive in
 last chunk's rays stay in the tracer; scenes and detector positions the form does not serve go through the ray storage."""
 import numpy as np
 import pytest
-import torch
 
 import optrace_amd as ot
 from optrace_amd.ray_storage import TailStorage
 import scenes
-from test_gpu_fused_detector import same_image, image_scene
+from test_gpu_fused_detector import same_image
 
 pytestmark = pytest.mark.gpu
 
