@@ -292,6 +292,13 @@ class Raytracer(Group):
         return (tuple(map(id, self.lenses)), tuple(map(id, self.apertures)), tuple(map(id, self.filters)),
                 tuple(map(id, self.ray_sources)))
 
+    def _scene_unchanged(self) -> bool:
+        """Is everything the last full trace established (checks passed, compiled scene, source table) still valid?  One
+        integer comparison, the identities of the list members and the bytes of the few small writeable arrays."""
+        fast = self._fast
+        return (fast is not None and fast[0] == _base.mutation_epoch() and fast[1] == self._structure()
+                and not self.geometry_error and all(a.tobytes() == b for a, b in fast[5]))
+
     def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None, _N_list=None,
               _chunk: int = 0, _power_scale: float = 1.0, _tail: TailStorage = None) -> None:
         """Trace N rays through the current geometry.
@@ -314,8 +321,7 @@ class Raytracer(Group):
         if _tail is not None and _initial_rays is not None:
             raise ValueError("a render-only trace generates its rays on the device")
         fast = self._fast
-        if (fast is not None and fast[0] == _base.mutation_epoch() and fast[1] == self._structure()
-                and not self.geometry_error and all(a.tobytes() == b for a, b in fast[5])):
+        if self._scene_unchanged():
             check_type("N", N, int)
             if N < 1:
                 raise ValueError(f"Ray number N needs to be at least 1, but is {N}.")
@@ -473,7 +479,13 @@ class Raytracer(Group):
             k = sp.get("detector_index", 0)
             det = self.detectors[k]
             if sp.get("pos") is not None:
+                # moving a detector changes nothing a trace depends on: the change counter (base.mutation_epoch) stays
+                # where it was, so that the next trace of an iterative render still takes its shortcut -- unless the
+                # detector shares its surface object with a tracing element (then the move IS a change of the scene)
+                epoch = _base._EPOCH[0]
                 det.move_to(sp["pos"])
+                if all(det.surface is not ts for ts in self.tracing_surfaces):
+                    _base._EPOCH[0] = epoch
             dsurf = det.surface
 
             method = sp.get("projection_method", "Equidistant")
@@ -931,7 +943,8 @@ class Raytracer(Group):
         that is the ray's last section, which is all a render-only trace keeps."""
         if any(rs.orientation == "Function" for rs in self.ray_sources):  # (their generation needs a position pre-pass)
             return False
-        self._compile()
+        if not (self._scene_unchanged() and self._scene_handle is not None):
+            self._compile()
         if not _capi.load_library().ot_scene_tail_supported(self._scene_handle):
             return False
         z_last = max([surf.z_max for surf in self.tracing_surfaces] + [rs.extent[5] for rs in self.ray_sources])
@@ -977,7 +990,7 @@ class Raytracer(Group):
         extentc = per_image(extent, "extent", isinstance(extent, list) and not isinstance(extent[0], (int, float)))
 
         n_sec = len(self.tracing_surfaces) + 2
-        if self._pretrace_check(min(N, 1000)):
+        if not self._scene_unchanged() and self._pretrace_check(min(N, 1000)):
             raise RuntimeError("Geometry checks failed. Tracing aborted. Check the warnings.")
         # Only the rays of the LAST chunk stay in the tracer (raytracer.py:1235-1267).  Every chunk before it is traced
         # render-only where the scene and the detector positions allow it: no section is stored, the living rays' last

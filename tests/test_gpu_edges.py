@@ -684,3 +684,37 @@ def test_padded_plane_stride_equals_packed_storage(monkeypatch):
         else:
             assert np.array_equal(a[key], b[key], equal_nan=True), key
     assert a["msgs"].sum() > 0 and a["img_auto"][..., 3].sum() > 0 and a["hurb_msgs"].sum() > 0
+
+
+def test_moving_a_detector_keeps_the_trace_shortcut_unless_it_shares_its_surface():
+    """`iterative_render` moves its detector from position to position (raytracer.py:1244).  That changes nothing a trace
+    depends on, so the unchanged-scene shortcut of `trace` survives it (one integer comparison instead of a snapshot per
+    chunk) -- unless the detector's surface object also belongs to a tracing element: then the move is a change of the
+    scene and the next trace sees it."""
+    from optrace_amd import base as _base
+    with ot.global_options.no_warnings():
+        RT = scenes.c1_single_lens(ot, seed=3)
+        RT.trace(50_000)
+        assert RT._scene_unchanged()
+        e0 = _base.mutation_epoch()
+        a = RT.iterative_render(120_000, pos=[[0, 0, 18.], [0, 0, 22.]], extent=[[-2, 2, -2, 2]] * 2)
+        assert _base.mutation_epoch() == e0 and RT._scene_unchanged(), "detector moves must not look like scene changes"
+        assert a[0].power() > 0 and not np.array_equal(a[0]._data, a[1]._data)
+        # a real change is still seen
+        RT.lenses[0].move_to([0, 0, 1.0])
+        assert not RT._scene_unchanged()
+        RT.trace(50_000)
+        # a detector that shares its surface with an aperture: moving it moves the aperture
+        RT2 = ot.Raytracer(outline=[-5, 5, -5, 5, -5, 40], seed=1)
+        RT2.add(ot.RaySource(ot.CircularSurface(r=1), divergence="None", s=[0, 0, 1], pos=[0, 0, 0]))
+        RT2.add(ot.Aperture(ot.RingSurface(r=3, ri=0.5), pos=[0, 0, 10]))
+        RT2.add(ot.Detector(ot.RectangularSurface(dim=[4, 4]), pos=[0, 0, 30]))
+        RT2.trace(20_000)
+        z_before = float(RT2.rays.p_list[:, 1, 2].max())
+        # (elements copy the surfaces they are given, so this takes force: the detector now IS the aperture's surface object)
+        RT2.detectors[0].__dict__["front"] = RT2.apertures[0].front
+        assert RT2.detectors[0].surface is RT2.apertures[0].front
+        RT2._detector_requests([dict(detector_index=0, pos=[0, 0, 14.0])])
+        assert not RT2._scene_unchanged()
+        RT2.trace(20_000)
+        assert abs(float(RT2.rays.p_list[:, 1, 2].max()) - 14.0) < 1e-9 and abs(z_before - 10.0) < 1e-9
