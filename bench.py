@@ -287,13 +287,29 @@ def configs_block(ot, torch, lib, scenes):
 def c4_sharded_block(ot, torch, lib, scenes, dist, use_dist, backend, dev, world, steps=3):
     """BASELINE config 4 AS STATED: image_render_many_rays.py, 2e8 rays sharded over the ranks, six detector positions,
     one RCCL reduce of the six stacked histograms -- `distributed.sharded_iterative_render` (every rank traces its shard
-    once, in storage-sized chunks, and bins each chunk into all positions in one pass over the sections).  Strong
+    once, in render-only chunks plus one stored chunk, and bins each chunk into all positions in one pass).  Strong
     scaling: the 2e8 rays are the job's.  -> dict on every rank (the caller prints rank 0's)."""
+    return sharded_block(ot, torch, lib, dist, use_dist, backend, dev, world, scenes.c4_image_render, 200_000_000,
+                         scenes.C4_POSITIONS, [[-8., 8., -8., 8.]] * len(scenes.C4_POSITIONS),
+                         "image_render_many_rays.py geometry, 2e8 rays sharded over the ranks, six detector positions "
+                         "(user extents), distributed.sharded_iterative_render", "c4_sharded_ms", steps)
+
+
+def c5_sharded_block(ot, torch, lib, scenes, dist, use_dist, backend, dev, world, steps=3):
+    """BASELINE config 5 as stated: hurb_apertures.py's slit + lens, HURB on, polarisation tracked, 1e8 rays sharded over
+    the ranks, the detector image with an AUTOMATIC extent: the ranks agree on the extent of their first chunks' hits (one
+    MIN and one MAX all-reduce of 2 doubles each, raytracer.py:1042-1049, 1262) before they bin, then one histogram
+    reduce."""
+    return sharded_block(ot, torch, lib, dist, use_dist, backend, dev, world, lambda o: scenes.hurb_slit_lens(o, seed=51),
+                         100_000_000, None, None,
+                         "hurb_apertures.py slit + lens, HURB on, polarisation on, 1e8 rays sharded over the ranks, one "
+                         "detector image with an automatic extent (extent agreement + histogram reduce), "
+                         "distributed.sharded_iterative_render", "c5_sharded_ms", steps)
+
+
+def sharded_block(ot, torch, lib, dist, use_dist, backend, dev, world, build, N, pos, ext, workload, key, steps):
     from optrace_amd import _capi
     from optrace_amd import distributed as D
-    N = 200_000_000
-    pos = scenes.C4_POSITIONS
-    ext = [[-8., 8., -8., 8.]] * len(pos)
     on_host = use_dist and backend != "nccl"
 
     def sync():
@@ -303,7 +319,7 @@ def c4_sharded_block(ot, torch, lib, scenes, dist, use_dist, backend, dev, world
         torch.cuda.synchronize()
 
     with ot.global_options.no_warnings():
-        RT = scenes.c4_image_render(ot)
+        RT = build(ot)
         RT.trace(100_000)
         _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 1))
         D.sharded_iterative_render(RT, N, pos=pos, extent=ext, base_seed=1)  # untimed: tables, allocator pools, communicator
@@ -336,11 +352,10 @@ def c4_sharded_block(ot, torch, lib, scenes, dist, use_dist, backend, dev, world
     t = t.cpu().tolist()
     del RT, imgs, stack
     _release(torch, lib)
-    return {"workload": "image_render_many_rays.py geometry, 2e8 rays sharded over the ranks, six detector positions "
-                        "(user extents), distributed.sharded_iterative_render", "rays_total": N, "n_gpus": world,
-            "scaling": "strong", "positions": len(pos), "c4_sharded_ms": 1e3 * t[0], "rays_per_s": N / t[0],
+    return {"workload": workload, "rays_total": N, "n_gpus": world,
+            "scaling": "strong", "positions": len(shapes), key: 1e3 * t[0], "rays_per_s": N / t[0],
             "trace_ms_per_rank_min_max": [-t[2], t[1]], "histogram_allreduce_ms": t[3],
-            "histogram_bytes": int(len(pos) * shapes[0][0] * shapes[0][1] * 32), "image_shapes": shapes,
+            "histogram_bytes": int(sum(sh[0] * sh[1] * 32 for sh in shapes)), "image_shapes": shapes,
             "image_power": power, "backend": backend if use_dist else None}
 
 
@@ -501,7 +516,7 @@ def main():
     cpu = None
     if rank == 0 and not args.skip_cpu and world == 1:  # CPU leg on rank 0 at N = 1 only (reads the first sections of the
         cpu = cpu_baseline(RT, scene, args.cpu_seconds)  # headline's storage: before that is released)
-    cfgs = sharded = None
+    cfgs = sharded = sharded5 = None
     if not args.skip_configs:
         del img, hist
         RT.rays.__init__()
@@ -509,6 +524,7 @@ def main():
         if world == 1:
             cfgs = configs_block(ot, torch, lib, scenes)
         sharded = c4_sharded_block(ot, torch, lib, scenes, dist if use_dist else None, use_dist, backend, dev, world)
+        sharded5 = c5_sharded_block(ot, torch, lib, scenes, dist if use_dist else None, use_dist, backend, dev, world)
 
     if rank == 0:
         pol = not args.no_pol
@@ -567,6 +583,8 @@ def main():
             out["configs"] = cfgs
         if sharded is not None:
             out["c4_sharded"] = sharded
+        if sharded5 is not None:
+            out["c5_sharded"] = sharded5
         if other is not None:
             out["no_pol"] = other  # BASELINE config C2 is quoted with polarisation on and off: the other setting
         if cpu is not None:
