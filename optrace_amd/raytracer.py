@@ -110,7 +110,8 @@ class Raytracer(Group):
     # bookkeeping of the tracer itself: writing these is not a scene change (base.mutation_epoch)
     _INTERNAL = frozenset(("_msgs", "_last_trace_snapshot", "_scene", "_scene_handle", "_scene_key", "_checked_key",
                            "_rays_known_current", "_source_cache", "geometry_error", "fault_pos", "_fast",
-                           "_msgs_host", "_kernel_ms_log", "_tail_book", "_lock", "_new_lock"))
+                           "_msgs_host", "_kernel_ms_log", "_tail_book", "_lock", "_new_lock",
+                           "seed"))  # (the RNG seed is read at every trace and part of nothing that is compiled or checked)
 
     def __setattr__(self, key: str, val: Any) -> None:
         if key in self._INTERNAL:
