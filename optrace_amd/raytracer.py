@@ -459,20 +459,24 @@ class Raytracer(Group):
                     f"numerical hit finding at detector {detector_index}. "
                     "Where and whether they intersect might be wrong.")
 
-    def _detector_requests(self, specs: list, rays=None) -> list:
+    def _detector_requests(self, specs: list, rays=None, no_rays: bool = False) -> list:
         """Checks of `_hit_detector` (raytracer.py:897-920) and, per spec, everything the device calls need:
         dicts with Ns, Ne (ray range), surf_desc, projection (name), crop (user extent or None), desc, centre.
-        `rays`: a `TailStorage` to take the rays from instead of `self.rays` (all its slots, no per-source ranges)."""
+        `rays`: a `TailStorage` to take the rays from instead of `self.rays` (all its slots, no per-source ranges);
+        `no_rays`: no storage yet (`_plan_renders` before the first trace): nothing about rays is checked or recorded."""
         if not self.detectors:
             raise RuntimeError("Detector Missing")
-        if rays is None:
+        if rays is None and not no_rays:
             self._need_rays()
         ranges = []
         for sp in specs:  # all indices first: nothing is moved or launched for a bad request
-            ranges.append(self._ray_range(sp.get("source_index")) if rays is None else (0, int(rays.N)))
+            if no_rays:  # (a plan made before the rays exist: it ranges over the whole of whatever storage it is launched on)
+                ranges.append((0, 0))
+            else:
+                ranges.append(self._ray_range(sp.get("source_index")) if rays is None else (0, int(rays.N)))
             if not 0 <= sp.get("detector_index", 0) < len(self.detectors):
                 raise IndexError("Invalid detector_index.")
-        if rays is None:
+        if rays is None and not no_rays:
             self._need_current()
 
         out = []
@@ -551,9 +555,23 @@ class Raytracer(Group):
         `rays`: a `TailStorage` (render-only chunk) instead of `self.rays`; `weight_scale`: every hit's weight times this (in
         f64) before it is added -- the chunks of an iterative render bin straight into one image with rays_step / N each.
         -> RenderImages (raytracer.py:1053-1098 for each spec)."""
-        reqs = self._detector_requests(specs, rays)
-        src_rays = self.rays if rays is None else rays
-        images, calls = [], {}
+        plan = self._plan_renders(specs, limits, into=into, rays=rays)
+        self._launch_renders(plan, rays=rays, weight_scale=weight_scale)
+        images = plan["images"]
+        if not kwargs.get("_dont_filter", False):
+            for img in images:
+                if img._limit is not None:
+                    img._apply_rayleigh_filter()
+        return images
+
+    def _plan_renders(self, specs: list, limits: list, into: list = None, rays=None, whole_storage: bool = False) -> dict:
+        """Everything `_render_detectors` does on the host before the launch: checks, the detectors moved to their positions,
+        one `RenderImage` per spec with its fixed extent and pixel grid, the histograms (one zero-filled allocation for all
+        images that have none yet) and the request records of `ot_detector_images`.  `whole_storage`: the requests range over
+        whatever storage `_launch_renders` is given (no source_index) -- `iterative_render` plans once, before its first trace
+        where the extents are known, and launches the plan chunk after chunk."""
+        reqs = self._detector_requests(specs, rays, no_rays=whole_storage)
+        images, calls, shapes = [], {}, []
         dev = require_device()
         for n, (sp, rq, limit) in enumerate(zip(specs, reqs, limits)):
             label = rq["desc"]
@@ -571,31 +589,41 @@ class Raytracer(Group):
             img._fix_extent()
             Nx, Ny = img._pixel_counts()
             tgt = None if into is None else into[n]
+            if tgt is not None and tuple(tgt.shape) != (Ny, Nx, 4):
+                raise ValueError("histogram to accumulate into has the wrong shape")
+            images.append(img)
+            shapes.append((Ny, Nx, tgt))
+        # the new histograms: ONE zero-filled allocation, sliced (six images of an iterative render: one fill kernel)
+        sizes = [Ny * Nx * 4 if tgt is None else 0 for Ny, Nx, tgt in shapes]
+        pool = alloc_retry(lambda: torch.zeros(sum(sizes), dtype=torch.float64, device=dev)) if sum(sizes) else None
+        off = 0
+        for n, (img, rq, (Ny, Nx, tgt)) in enumerate(zip(images, reqs, shapes)):
             if tgt is not None:
-                if tuple(tgt.shape) != (Ny, Nx, 4):
-                    raise ValueError("histogram to accumulate into has the wrong shape")
                 hist = tgt.view(-1)
             else:
-                hist = alloc_retry(lambda: torch.zeros(Ny * Nx * 4, dtype=torch.float64, device=dev))
+                hist = pool[off:off + sizes[n]]
+                off += sizes[n]
             img._dev = hist.view(Ny, Nx, 4)
             img._host = None
-            images.append(img)
-            calls.setdefault((rq["Ns"], rq["Ne"]), []).append(
+            calls.setdefault(None if whole_storage else (rq["Ns"], rq["Ne"]), []).append(
                 (n, dict(surf_desc=rq["surf_desc"], projection=_capi.PROJECTIONS[rq["projection"]], crop=rq["crop"],
-                         extent=img.extent, Nx=Nx, Ny=Ny, hist=hist, weight_scale=weight_scale)))
-        for (Ns, Ne), part_all in calls.items():
+                         extent=img.extent, Nx=Nx, Ny=Ny, hist=hist)))
+        return dict(images=images, calls=calls, detector_indices=[sp.get("detector_index", 0) for sp in specs])
+
+    def _launch_renders(self, plan: dict, rays=None, weight_scale: float = 1.0) -> None:
+        """`ot_detector_images` for a plan of `_plan_renders`, on `rays` (a `TailStorage`) or `self.rays`."""
+        src_rays = self.rays if rays is None else rays
+        for key, part_all in plan["calls"].items():
+            Ns, Ne = (0, int(src_rays.N)) if key is None else key
+            if Ne <= Ns:  # (a render-only chunk none of whose rays survived)
+                continue
             for b in range(0, len(part_all), 8):
                 part = part_all[b:b + 8]
-                if Ne <= Ns:  # (a render-only chunk none of whose rays survived)
-                    continue
+                for _, r in part:
+                    r["weight_scale"] = weight_scale
                 ills = _detector.detector_images(src_rays, Ns, Ne - Ns, [r for _, r in part])
                 for (n, _), ill_count in zip(part, ills):
-                    self._warn_ill(ill_count, specs[n].get("detector_index", 0))
-        if not kwargs.get("_dont_filter", False):
-            for img in images:
-                if img._limit is not None:
-                    img._apply_rayleigh_filter()
-        return images
+                    self._warn_ill(ill_count, plan["detector_indices"][n])
 
     def _auto_extents(self, specs: list, agree=None, sample_rays: int = None, rays=None) -> list:
         """Automatic extents (raytracer.py:1042-1049) of the specs without a user extent, from an extent-only pass over
@@ -1021,11 +1049,37 @@ class Raytracer(Group):
                 # ms, 66 666 688 in 3.4 ms); the last chunk takes what is left
                 rays_step = -(-rays_step // 1024) * 1024
             chunks = [rays_step] * (iterations - 1) + [N - (iterations - 1) * rays_step]
-        images: list = []
         tail = TailStorage() if render_only and len(chunks) > 1 else None
 
         nt = n_sec
         msgs_cum = np.zeros((len(self.INFOS), n_sec), dtype=int)
+
+        # Up to 8 positions are intersected in one pass over the sections, hit search and binning fused (`ot_detector_images`);
+        # the extents are given by the caller or fixed by the first chunk (raytracer.py:1262).  The reference scales every
+        # chunk's image by rays_step / N and adds it (raytracer.py:1257-1264); here the factor rides with the weights into the
+        # binning (`weight_scale`, applied in f64), so that every chunk is binned straight into the one image of its position:
+        # no second set of histograms, no passes over them.  The host side of a group of positions -- detectors moved, images
+        # with their grids, one zero-filled allocation, the request records -- is a PLAN made once (`_plan_renders`): before
+        # the first trace where the caller gave the extents, right after it otherwise, and launched chunk after chunk (the
+        # gap between a trace and its binning was 0.15-0.3 ms of host work per chunk: a fifth of a rank's time when 2e8 rays
+        # are sharded over eight GPUs).
+        groups = [list(range(j0, min(j0 + 8, len(pos)))) for j0 in range(0, len(pos), 8)]
+        plans = [None] * len(groups)
+        images = [None] * len(pos)
+
+        def specs_of(group):
+            return [dict(detector_index=detector_index[j], extent=extentc[j], projection_method=projection_method[j],
+                         pos=pos[j]) for j in group]
+
+        def make_plan(gi, specs):
+            plans[gi] = self._plan_renders(specs, [limit[j] for j in groups[gi]], whole_storage=True)
+            for g, j in enumerate(groups[gi]):
+                images[j] = plans[gi]["images"][g]
+                extentc[j] = images[j]._extent0
+
+        for gi, group in enumerate(groups):
+            if all(extentc[j] is not None for j in group):
+                make_plan(gi, specs_of(group))
 
         for i, n_i in enumerate(chunks):  # one chunk of rays per iteration (raytracer.py:1235-1267)
             src = tail if (tail is not None and i < len(chunks) - 1) else None
@@ -1034,24 +1088,11 @@ class Raytracer(Group):
                 msgs_cum += self._msgs
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
-                # up to 8 positions are intersected in one pass over the sections, hit search and binning fused
-                # (`ot_detector_images`); the extents are given by the caller or fixed by the first chunk (raytracer.py:1262).
-                # The reference scales every chunk's image by rays_step / N and adds it (raytracer.py:1257-1264); here the
-                # factor rides with the weights into the binning (`weight_scale`, applied in f64), so that every chunk is
-                # binned straight into the one image of its position: no second set of histograms, no passes over them
-                for j0 in range(0, len(pos), 8):
-                    group = list(range(j0, min(j0 + 8, len(pos))))
-                    specs = [dict(detector_index=detector_index[j], extent=extentc[j],
-                                  projection_method=projection_method[j], pos=pos[j]) for j in group]
-                    into = [images[j]._dev if i else None for j in group]
-                    if not all(extentc[j] is not None for j in group):  # first chunk: extents from their own pass
-                        specs = self._auto_extents(specs, agree=_agree_extents, sample_rays=self.ITER_EXTENT_RAYS, rays=src)
-                    imgs = self._render_detectors(specs, [limit[j] for j in group], into=into, rays=src,
-                                                  weight_scale=n_i / N, _dont_filter=True)
-                    if i == 0:
-                        for g, j in enumerate(group):
-                            images.append(imgs[g])
-                            extentc[j] = imgs[g]._extent0
+                for gi, group in enumerate(groups):
+                    if plans[gi] is None:  # automatic extents: those of this, the first chunk (an extent-only pass or a sample)
+                        make_plan(gi, self._auto_extents(specs_of(group), agree=_agree_extents,
+                                                         sample_rays=self.ITER_EXTENT_RAYS, rays=src))
+                    self._launch_renders(plans[gi], rays=src, weight_scale=n_i / N)
             finally:
                 self._rays_known_current = False
         if tail is not None:
