@@ -985,6 +985,36 @@ class Raytracer(Group):
                 return False
         return True
 
+    def _chunk_plan(self, N: int, n_sec: int, render_only: bool) -> list:
+        """Ray counts of the chunks of an iterative render of N rays (raytracer.py:1216-1217, 1238-1239): with
+        ITER_RAYS_STEP set, the reference's rule; otherwise chunks sized by storage -- with render-only chunks: as large as
+        ITER_STORAGE_BYTES of tail storage and one launch allow, then one stored chunk of ITER_LAST_RAYS."""
+        rays_step = self.ITER_RAYS_STEP  # None: sized by storage
+        if rays_step is not None:  # the reference's rule (raytracer.py:1216-1217, 1238-1239)
+            iterations = max(N // rays_step, 1)
+            chunks = [rays_step] * (iterations - 1) + [N - (iterations - 1) * rays_step]
+        elif render_only and N > self.ITER_LAST_RAYS:
+            # one stored chunk of ITER_LAST_RAYS at the end; before it render-only chunks as large as ITER_STORAGE_BYTES
+            # of tail storage (60 B per ray at most) and one launch (2^28 rays) allow
+            rest = N - self.ITER_LAST_RAYS
+            most = min(1 << 28, self.ITER_STORAGE_BYTES // 60) // 1024 * 1024
+            k = -(-rest // most)
+            step = -(-(-(-rest // k)) // 1024) * 1024
+            chunks = [step] * (k - 1) + [rest - (k - 1) * step] + [self.ITER_LAST_RAYS]
+        else:
+            # chunk = what ITER_STORAGE_BYTES of ray storage hold (the reference's 1 M rays are sized for a few GB of
+            # host RAM, raytracer.py:40); chunks of equal size, at least 1 M rays
+            step_max = max(1_000_000, self.rays.max_rays_for_size(self.ITER_STORAGE_BYTES, n_sec, self.no_pol))
+            iterations = -(-N // step_max)
+            rays_step = -(-N // iterations)
+            if iterations > 1:
+                # a multiple of 1024 rays: the planes of the storage then start on 128-byte lines.  With an odd count
+                # every wave's store straddles a line it shares with its neighbour (C4: 66 666 667 rays traced in 4.8
+                # ms, 66 666 688 in 3.4 ms); the last chunk takes what is left
+                rays_step = -(-rays_step // 1024) * 1024
+            chunks = [rays_step] * (iterations - 1) + [N - (iterations - 1) * rays_step]
+        return chunks
+
     def iterative_render(self, N, detector_index=0, limit=None, projection_method="Equidistant", pos=None,
                          extent=None, _power_scale: float = 1.0, _agree_extents=None, _finish: bool = True) -> list:
         """Render detector images from N rays traced in chunks of ITER_RAYS_STEP; images of all chunks
@@ -1025,30 +1055,7 @@ class Raytracer(Group):
         # render-only where the scene and the detector positions allow it: no section is stored, the living rays' last
         # sections go to a compact storage the detector passes read (`trace(_tail=...)`, TailStorage)
         render_only = self.ITER_RENDER_ONLY and self._render_only_applies(detector_index, pos)
-        rays_step = self.ITER_RAYS_STEP  # None: sized by storage
-        if rays_step is not None:  # the reference's rule (raytracer.py:1216-1217, 1238-1239)
-            iterations = max(N // rays_step, 1)
-            chunks = [rays_step] * (iterations - 1) + [N - (iterations - 1) * rays_step]
-        elif render_only and N > self.ITER_LAST_RAYS:
-            # one stored chunk of ITER_LAST_RAYS at the end; before it render-only chunks as large as ITER_STORAGE_BYTES
-            # of tail storage (60 B per ray at most) and one launch (2^28 rays) allow
-            rest = N - self.ITER_LAST_RAYS
-            most = min(1 << 28, self.ITER_STORAGE_BYTES // 60) // 1024 * 1024
-            k = -(-rest // most)
-            step = -(-(-(-rest // k)) // 1024) * 1024
-            chunks = [step] * (k - 1) + [rest - (k - 1) * step] + [self.ITER_LAST_RAYS]
-        else:
-            # chunk = what ITER_STORAGE_BYTES of ray storage hold (the reference's 1 M rays are sized for a few GB of
-            # host RAM, raytracer.py:40); chunks of equal size, at least 1 M rays
-            step_max = max(1_000_000, self.rays.max_rays_for_size(self.ITER_STORAGE_BYTES, n_sec, self.no_pol))
-            iterations = -(-N // step_max)
-            rays_step = -(-N // iterations)
-            if iterations > 1:
-                # a multiple of 1024 rays: the planes of the storage then start on 128-byte lines.  With an odd count
-                # every wave's store straddles a line it shares with its neighbour (C4: 66 666 667 rays traced in 4.8
-                # ms, 66 666 688 in 3.4 ms); the last chunk takes what is left
-                rays_step = -(-rays_step // 1024) * 1024
-            chunks = [rays_step] * (iterations - 1) + [N - (iterations - 1) * rays_step]
+        chunks = self._chunk_plan(N, n_sec, render_only)
         tail = TailStorage() if render_only and len(chunks) > 1 else None
 
         nt = n_sec

@@ -455,3 +455,35 @@ def test_no_large_writeable_arrays_on_tracked_objects():
         RT.add(ot.RaySource(ot.GrayscaleImage(scenes.synthetic_gray_image(), [4, 3]), pos=[0, 0, 1],
                             spectrum=ot.LightSpectrum("Data", wls=np.linspace(400., 700., 50), vals=np.linspace(1., 2., 50))))
         assert writeable_arrays(RT) == []
+
+
+def test_chunk_plan_of_an_iterative_render():
+    """`Raytracer._chunk_plan`: with ITER_RAYS_STEP the reference's rule (raytracer.py:1216-1217, 1238-1239: N // step
+    iterations, the last one takes the remainder); otherwise by storage -- render-only chunks as large as the tail storage
+    and one launch allow, then ONE stored chunk of ITER_LAST_RAYS; without render-only chunks equal chunks that fit
+    ITER_STORAGE_BYTES of ray storage.  Every plan sums to N, chunks before the last are multiples of 1024 rays."""
+    RT = ot.Raytracer(outline=[-5, 5, -5, 5, 0, 10])
+    old = (ot.Raytracer.ITER_RAYS_STEP, ot.Raytracer.ITER_LAST_RAYS, ot.Raytracer.ITER_STORAGE_BYTES)
+    try:
+        ot.Raytracer.ITER_RAYS_STEP = 1_000_000
+        assert RT._chunk_plan(3_500_000, 4, True) == [1_000_000, 1_000_000, 1_500_000]
+        assert RT._chunk_plan(999, 4, True) == [999]
+        ot.Raytracer.ITER_RAYS_STEP = None
+        last = ot.Raytracer.ITER_LAST_RAYS
+        assert RT._chunk_plan(last, 4, True) == [last]
+        assert RT._chunk_plan(last + 5, 4, True) == [5, last]
+        plan = RT._chunk_plan(200_000_000, 4, True)
+        assert plan == [200_000_000 - last, last]
+        for N in (10 ** 9, 3 * 10 ** 8 + 17, (1 << 28) + last + 1):
+            plan = RT._chunk_plan(N, 4, True)
+            assert sum(plan) == N and plan[-1] == last and len(plan) >= 2
+            assert all(0 < n <= min(1 << 28, ot.Raytracer.ITER_STORAGE_BYTES // 60) for n in plan[:-1])
+            assert all(n % 1024 == 0 for n in plan[:-2])
+        # through the ray storage: equal chunks that fit the budget
+        RT.no_pol = True
+        plan = RT._chunk_plan(200_000_000, 4, False)
+        assert sum(plan) == 200_000_000 and len(plan) == 3 and all(n % 1024 == 0 for n in plan[:-1])
+        assert max(plan) * (4 * 36 + 28) <= ot.Raytracer.ITER_STORAGE_BYTES * 1.01
+        assert RT._chunk_plan(500_000, 4, False) == [500_000]
+    finally:
+        ot.Raytracer.ITER_RAYS_STEP, ot.Raytracer.ITER_LAST_RAYS, ot.Raytracer.ITER_STORAGE_BYTES = old
