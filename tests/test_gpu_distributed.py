@@ -240,3 +240,36 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
     # both ranks' 1 M-ray bundles: 5 sources of unit power, part of it absorbed at the stop
     assert 1.0 < out["detector"]["image_power_all_ranks"] <= 10.0
+    # configs 4 and 5 as stated, sharded over the two ranks: the renders with their exchanges
+    for key, n_img in (("c4_sharded", 6), ("c5_sharded", 1)):
+        blk = out[key]
+        assert blk["n_gpus"] == 2 and blk["scaling"] == "strong" and blk["positions"] == n_img
+        assert blk[key + "_ms"] > 0 and blk["histogram_allreduce_ms"] > 0
+        assert len(blk["image_power"]) == n_img and all(p > 0 for p in blk["image_power"])
+    assert "configs" not in out, "the per-configuration block is rank 0's at one GPU"
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_carries_every_baseline_config():
+    """One GPU: the driver's line has the `configs` block (C1 at 1e7 rays, C3, C4, C5, A1 at full size: trace kernel time and
+    roofline fraction, detector image with an automatic and a given extent, the chunked render) and both sharded blocks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "2", "--skip-cpu"], env=env,
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and 0.3 < out["roofline"]["frac"] < 1.0
+    cfgs = out["configs"]
+    assert set(cfgs) == {"C1_single_lens_1e7", "C3_arizona_eye_rgb_5e7", "C4_image_render_2e8", "C5_hurb_slit_lens_1e8",
+                         "A1_double_gauss_aspheric_1e7"}
+    for name, c in cfgs.items():
+        assert "error" not in c, (name, c)
+        assert c["trace_ms"] > 0 and 0.05 < c["roofline_frac"] < 1.0
+        assert c["algorithmic_bytes"] == c["rays"] * (c["sections"] * (48 if c["pol"] else 36) + 28)
+        for key in ("detector_image_auto", "detector_image_user"):
+            assert c[key]["ms"] > 0 and 0 < c[key]["frac"] < 1.0
+        assert c["iterative_render"]["ms"] >= c["trace_ms"] * 0.5
+    assert cfgs["C4_image_render_2e8"]["iterative_render"]["positions"] == 6
+    assert out["c4_sharded"]["n_gpus"] == 1 and out["c5_sharded"]["rays_total"] == 100_000_000
