@@ -72,6 +72,8 @@ class Raytracer(Group):
     ITER_LAST_RAYS: int = 1 << 20
     """... and the last chunk, whose rays stay in `self.rays` afterwards like those of the reference's last iteration
     (ITER_RAYS_STEP = 1 M there, raytracer.py:40, 1235-1267), then has this many rays."""
+    ITER_GROUP: int = 8
+    """Detector positions per pass over a chunk's rays (at most 8: `ot_detector_images`)."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
     """Ray storage of one chunk of `iterative_render` when ITER_RAYS_STEP is None: 16 GB of the 288 GB of HBM are
     19 M rays of a 15-surface scene with polarisation or 93 M rays of a two-surface scene without."""
@@ -1070,7 +1072,7 @@ class Raytracer(Group):
         # the first trace where the caller gave the extents, right after it otherwise, and launched chunk after chunk (the
         # gap between a trace and its binning was 0.15-0.3 ms of host work per chunk: a fifth of a rank's time when 2e8 rays
         # are sharded over eight GPUs).
-        groups = [list(range(j0, min(j0 + 8, len(pos)))) for j0 in range(0, len(pos), 8)]
+        groups = [list(range(j0, min(j0 + self.ITER_GROUP, len(pos)))) for j0 in range(0, len(pos), self.ITER_GROUP)]
         plans = [None] * len(groups)
         images = [None] * len(pos)
 

@@ -13,6 +13,8 @@ import optrace_amd as ot
 import scenes
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 200_000_000
+if len(sys.argv) > 2:
+    ot.Raytracer.ITER_GROUP = int(sys.argv[2])  # detector positions per pass
 pos = scenes.C4_POSITIONS
 with ot.global_options.no_warnings():
     for mode in (True, False, True):
