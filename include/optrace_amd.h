@@ -366,8 +366,8 @@ int ot_generate_and_trace_host(const ot_scene* scene, const ot_sources* src,
  * ot_detector_extent_sample, ot_detector_image_auto_*) take `tail` with count = result2[0] like any other storage;
  * they give the images of the stored path for every detector that lies behind the last tracing surface.  The order
  * of the rays is not the order of generation (no per-source ranges).  msgs_host as for
- * ot_generate_and_trace_host.  Scenes whose surfaces need the numeric hit search: OT_ERR_UNSUPPORTED
- * (ot_scene_tail_supported tells beforehand). */
+ * ot_generate_and_trace_host.  Every scene has the form (ot_scene_tail_supported: 1 for a valid handle; kept for callers
+ * written against ABI 7, where scenes with a numeric hit search had none). */
 int64_t ot_tail_capacity(int64_t n_rays);
 int ot_scene_tail_supported(const ot_scene* scene);
 int ot_generate_and_trace_tail(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,

@@ -1110,9 +1110,15 @@ static int launch_trace(const ot_scene* sc_c, const ot_sources* src, const Range
         L.pol = pol;
         L.gen = src != nullptr;
         L.spec = (src && lines) ? 2 : (tab ? 1 : 0);
-        if (tail) {  // (ot_generate_and_trace_tail has checked the feature level)
-            if (feat == OT_FEAT(OT_HIT_CLOSED, 0)) launch_trace_tail_feat<OT_FEAT(OT_HIT_CLOSED, 0)>(L, *tail);
-            else launch_trace_tail_feat<OT_FEAT(OT_HIT_CLOSED, 1)>(L, *tail);
+        if (tail) {  // the render-only form of the same feature level
+            switch (feat) {
+                case OT_FEAT(OT_HIT_CLOSED, 0): launch_trace_tail_feat<OT_FEAT(OT_HIT_CLOSED, 0)>(L, *tail); break;
+                case OT_FEAT(OT_HIT_CLOSED, 1): launch_trace_tail_feat<OT_FEAT(OT_HIT_CLOSED, 1)>(L, *tail); break;
+                case OT_FEAT(OT_HIT_ILLINOIS, 0): launch_trace_tail_feat<OT_FEAT(OT_HIT_ILLINOIS, 0)>(L, *tail); break;
+                case OT_FEAT(OT_HIT_ILLINOIS, 1): launch_trace_tail_feat<OT_FEAT(OT_HIT_ILLINOIS, 1)>(L, *tail); break;
+                case OT_FEAT(OT_HIT_SPLINE, 0): launch_trace_tail_feat<OT_FEAT(OT_HIT_SPLINE, 0)>(L, *tail); break;
+                default: launch_trace_tail_feat<OT_FEAT(OT_HIT_SPLINE, 1)>(L, *tail); break;
+            }
             continue;
         }
         switch (feat) {
@@ -1214,9 +1220,7 @@ extern "C" int64_t ot_tail_capacity(int64_t n_rays) {
     return 65536 * std::max<int64_t>(1, (waves + OT_TAIL_PIECES - 1) / OT_TAIL_PIECES);
 }
 
-extern "C" int ot_scene_tail_supported(const ot_scene* scene) {
-    return scene && scene->hit_level == OT_HIT_CLOSED ? 1 : 0;
-}
+extern "C" int ot_scene_tail_supported(const ot_scene* scene) { return scene ? 1 : 0; }  // (every feature level has the form)
 
 extern "C" int ot_generate_and_trace_tail(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,
                                           int32_t n_ranges, uint64_t seed, int64_t n_rays, const ot_rays* tail,
@@ -1224,8 +1228,6 @@ extern "C" int ot_generate_and_trace_tail(const ot_scene* scene, const ot_source
     if (!scene || !src || !tail || !fill || !result2 || !msgs_host)
         return fail(OT_ERR_INVALID, "ot_generate_and_trace_tail: null argument");
     if (n_rays < 1) return fail(OT_ERR_INVALID, "ot_generate_and_trace_tail: no rays");
-    if (scene->hit_level != OT_HIT_CLOSED)
-        return fail(OT_ERR_UNSUPPORTED, "ot_generate_and_trace_tail: scenes with a numeric hit search take ot_generate_and_trace");
     if (tail->nt != 2 || !tail->p || !tail->w || !tail->wl)
         return fail(OT_ERR_INVALID, "ot_generate_and_trace_tail: the tail storage has two sections and needs p, w and wl");
     if (tail->N < ot_tail_capacity(n_rays) || tail->N % 65536)

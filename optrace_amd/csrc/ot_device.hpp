@@ -783,17 +783,26 @@ OT_HD double filter_T(FD& f, PL pool, float wl32) {
 // k = rint(2 t), then the fdlibm kernels on |x| <= pi / 4 (errors < 1 ulp).  About 30 instructions against ~80 of the
 // device library's sincospi with its general range reduction.
 OT_DEV void sincospi_small(double t, double* sn, double* cs) {
-#pragma clang fp contract(fast)
+    // explicit fused multiply-adds (not `#pragma clang fp contract`): every kernel that generates rays -- stored and
+    // render-only forms, every feature level -- must form the SAME bits, whatever the code around the call looks like
     const double k = rint(2.0 * t);
-    const double x = (t - 0.5 * k) * 3.141592653589793;  // exact subtraction, |x| <= pi / 4
+    const double x = __builtin_fma(-0.5, k, t) * 3.141592653589793;  // exact subtraction, |x| <= pi / 4
     const double z = x * x;
     // __kernel_sin / __kernel_cos (fdlibm), argument reduced exactly so the tail terms vanish
-    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
-    const double s0 = x + x * z * ps;
-    const double c0 = 1.0 - 0.5 * z + z * z * pc;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(z, ps, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(z, pc, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double s0 = __builtin_fma(x * z, ps, x);
+    const double c0 = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
     const int q = (int)k & 3;  // rotation by q quarter turns (two's complement & 3 is the quadrant for negative k too)
     const double s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
     *sn = (q & 2) ? -s1 : s1;

@@ -186,7 +186,6 @@ OT_DEV void fill_dither_for(GenCtx& g, SRC& src) {
 
 // random.stratified_interval_sampling random.py:48-67: one of n strata of [a, b), uniformly dithered
 OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double b) {
-#pragma clang fp contract(fast)  // (generation is statistical, nothing here feeds a hit mask: fused multiply-adds allowed)
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
     double dba = (b - a) * g.inv_n;
     return a + stratum_plus_dither(g, dither_slot(stream), (double)k) * dba;
@@ -194,7 +193,6 @@ OT_DEV double strat_interval(const GenCtx& g, uint32_t stream, double a, double 
 
 // the same for a stratum index the caller already has (a second stream tied to another one's permutation, see generate_ray)
 OT_DEV double strat_interval_at(const GenCtx& g, uint32_t k, uint32_t stream, double a, double b) {
-#pragma clang fp contract(fast)  // (generation is statistical, nothing here feeds a hit mask: fused multiply-adds allowed)
     double dba = (b - a) * g.inv_n;
     return a + stratum_plus_dither(g, dither_slot(stream), (double)k) * dba;
 }
@@ -202,7 +200,6 @@ OT_DEV double strat_interval_at(const GenCtx& g, uint32_t k, uint32_t stream, do
 // random.stratified_rectangle_sampling random.py:8-45: floor(sqrt(n))^2 jittered grid cells, the remaining
 // n - N2^2 samples uniform over the rectangle
 OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, double c, double d, double& x, double& y) {
-#pragma clang fp contract(fast)  // (generation is statistical, nothing here feeds a hit mask: fused multiply-adds allowed)
     uint32_t k = permute_index(g.j, g.n, stream_key(g.seed, g.range, stream));
     const int slot = dither_slot(stream);
     if ((g.n & (g.n - 1u)) == 0u && g.n >= 4u) {
@@ -235,7 +232,6 @@ OT_DEV void strat_rect(const GenCtx& g, uint32_t stream, double a, double b, dou
 // random.stratified_ring_sampling random.py:70-110: Shirley's equal-area square->disc map, then disc->annulus.
 // polar == false: cartesian (x, y); polar == true: (|r|, theta / pi) with theta shifted by -pi for negative r.
 OT_DEV void strat_ring(const GenCtx& g, uint32_t stream, double ri, double r, bool polar, double& o0, double& o1) {
-#pragma clang fp contract(fast)  // (generation is statistical, nothing here feeds a hit mask: fused multiply-adds allowed)
     double x, y;
     strat_rect(g, stream, -r, r, -r, r, x, y);
     double x2 = x * x, y2 = y * y;
@@ -377,7 +373,6 @@ OT_DEV uint32_t pixel_pick_finish(SRC& src, const PixelPick& pk, int npx, const 
 // image source to the formula kernels, and the bench kernel keeps the 76 registers it needs without that path).
 template <bool IMAGES = true, class SRC>
 OT_DEV NewRay generate_ray(SRC& src, const GenCtx& g, bool no_pol) {
-#pragma clang fp contract(fast)  // (generation is statistical, nothing here feeds a hit mask: fused multiply-adds allowed)
     NewRay o;
     o.w = g.w;  // power / N, ray_source.py:220
     const bool image = IMAGES && src.shape >= OT_SRC_IMAGE_RGB;

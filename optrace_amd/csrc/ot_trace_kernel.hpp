@@ -312,8 +312,10 @@ __global__ __launch_bounds__(256, OT_TRACE_WAVES(FEAT, SPEC, POL)) void trace_ta
                 if ((float)ltab[j] == r.wl) lj = j;
         }
         const ot_rays none = {};
+        // spline level: 25 doubles per lane behind the counters for the spline patch cache (as in trace_kernel)
+        double* patch = (FEAT / 2 >= OT_HIT_SPLINE) ? lds + n_tab + (n_cnt + 2) / 2 : nullptr;
         bool ok = trace_ray<POL, SPEC, FEAT, true>(sc, none, local, (uint64_t)ray, r, (const double*)nullptr, seed, cnt, ltab, lj,
-                                                   (double*)nullptr, &tail);
+                                                   patch, &tail);
         if (!ok) cnt[n_cnt - 1] = 1u;
     }
     // the living rays of this wave, compacted

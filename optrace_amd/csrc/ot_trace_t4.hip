@@ -1,0 +1,4 @@
+// trace_tail_kernel variants (render-only chunks) of feature level OT_FEAT(OT_HIT_SPLINE, 0): spline surfaces
+#include "ot_trace_kernel.hpp"
+
+OT_DEFINE_TRACE_TAIL_LAUNCHER(OT_FEAT(OT_HIT_SPLINE, 0))

@@ -67,8 +67,8 @@ class Raytracer(Group):
     """`iterative_render`: every chunk but the last is traced render-only -- no section is stored, the last section of
     every ray alive behind the last surface goes to a compact `TailStorage` (56 B per LIVING ray instead of 36-48 B per
     ray and section), which the detector passes read -- wherever that gives the stored path's images: scenes of flat and
-    conic surfaces (ot_scene_tail_supported), no orientation="Function" source, every detector position behind the last
-    tracing surface.  False: every chunk through the ray storage."""
+    no orientation="Function" source, every detector position behind the last tracing surface (every feature level of the
+    trace kernel has its render-only form).  False: every chunk through the ray storage."""
     ITER_LAST_RAYS: int = 1 << 20
     """... and the last chunk, whose rays stay in `self.rays` afterwards like those of the reference's last iteration
     (ITER_RAYS_STEP = 1 M there, raytracer.py:40, 1235-1267), then has this many rays."""
@@ -973,10 +973,6 @@ class Raytracer(Group):
         detector sees a ray through the section that crosses it (raytracer.py:929-985); behind the last tracing surface
         that is the ray's last section, which is all a render-only trace keeps."""
         if any(rs.orientation == "Function" for rs in self.ray_sources):  # (their generation needs a position pre-pass)
-            return False
-        if not (self._scene_unchanged() and self._scene_handle is not None):
-            self._compile()
-        if not _capi.load_library().ot_scene_tail_supported(self._scene_handle):
             return False
         z_last = max([surf.z_max for surf in self.tracing_surfaces] + [rs.extent[5] for rs in self.ray_sources])
         for k, p in zip(detector_index, pos):

@@ -6,7 +6,7 @@ render-only trace stores no section and writes that last section for the living 
 Checked here: the records are the stored path's, bit for bit (same seed: same generation, same arithmetic -- the stored
 path is what the reference fixtures pin, tests/test_gpu_parity.py, test_gpu_parity_paths.py); the images of an iterative
 render are the stored path's (same pixels lit, sums to 1e-11: the hits arrive in another order); counters are equal; the
-last chunk's rays stay in the tracer; scenes and detector positions the form does not serve go through the ray storage."""
+last chunk's rays stay in the tracer; sources and detector positions the form does not serve go through the ray storage."""
 import numpy as np
 import pytest
 
@@ -57,6 +57,10 @@ SCENES = {
     "hurb_slit_lens": lambda **kw: hurb_scene(ot, **kw),
     "relay_with_stop": lambda **kw: relay_with_stop(ot, **kw),
     "c1_single_lens": lambda **kw: scenes.c1_single_lens(ot, **kw),
+    # the numeric hit levels: aspheres (+ filters, a slit, with and without HURB: feature levels 2 and 3), spline surfaces
+    "asphere": lambda **kw: scenes.asphere_scene(ot, **kw),
+    "asphere_hurb": lambda **kw: scenes.asphere_scene(ot, use_hurb=True, **kw),
+    "freeform": lambda **kw: scenes.freeform_scene(ot, **kw),
 }
 
 
@@ -104,7 +108,8 @@ def test_iterative_render_render_only_equals_stored_path(name):
         out = {}
         for mode in (True, False):
             RT = SCENES[name](seed=5)
-            det = RT.detectors[0]
+            di = int(np.argmax([d.pos[2] for d in RT.detectors]))  # the detector behind the last surface
+            det = RT.detectors[di]
             z0 = float(det.pos[2])
             z_last = max(s.z_max for s in RT.tracing_surfaces)
             pos = [[0, 0, z] for z in (z0, 0.5 * (z0 + z_last) + 0.1, z0 - 0.3)]
@@ -119,7 +124,7 @@ def test_iterative_render_render_only_equals_stored_path(name):
 
             RT.trace = spy
             with settings(ITER_RAYS_STEP=n, ITER_RENDER_ONLY=mode, ITER_EXTENT_RAYS=1 << 60):
-                imgs = RT.iterative_render(3 * n + 77, pos=pos, extent=exts)
+                imgs = RT.iterative_render(3 * n + 77, detector_index=di, pos=pos, extent=exts)
             del RT.trace
             assert traced == [(n, mode), (n, mode), (n + 77, False)], "the last chunk always goes through the storage"
             assert RT.rays.N == n + 77
@@ -185,14 +190,20 @@ def test_scenes_and_positions_the_form_does_not_serve_take_the_storage():
         z_mid = 0.5 * (RT.lenses[2].back.pos[2] + RT.apertures[0].pos[2])
         assert not RT._render_only_applies([0, 0], [RT.detectors[0].pos, [0, 0, z_mid]])
         assert RT._render_only_applies([0], [RT.detectors[0].pos])
-        # aspheres: numeric hit search
-        RA = scenes.asphere_scene(ot, seed=2)
-        assert not RA._render_only_applies([1], [RA.detectors[1].pos])
+        # a source whose orientation is a Python callable: its generation needs a position pre-pass on the host
+        RA = ot.Raytracer(outline=[-10, 10, -10, 10, -25, 60], seed=2)
+        RA.add(ot.RaySource(ot.RectangularSurface(dim=[2, 3]), divergence="None", orientation="Function",
+                            or_func=lambda x, y: np.tile([0., 0., 1.], (x.shape[0], 1)), pos=[0, 0, -20],
+                            spectrum=ot.LightSpectrum("Monochromatic", wl=550.)))
+        RA.add(ot.Lens(ot.SphericalSurface(r=3, R=8), ot.SphericalSurface(r=3, R=-8), de=0.1,
+                       n=ot.RefractionIndex("Constant", n=1.5), pos=[0, 0, 0]))
+        RA.add(ot.Detector(ot.RectangularSurface(dim=[4, 4]), pos=[0, 0, 20]))
+        assert not RA._render_only_applies([0], [RA.detectors[0].pos])
         tails = []
         orig = RA.trace
         RA.trace = lambda N, **kw: (tails.append(kw.get("_tail") is not None), orig(N, **kw))[1]
         with settings(ITER_RAYS_STEP=50_000):
-            imgs = RA.iterative_render(150_000, detector_index=1)
+            imgs = RA.iterative_render(150_000)
         del RA.trace
         assert tails == [False] * 3 and imgs[0].power() > 0
         with pytest.raises(ValueError):
