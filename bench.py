@@ -334,19 +334,27 @@ def sharded_block(ot, torch, lib, dist, use_dist, backend, dev, world, build, N,
         sync()
         trace_ms = sum(log) / steps  # this rank's trace kernels per render (all its chunks)
         RT._kernel_ms_log = None
-        # the exchange alone: the six stacked histograms once more (values irrelevant)
+        # the exchange alone, as the render does it (the window of lit pixels of all histograms in one message) and whole
+        tr, tw = [], []
+        for _ in range(3):
+            sync()
+            t1 = time.perf_counter()
+            D.allreduce_images([im._dev for im in imgs])
+            torch.cuda.synchronize()
+            tr.append(1e3 * (time.perf_counter() - t1))
+        sent = dict(D.last_exchange)
         stack = torch.stack([im._dev for im in imgs])
-        tr = []
         for _ in range(3):
             sync()
             t1 = time.perf_counter()
             D.allreduce_image(stack)
             torch.cuda.synchronize()
-            tr.append(1e3 * (time.perf_counter() - t1))
+            tw.append(1e3 * (time.perf_counter() - t1))
         power = [float(im.power()) for im in imgs]
         shapes = [list(im._dev.shape) for im in imgs]
         _capi.check(lib.ot_scene_set_timing(RT._scene_handle, 0))
-    t = torch.tensor([_median(ts), trace_ms, -trace_ms, _median(tr)], dtype=torch.float64, device="cpu" if on_host else dev)
+    t = torch.tensor([_median(ts), trace_ms, -trace_ms, _median(tr), _median(tw)], dtype=torch.float64,
+                     device="cpu" if on_host else dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t = t.cpu().tolist()
@@ -355,6 +363,8 @@ def sharded_block(ot, torch, lib, dist, use_dist, backend, dev, world, build, N,
     return {"workload": workload, "rays_total": N, "n_gpus": world,
             "scaling": "strong", "positions": len(shapes), key: 1e3 * t[0], "rays_per_s": N / t[0],
             "trace_ms_per_rank_min_max": [-t[2], t[1]], "histogram_allreduce_ms": t[3],
+            "histogram_bytes_sent": sent["bytes"], "lit_window": sent["window"],
+            "whole_histograms_allreduce_ms": t[4],
             "histogram_bytes": int(sum(sh[0] * sh[1] * 32 for sh in shapes)), "image_shapes": shapes,
             "image_power": power, "backend": backend if use_dist else None}
 
@@ -501,7 +511,7 @@ def main():
     if use_dist:
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
-        D.allreduce_image(hist)  # the one exchange step: all-reduce of the (Ny, Nx, 4) f64 histogram
+        D.allreduce_images([hist])  # the one exchange step: all-reduce of the (Ny, Nx, 4) f64 histogram (its lit window)
         torch.cuda.synchronize()
         t_red = time.perf_counter() - tr0
         cnt = D.allreduce_counters(RT._msgs, device=None if on_host else dev)

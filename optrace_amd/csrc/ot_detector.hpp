@@ -177,7 +177,9 @@ OT_DEV V3 pair_direction(const SectionPair& sp) {
 // That case, for a flat detector, settled from the prefetched pair of sections without the section search of
 // detector_hit (same arithmetic, same results: the search would pick this section, raytracer.py:929-985); rays that
 // end before the detector are settled too (no hit).  Returns false for a lane that needs the general search.
-template <class DET>
+// CONIC: conic detectors as well (else flat ones only: the fused kernels, which keep the conic code out of their tile
+// loops); CROP = false leaves the user extent to the caller (who projects first).
+template <bool CONIC = false, bool CROP = true, class DET>
 OT_DEV bool detector_hit_last(DET& D, int nt, bool active, const SectionPair& sp, const V3& sdir, V3& ph, float& w,
                               bool& valid) {
     const auto& det = D.det;
@@ -187,13 +189,13 @@ OT_DEV bool detector_hit_last(DET& D, int nt, bool active, const SectionPair& sp
     if (!active) return true;
     const bool reaches = sp.zl >= det.z_min;
     if (!reaches && !(sp.zl >= det.z_max)) return true;  // np.all(~bh_zmin & ~bh_zmax): ends before the detector
-    if (!(det.flat && nt >= 2 && reaches && !(sp.zq >= det.z_min))) return false;
+    if (!((CONIC || det.flat) && nt >= 2 && reaches && !(sp.zq >= det.z_min))) return false;
     const V3 p = {sp.xq, sp.yq, sp.zq};
     bool ish, ill;
-    find_hit<OT_HIT_CLOSED>(det, p, sdir, ph, ish, ill);
+    find_hit<OT_HIT_CLOSED>(det, p, sdir, ph, ish, ill);  // (closed forms report no ill-conditioned hits)
     w = (ph.z > sp.zl + OT_C_EPS) ? 0.f : sp.wq;  // a hit behind the end of the ray is none (raytracer.py:985)
     valid = ish && (w > 0);
-    if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
+    if (CROP && D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
     return true;
 }
 
@@ -225,7 +227,7 @@ OT_DEV void detector_hit_pair(DET& D, bool active, const SectionPair& sp, const 
 // -> valid, ph (projected), w; any_ill / timeout report the numeric hit search.
 // PROJ = false leaves the sphere projections out (their atan / tan polynomials cost ~64 VGPRs of hoisted constants once
 // the hit search sits inside a loop).
-template <bool NUMERIC, bool PROJ = true, class DET>
+template <bool NUMERIC, bool PROJ = true, bool CROP = true, class DET>
 OT_DEV void detector_hit(const ot_rays& R, int64_t r, bool active, DET& D, const SectionPair& sp, const V3& sdir, V3& ph,
                          float& w, bool& valid, bool& any_ill, bool& timeout) {
     const int64_t N = R.N;
@@ -312,24 +314,14 @@ OT_DEV void detector_hit(const ot_rays& R, int64_t r, bool active, DET& D, const
     valid = active && ish && (w > 0);
     if (PROJ && valid) sphere_project(det.px, det.py, det.pz, D.Rcurv, D.projection, ph);
     // user extent: hits outside are dropped (raytracer.py:1036-1040)
-    if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
+    if (CROP && D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
 }
 
-template <bool NUMERIC, class DET>
-OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, int64_t count, DET& D, const SectionPair& sp,
-                         const V3& sdir, double (*sext)[4][4], int di) {
+// What becomes of a ray's hit: the entry of the (compact or dense) hit list, the counters, the extent (step one).
+template <class DET>
+OT_DEV void detector_emit(const ot_rays& R, int64_t q, int64_t r, bool active, int64_t count, DET& D, const V3& ph, float w,
+                          bool valid, bool any_ill, bool timeout, double (*sext)[4][4], int di) {
     const int lane = __lane_id();
-    {
-    V3 ph;
-    float w;
-    bool valid, any_ill = false, timeout = false;
-    // flat detector behind the last surface without a sphere projection (the usual case): settled from the prefetched
-    // pair of sections; the section search only if a lane of the wave needs it
-    bool settled = false;
-    if (!NUMERIC && (D.projection == OT_PROJ_NONE || D.projection == OT_PROJ_ORTHOGRAPHIC)) settled = detector_hit_last(D, R.nt, active, sp, sdir, ph, w, valid);
-    if (__ballot(!settled) != 0ull) {
-        if (!settled) detector_hit<NUMERIC>(R, r, active, D, sp, sdir, ph, w, valid, any_ill, timeout);
-    }
     if (D.fill) {
         // Compact list: the wave's valid hits go, in any order, to the next free entries of a piece.  Ranks inside the
         // wave from the ballot, the wave's base from ONE returning atomic on the piece's fill count; no barrier -- the
@@ -344,8 +336,9 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
             unsigned int base = 0u;
             if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&D.fill[piece], (unsigned int)__popcll(m));
             base = (unsigned int)__shfl((int)base, (int)__ffsll((long long)m) - 1);
+            base += (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
             if (valid) {
-                const int64_t i = (piece << D.piece_shift) + base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+                const int64_t i = (piece << D.piece_shift) + base;
                 if (D.ph) {  // (weights and wavelengths alone serve the detector spectrum)
                     D.ph[i] = ph.x;
                     D.ph[i + ((int64_t)OT_HIT_PIECES_N << D.piece_shift)] = ph.y;  // the y plane follows the x plane's capacity
@@ -374,7 +367,27 @@ OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, in
         if (lane == 0)
             for (int c = 0; c < 4; c++) sext[di][wave][c] = e[c];
     }
+}
+
+template <bool NUMERIC, class DET>
+OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, int64_t count, DET& D, const SectionPair& sp,
+                         const V3& sdir, double (*sext)[4][4], int di) {
+    V3 ph;
+    float w;
+    bool valid, any_ill = false, timeout = false;
+    // detector with a closed-form hit behind the last surface (the usual case): settled from the prefetched pair of
+    // sections; the section search only if a lane of the wave needs it.  Sphere projection and user extent follow either
+    // way (ONE copy of the projections' polynomials, outside of the search's loop: with them inside, every ray of a
+    // spherical detector took the general path -- BASELINE config 3's retina, 0.92 ms for the hit kernel of 5e7 rays)
+    bool settled = false;
+    if (!NUMERIC) settled = detector_hit_last<true, false>(D, R.nt, active, sp, sdir, ph, w, valid);
+    if (__ballot(!settled) != 0ull) {
+        if (!settled) detector_hit<NUMERIC, false, false>(R, r, active, D, sp, sdir, ph, w, valid, any_ill, timeout);
     }
+    if (valid) sphere_project(D.det.px, D.det.py, D.det.pz, D.Rcurv, D.projection, ph);
+    // user extent: hits outside are dropped (raytracer.py:1036-1040)
+    if (D.crop.on) valid = valid && D.crop.x0 <= ph.x && ph.x <= D.crop.x1 && D.crop.y0 <= ph.y && ph.y <= D.crop.y1;
+    detector_emit(R, q, r, active, count, D, ph, w, valid, any_ill, timeout, sext, di);
 }
 
 // Extent, step two, once per workgroup behind ONE barrier for all detectors of the launch: the four waves' values of

@@ -138,3 +138,91 @@ def test_k_image_extent_agreement_and_stacked_histogram_exchange(tmp_path):
     # without a process group the helpers are the identity
     raw = np.array([[0.0, 1.0, 2.0, 3.0]])
     np.testing.assert_array_equal(D.allreduce_extents(raw), raw)
+
+
+# ---- allreduce_images: one message, lit window only ---------------------------------------------------------------------
+def test_lit_window_and_block_view():
+    pool = torch.zeros(3 * 6 * 7 * 4, dtype=torch.float64)
+    hists = [pool[k * 168:(k + 1) * 168].view(6, 7, 4) for k in range(3)]
+    block = D._as_one_block(hists)
+    assert block is not None and block.shape == (3, 6, 7, 4) and block.data_ptr() == pool.data_ptr()
+    assert D._as_one_block([hists[0], hists[2]]) is None                    # a gap
+    assert D._as_one_block([hists[0], torch.zeros(6, 7, 4, dtype=torch.float64)]) is None  # another allocation
+    assert D.lit_window(block).tolist() == [6, 0, 7, 0]                     # all dark: an empty window
+    hists[0][2, 3, 3] = 1.0
+    hists[2][4, 1, 0] = -2.0                                                # (any channel counts)
+    assert D.lit_window(block).tolist() == [2, -5, 1, -4]
+    block[1, 0, 6, 1] = 5.0
+    assert D.lit_window(block).tolist() == [0, -5, 1, -7]
+    # without a process group: nothing to exchange
+    assert D.allreduce_images(hists) == dict(bytes=0, window=None)
+    with pytest.raises(TypeError):
+        D.allreduce_images([torch.zeros(3, 3, 4)])
+
+
+def _worker_img(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5 + rank)
+    res = {}
+
+    def images(K, Ny, Nx, y0, y1, x0, x1, pooled=True):
+        if pooled:
+            pool = torch.zeros(K * Ny * Nx * 4, dtype=torch.float64)
+            hs = [pool[k * Ny * Nx * 4:(k + 1) * Ny * Nx * 4].view(Ny, Nx, 4) for k in range(K)]
+        else:
+            hs = [torch.zeros(Ny, Nx, 4, dtype=torch.float64) for _ in range(K)]
+        for h in hs:
+            h[y0:y1, x0:x1] = torch.from_numpy(rng.random((y1 - y0, x1 - x0, 4)))
+        return hs
+
+    # 1) a picture in a part of the extent, the ranks' windows differ: the union travels
+    hs = images(3, 40, 50, 10 + rank, 20 + rank, 5, 15 + 2 * rank)
+    mine = [h.clone() for h in hs]
+    info = D.allreduce_images(hs)
+    res["win"], res["win_bytes"] = np.array(info["window"]), info["bytes"]
+    res["a_sum"], res["a_mine"] = torch.stack(hs).numpy(), torch.stack(mine).numpy()
+    # 2) separate allocations: stacked, exchanged, copied back
+    hs = images(2, 30, 30, 3, 9, 4, 8, pooled=False)
+    mine = [h.clone() for h in hs]
+    info = D.allreduce_images(hs)
+    res["b_bytes"] = info["bytes"]
+    res["b_sum"], res["b_mine"] = torch.stack(hs).numpy(), torch.stack(mine).numpy()
+    # 3) the picture fills the extent: the histograms travel whole
+    hs = images(2, 16, 16, 0, 16, 1, 16)
+    mine = [h.clone() for h in hs]
+    info = D.allreduce_images(hs)
+    res["c_window_is_none"], res["c_bytes"] = info["window"] is None, info["bytes"]
+    res["c_sum"], res["c_mine"] = torch.stack(hs).numpy(), torch.stack(mine).numpy()
+    # 4) nobody has a hit; 5) shapes differ: one exchange per image
+    info = D.allreduce_images(images(2, 8, 8, 0, 0, 0, 0))
+    res["d_bytes"], res["d_window"] = info["bytes"], np.array(info["window"])
+    hs = images(1, 8, 9, 1, 3, 1, 3) + images(1, 9, 8, 2, 4, 2, 4)
+    mine = [h.clone() for h in hs]
+    info = D.allreduce_images(hs)
+    res["e_bytes"] = info["bytes"]
+    for k in range(2):
+        res[f"e_sum{k}"], res[f"e_mine{k}"] = hs[k].numpy(), mine[k].numpy()
+    np.savez(out + f".{rank}.npz", **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_histogram_exchange_sends_the_lit_window_only(tmp_path):
+    out = str(tmp_path / "img")
+    mp.spawn(_worker_img, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    np.testing.assert_array_equal(r0["win"], [10, 21, 5, 17])               # the union of rows 10-19 / 11-20, columns 5-14 / 5-16
+    assert int(r0["win_bytes"]) == 3 * 11 * 12 * 32 < 3 * 40 * 50 * 32
+    assert int(r0["b_bytes"]) == 2 * 6 * 4 * 32
+    assert bool(r0["c_window_is_none"]) and int(r0["c_bytes"]) == 2 * 16 * 16 * 32
+    assert int(r0["d_bytes"]) == 0 and not r0["d_window"].any()
+    assert int(r0["e_bytes"]) == (8 * 9 + 9 * 8) * 32
+    for key in ("a", "b", "c"):
+        want = r0[key + "_mine"] + r1[key + "_mine"]
+        np.testing.assert_array_equal(r0[key + "_sum"], want)               # two summands: no rounding order to speak of
+        np.testing.assert_array_equal(r1[key + "_sum"], want)               # identical on every rank
+    for k in range(2):
+        np.testing.assert_array_equal(r0[f"e_sum{k}"], r0[f"e_mine{k}"] + r1[f"e_mine{k}"])
