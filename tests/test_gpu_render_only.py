@@ -70,8 +70,25 @@ def test_tail_records_are_the_stored_sections_bit_for_bit(name, N):
     """Same seed through `trace(N)` and `trace(N, _tail=...)`: the set of (p[nt-2], p[nt-1], w[nt-2], wl) over the rays alive
     in the last section is identical; every slot in use beyond them carries weight 0; counters equal."""
     with ot.global_options.no_warnings():
-        RT = SCENES[name](seed=17)
+        check_tail_records(SCENES[name](seed=17), N)
+
+
+@pytest.mark.parametrize("hurb", [False, True])
+@pytest.mark.parametrize("scene_seed", range(3000, 3016))
+def test_tail_records_of_random_systems(scene_seed, hurb):
+    """Random sequential systems (tests/scenes.py::random_scene: lenses with flat / spherical / conic / aspheric / tilted
+    surfaces, ring and slit apertures, filters, ideal lenses, with and without polarisation; HURB on: the diffracting form
+    of every aperture) -- whatever kernel variant the scene compiler picks, its render-only form writes the same records."""
+    with ot.global_options.no_warnings():
+        RT = scenes.random_scene(ot, scene_seed, seed=scene_seed, use_hurb=hurb)
+        check_tail_records(RT, 50_003)
+
+
+def check_tail_records(RT, N):
+    if True:
         RT.trace(N)
+        if RT.geometry_error:
+            pytest.skip("random geometry collides")
         msgs = RT._msgs.copy()
         r = RT.rays
         nt = r.Nt
