@@ -1933,7 +1933,7 @@ extern "C" int ot_detector_images(const ot_rays* rays, int64_t first, int64_t co
                 hipLaunchKernelGGL(fuse_chunk_hist_multi_kernel, dim3(gc, 1, nd), dim3(1024), 0, st, dd, dix);
                 hipLaunchKernelGGL(fuse_chunk_scan_multi_kernel, dim3(1, 1, nd), dim3(1024), 0, st, dd, dix);
                 hipLaunchKernelGGL(fuse_chunk_place_multi_kernel, dim3(gc, 1, nd), dim3(1024), 0, st, dd, dix);
-                hipLaunchKernelGGL(fuse_accum_multi_kernel, dim3(n_slabs, 1, nd), dim3(1024), lds_accum, st, dd, dix, table);
+                hipLaunchKernelGGL(fuse_accum_multi_kernel, dim3(std::min<unsigned>(n_slabs, (unsigned)cus), 1, nd), dim3(1024), lds_accum, st, dd, dix, table);
                 hipLaunchKernelGGL(fuse_reduce_multi_kernel, dim3(OT_TILE_PX / 256, (unsigned)Kmax, nd), dim3(256), 0, st, dd, dix);
                 err = hipGetLastError();
             }
@@ -2159,7 +2159,7 @@ extern "C" int ot_detector_image_auto_finish(ot_auto_image* im_raw, const double
     hipLaunchKernelGGL(fuse_chunk_hist_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
     hipLaunchKernelGGL(fuse_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, f, ix);
     hipLaunchKernelGGL(fuse_chunk_place_kernel, dim3(gc), dim3(1024), 0, st, f, ix);
-    hipLaunchKernelGGL(spec_accum_kernel, dim3(ix.n_slabs), dim3(1024), lds_accum, st, f, ix, table);
+    hipLaunchKernelGGL(spec_accum_kernel, dim3(std::min<unsigned>(ix.n_slabs, (unsigned)cu_count())), dim3(1024), lds_accum, st, f, ix, table);
     hipLaunchKernelGGL(spec_reduce_kernel, dim3(OT_TILE_PX / 256, (unsigned)f.K), dim3(256), 0, st, f, ix);
     hipLaunchKernelGGL(spec_escaped_kernel, dim3(64), dim3(256), 0, st, f, table);
     HIP_TRY(hipGetLastError());

@@ -919,87 +919,93 @@ __global__ __launch_bounds__(1024) void fuse_chunk_place_multi_kernel(const Fuse
 // -- C4's picture covers a fifth of the detector, 42 of 225 tiles hold every record -- and a fixed number of workgroups
 // per tile left most CUs idle behind the few heavy tiles (1.7 of 4 waves per SIMD resident on average).  Workgroup b
 // finds its tile by bisection of wstart in LDS, adds its chunks into an LDS tile and writes slab b.
-OT_DEV void fuse_accum_body(const FuseOne& F, const FuseIndex& ix, const double* __restrict__ table, const unsigned int bx, const unsigned int by) {
+OT_DEV void fuse_accum_body(const FuseOne& F, const FuseIndex& ix, const double* __restrict__ table, const unsigned int bx, const unsigned int stride) {
     if (!F.spread[0]) return;
     extern __shared__ double lds[];  // [TILE_PX * 4 tile] [471 * 6 observer table: (value, difference) pairs]; the tile part first holds wstart
     double* tile = lds;
     double* obs = lds + OT_TILE_PX * 4;
     unsigned int* ws = (unsigned int*)lds;
     const int K = F.K;
-    const unsigned int b = bx;
-    if (b >= ix.wstart[K]) return;  // (the grid is sized for the worst case: most workgroups leave here, before the table)
-    for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
-    __syncthreads();
-    int lo = 0, hi = K;  // ws[lo] <= b < ws[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (ws[mid] <= b) lo = mid; else hi = mid;
-    }
-    const int t = lo;
-    const unsigned int part = b - ws[t];
-    __syncthreads();  // everyone has read ws: the tile may be cleared
-    const unsigned int c0 = ix.tstart[t], n_t = ix.tstart[t + 1] - c0;
-    const unsigned int j_begin = part * OT_FUSE_CPW;
-    const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
-    for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
+    // The grid holds as many workgroups as can be resident (one per CU: the tile takes the LDS); workgroup bx takes the slabs
+    // bx, bx + stride, ...  (One workgroup per slab of the WORST case -- every chunk of the pool in use -- meant thousands of
+    // launches that found nothing to do: 0.1-0.15 ms per pass of C4, and most of the short last chunk's 0.17 ms.)
+    const unsigned int total = ix.wstart[K];
+    if (bx >= total) return;
     for (int i = threadIdx.x; i < OT_OBS_N * 6; i += blockDim.x) obs[i] = table[OT_OBS6_OFF + i];
-    __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
-    for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
-        const unsigned int c = ix.list[c0 + j_begin + i];
-        s_chunk[i] = c;
-        s_fill[i] = F.chunk_fill[c];
-    }
-    __syncthreads();
-    // The workgroup's chunk numbers and fill counts go to LDS first (list -> fill -> record used to be three dependent
-    // round trips per round), and the records of round i + 1 are requested before those of round i are added.
-    constexpr int PER = 1024 / OT_FUSE_CH;  // chunks a workgroup handles at once
-    constexpr int DEPTH = 4;                // chunk rounds per stage; two stages in flight per thread
-    const int g = threadIdx.x / OT_FUSE_CH, slot = threadIdx.x % OT_FUSE_CH;
-    const int n_c = (int)(j_end - j_begin);
-    const TileRec* __restrict__ recs = F.rec;
-    auto load = [&](int first, TileRec* rec, bool* ok) {
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {
-            const int i = first + k * PER, ic = i < n_c ? i : 0;
-            ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
-            if (ok[k]) rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];
+    for (unsigned int b = bx; b < total; b += stride) {
+        for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
+        __syncthreads();
+        int lo = 0, hi = K;  // ws[lo] <= b < ws[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ws[mid] <= b) lo = mid; else hi = mid;
         }
-    };
-    auto add = [&](const TileRec* rec, const bool* ok) {
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {
-            if (!ok[k]) continue;
-            const double wm = (double)rec[k].w * F.a.ws;
-            double xo, yo, zo;
-            observer_xyz_at6(obs, (double)rec[k].wl, xo, yo, zo);
-            // plane-major tile [channel][pixel]: the lanes of one add then spread over 16 bank pairs; pixel-major
-            // (4 doubles per pixel) would leave them 4 and make every add a 16-way bank conflict
-            double* hv = tile + (int)rec[k].px;
-            unsafeAtomicAdd(hv + 0 * OT_TILE_PX, xo * wm);
-            unsafeAtomicAdd(hv + 1 * OT_TILE_PX, yo * wm);
-            unsafeAtomicAdd(hv + 2 * OT_TILE_PX, zo * wm);
-            unsafeAtomicAdd(hv + 3 * OT_TILE_PX, 1.0 * wm);
+        const int t = lo;
+        const unsigned int part = b - ws[t];
+        __syncthreads();  // everyone has read ws: the tile may be cleared
+        const unsigned int c0 = ix.tstart[t], n_t = ix.tstart[t + 1] - c0;
+        const unsigned int j_begin = part * OT_FUSE_CPW;
+        const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
+        for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
+        __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
+        for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
+            const unsigned int c = ix.list[c0 + j_begin + i];
+            s_chunk[i] = c;
+            s_fill[i] = F.chunk_fill[c];
         }
-    };
-    TileRec ra[DEPTH], rb[DEPTH];
-    bool oa[DEPTH], ob[DEPTH];
-    load(g, ra, oa);
-    for (int i0 = g; i0 < n_c; i0 += 2 * PER * DEPTH) {
-        load(i0 + PER * DEPTH, rb, ob);
-        add(ra, oa);
-        load(i0 + 2 * PER * DEPTH, ra, oa);
-        add(rb, ob);
+        __syncthreads();
+        // The workgroup's chunk numbers and fill counts go to LDS first (list -> fill -> record used to be three dependent
+        // round trips per round), and the records of round i + 1 are requested before those of round i are added.
+        constexpr int PER = 1024 / OT_FUSE_CH;  // chunks a workgroup handles at once
+        constexpr int DEPTH = 4;                // chunk rounds per stage; two stages in flight per thread
+        const int g = threadIdx.x / OT_FUSE_CH, slot = threadIdx.x % OT_FUSE_CH;
+        const int n_c = (int)(j_end - j_begin);
+        const TileRec* __restrict__ recs = F.rec;
+        auto load = [&](int first, TileRec* rec, bool* ok) {
+    #pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                const int i = first + k * PER, ic = i < n_c ? i : 0;
+                ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
+                if (ok[k]) rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];
+            }
+        };
+        auto add = [&](const TileRec* rec, const bool* ok) {
+    #pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                if (!ok[k]) continue;
+                const double wm = (double)rec[k].w * F.a.ws;
+                double xo, yo, zo;
+                observer_xyz_at6(obs, (double)rec[k].wl, xo, yo, zo);
+                // plane-major tile [channel][pixel]: the lanes of one add then spread over 16 bank pairs; pixel-major
+                // (4 doubles per pixel) would leave them 4 and make every add a 16-way bank conflict
+                double* hv = tile + (int)rec[k].px;
+                unsafeAtomicAdd(hv + 0 * OT_TILE_PX, xo * wm);
+                unsafeAtomicAdd(hv + 1 * OT_TILE_PX, yo * wm);
+                unsafeAtomicAdd(hv + 2 * OT_TILE_PX, zo * wm);
+                unsafeAtomicAdd(hv + 3 * OT_TILE_PX, 1.0 * wm);
+            }
+        };
+        TileRec ra[DEPTH], rb[DEPTH];
+        bool oa[DEPTH], ob[DEPTH];
+        load(g, ra, oa);
+        for (int i0 = g; i0 < n_c; i0 += 2 * PER * DEPTH) {
+            load(i0 + PER * DEPTH, rb, ob);
+            add(ra, oa);
+            load(i0 + 2 * PER * DEPTH, ra, oa);
+            add(rb, ob);
+        }
+        __syncthreads();
+        double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
+        for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) slab[i] = tile[i];
+        __syncthreads();  // the slab is out: the tile part holds wstart again in the next round
     }
-    __syncthreads();
-    double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
-    for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) slab[i] = tile[i];
 }
 __global__ __launch_bounds__(1024) void fuse_accum_kernel(FuseOne F, FuseIndex ix, const double* __restrict__ table) {
-    fuse_accum_body(F, ix, table, blockIdx.x, blockIdx.y);
+    fuse_accum_body(F, ix, table, blockIdx.x, gridDim.x);
 }
 // several detectors in one launch (blockIdx.z), their records in device memory
 __global__ __launch_bounds__(1024) void fuse_accum_multi_kernel(const FuseOne* __restrict__ dets, const FuseIndex* __restrict__ ixs, const double* __restrict__ table) {
-    fuse_accum_body(dets[blockIdx.z], ixs[blockIdx.z], table, blockIdx.x, blockIdx.y);
+    fuse_accum_body(dets[blockIdx.z], ixs[blockIdx.z], table, blockIdx.x, gridDim.x);
 }
 
 // grid (16, K): thread = one pixel of tile blockIdx.y, all four planes
@@ -1109,83 +1115,86 @@ __global__ __launch_bounds__(1024) void spec_accum_kernel(FuseOne F, FuseIndex i
     double* obs = lds + OT_TILE_PX * 4;
     unsigned int* ws = (unsigned int*)lds;
     const int K = F.K;
-    const unsigned int b = blockIdx.x;
-    if (b >= ix.wstart[K]) return;  // (the grid is sized for the worst case: most workgroups leave here, before the table)
-    for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
-    __syncthreads();
-    int lo = 0, hi = K;  // ws[lo] <= b < ws[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (ws[mid] <= b) lo = mid; else hi = mid;
-    }
-    const int t = lo;
-    const unsigned int part = b - ws[t];
-    __syncthreads();  // everyone has read ws: the window may be cleared
-    const unsigned int c0 = ix.tstart[t], n_t = ix.tstart[t + 1] - c0;
-    const unsigned int j_begin = part * OT_FUSE_CPW;
-    const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
-    for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
+    const unsigned int total = ix.wstart[K];  // (resident workgroups take the slabs in turn, see fuse_accum_body)
+    if (blockIdx.x >= total) return;
     for (int i = threadIdx.x; i < OT_OBS_N * 6; i += blockDim.x) obs[i] = table[OT_OBS6_OFF + i];
-    __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
-    for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
-        const unsigned int c = ix.list[c0 + j_begin + i];
-        s_chunk[i] = c;
-        s_fill[i] = F.chunk_fill[c];
-    }
-    __syncthreads();
-    int ox, oy;
-    spec_origin(F, t, ox, oy);
-    const SpecRec* __restrict__ recs = (const SpecRec*)F.rec;
-    constexpr int PER = 1024 / OT_FUSE_CH;
-    constexpr int DEPTH = 4;  // two stages of DEPTH records in flight per thread, see fuse_accum_kernel
-    const int g = threadIdx.x / OT_FUSE_CH, slot = threadIdx.x % OT_FUSE_CH;
-    const int n_c = (int)(j_end - j_begin);
-    auto load = [&](int first, SpecRec* rec, bool* ok) {
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {
-            const int i = first + k * PER, ic = i < n_c ? i : 0;
-            ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
-            if (ok[k]) rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];
+    for (unsigned int b = blockIdx.x; b < total; b += gridDim.x) {
+        for (int i = threadIdx.x; i <= K; i += blockDim.x) ws[i] = ix.wstart[i];
+        __syncthreads();
+        int lo = 0, hi = K;  // ws[lo] <= b < ws[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ws[mid] <= b) lo = mid; else hi = mid;
         }
-    };
-    auto add = [&](const SpecRec* rec, const bool* ok) {
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {
-            if (!ok[k]) continue;
-            int32_t px, py;
-            const int pix = hit_pixel(F.a, rec[k].x, rec[k].y, px, py);
-            if (pix < 0) continue;
-            const double wm = (double)rec[k].w * F.a.ws;
-            double xo, yo, zo;
-            observer_xyz_at6(obs, (double)rec[k].wl, xo, yo, zo);
-            const int lx = px - ox, ly = py - oy;
-            if ((unsigned)lx < (unsigned)OT_TILE_W && (unsigned)ly < (unsigned)OT_TILE_W) {
-                double* hv = tile + ((ly << 6) | lx);  // plane-major window, see fuse_accum_kernel
-                unsafeAtomicAdd(hv + 0 * OT_TILE_PX, xo * wm);
-                unsafeAtomicAdd(hv + 1 * OT_TILE_PX, yo * wm);
-                unsafeAtomicAdd(hv + 2 * OT_TILE_PX, zo * wm);
-                unsafeAtomicAdd(hv + 3 * OT_TILE_PX, 1.0 * wm);
-            } else {
-                double* hg = F.hist + (int64_t)pix * 4;
-                unsafeAtomicAdd(hg + 0, xo * wm);
-                unsafeAtomicAdd(hg + 1, yo * wm);
-                unsafeAtomicAdd(hg + 2, zo * wm);
-                unsafeAtomicAdd(hg + 3, 1.0 * wm);
+        const int t = lo;
+        const unsigned int part = b - ws[t];
+        __syncthreads();  // everyone has read ws: the window may be cleared
+        const unsigned int c0 = ix.tstart[t], n_t = ix.tstart[t + 1] - c0;
+        const unsigned int j_begin = part * OT_FUSE_CPW;
+        const unsigned int j_end = (j_begin + OT_FUSE_CPW < n_t) ? j_begin + OT_FUSE_CPW : n_t;
+        for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) tile[i] = 0.0;
+        __shared__ unsigned int s_chunk[OT_FUSE_CPW], s_fill[OT_FUSE_CPW];
+        for (unsigned int i = threadIdx.x; i < j_end - j_begin; i += blockDim.x) {
+            const unsigned int c = ix.list[c0 + j_begin + i];
+            s_chunk[i] = c;
+            s_fill[i] = F.chunk_fill[c];
+        }
+        __syncthreads();
+        int ox, oy;
+        spec_origin(F, t, ox, oy);
+        const SpecRec* __restrict__ recs = (const SpecRec*)F.rec;
+        constexpr int PER = 1024 / OT_FUSE_CH;
+        constexpr int DEPTH = 4;  // two stages of DEPTH records in flight per thread, see fuse_accum_kernel
+        const int g = threadIdx.x / OT_FUSE_CH, slot = threadIdx.x % OT_FUSE_CH;
+        const int n_c = (int)(j_end - j_begin);
+        auto load = [&](int first, SpecRec* rec, bool* ok) {
+    #pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                const int i = first + k * PER, ic = i < n_c ? i : 0;
+                ok[k] = i < n_c && (unsigned int)slot < s_fill[ic];
+                if (ok[k]) rec[k] = recs[(size_t)s_chunk[ic] * OT_FUSE_CH + slot];
             }
+        };
+        auto add = [&](const SpecRec* rec, const bool* ok) {
+    #pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                if (!ok[k]) continue;
+                int32_t px, py;
+                const int pix = hit_pixel(F.a, rec[k].x, rec[k].y, px, py);
+                if (pix < 0) continue;
+                const double wm = (double)rec[k].w * F.a.ws;
+                double xo, yo, zo;
+                observer_xyz_at6(obs, (double)rec[k].wl, xo, yo, zo);
+                const int lx = px - ox, ly = py - oy;
+                if ((unsigned)lx < (unsigned)OT_TILE_W && (unsigned)ly < (unsigned)OT_TILE_W) {
+                    double* hv = tile + ((ly << 6) | lx);  // plane-major window, see fuse_accum_kernel
+                    unsafeAtomicAdd(hv + 0 * OT_TILE_PX, xo * wm);
+                    unsafeAtomicAdd(hv + 1 * OT_TILE_PX, yo * wm);
+                    unsafeAtomicAdd(hv + 2 * OT_TILE_PX, zo * wm);
+                    unsafeAtomicAdd(hv + 3 * OT_TILE_PX, 1.0 * wm);
+                } else {
+                    double* hg = F.hist + (int64_t)pix * 4;
+                    unsafeAtomicAdd(hg + 0, xo * wm);
+                    unsafeAtomicAdd(hg + 1, yo * wm);
+                    unsafeAtomicAdd(hg + 2, zo * wm);
+                    unsafeAtomicAdd(hg + 3, 1.0 * wm);
+                }
+            }
+        };
+        SpecRec ra[DEPTH], rb[DEPTH];
+        bool oa[DEPTH], ob[DEPTH];
+        load(g, ra, oa);
+        for (int i0 = g; i0 < n_c; i0 += 2 * PER * DEPTH) {
+            load(i0 + PER * DEPTH, rb, ob);
+            add(ra, oa);
+            load(i0 + 2 * PER * DEPTH, ra, oa);
+            add(rb, ob);
         }
-    };
-    SpecRec ra[DEPTH], rb[DEPTH];
-    bool oa[DEPTH], ob[DEPTH];
-    load(g, ra, oa);
-    for (int i0 = g; i0 < n_c; i0 += 2 * PER * DEPTH) {
-        load(i0 + PER * DEPTH, rb, ob);
-        add(ra, oa);
-        load(i0 + 2 * PER * DEPTH, ra, oa);
-        add(rb, ob);
+        __syncthreads();
+        double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
+        for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) slab[i] = tile[i];
+        __syncthreads();  // the slab is out: the window part holds wstart again in the next round
     }
-    __syncthreads();
-    double* slab = ix.slabs + (size_t)b * (OT_TILE_PX * 4);
-    for (int i = threadIdx.x; i < OT_TILE_PX * 4; i += blockDim.x) slab[i] = tile[i];
 }
 
 // grid (16, K): thread = one pixel of the window of tile blockIdx.y, all four planes; windows overlap -> atomics
