@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 8
+#define OT_ABI_VERSION 9
 
 /* ---- status codes -------------------------------------------------------------------------- */
 #define OT_OK 0
@@ -373,6 +373,17 @@ int ot_scene_tail_supported(const ot_scene* scene);
 int ot_generate_and_trace_tail(const ot_scene* scene, const ot_sources* src, const ot_source_range* ranges,
                                int32_t n_ranges, uint64_t seed, int64_t n_rays, const ot_rays* tail, uint32_t* fill,
                                int64_t* result2, int64_t* msgs_host, void* stream);
+
+/* The living rays of a stored chunk join the tail of the render-only chunk traced before it (ABI 9): `iterative_render`
+ * keeps the rays of its LAST chunk (raytracer.py:1235-1267), which therefore goes through the ray storage -- its binning need
+ * not be a pass of its own.  For the rays [first, first + count) of `rays` that are alive in their last section
+ * (w[nt - 2] > 0), positions nt - 2 and nt - 1, the wavelength and the weight times weight_scale (formed in f64, rounded to
+ * f32 once; the ratio chunk rays / tail rays makes the chunk's rays carry the power of the tail's) are appended to `tail`
+ * behind what ot_generate_and_trace_tail(n_rays = rays_before) has written there -- same `fill`, untouched in between --,
+ * then the tail is sealed again: result2 as above, for both together.  tail->N >= ot_tail_capacity(rays_before + count + 64).
+ * Synchronous. */
+int ot_tail_append(const ot_rays* rays, int64_t first, int64_t count, double weight_scale, int64_t rays_before,
+                   const ot_rays* tail, uint32_t* fill, int64_t* result2, void* stream);
 
 /* Measurement aid (the reference times `RT.trace` with perf_counter, tests/benchmark.py:81-86): with timing
  * on, every tracing launch of this scene records one HIP event right before and one right after the tracing

@@ -138,6 +138,7 @@ SIGNATURES = {
     "ot_tail_capacity": (i64, [i64]),
     "ot_scene_tail_supported": (C.c_int, [vp]),
     "ot_generate_and_trace_tail": (C.c_int, [vp, vp, C.POINTER(SourceRange), i32, u64, i64, C.POINTER(Rays), vp, vp, vp, vp]),
+    "ot_tail_append": (C.c_int, [C.POINTER(Rays), i64, i64, C.c_double, i64, C.POINTER(Rays), vp, vp, vp]),
     "ot_scene_set_timing": (C.c_int, [vp, i32]),
     "ot_scene_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "ot_surface_find_hit": (C.c_int, [C.POINTER(Surface), i64, vp, vp, vp, vp, vp, vp]),
@@ -176,7 +177,7 @@ SIGNATURES = {
 
 FOCUS_WS = 16  # OT_FOCUS_WS
 HIT_PIECES = 1024  # OT_HIT_PIECES
-ABI_VERSION = 8  # OT_ABI_VERSION
+ABI_VERSION = 9  # OT_ABI_VERSION
 ERR_UNSUPPORTED = -3  # OT_ERR_UNSUPPORTED
 
 _lib = None

@@ -1250,6 +1250,69 @@ extern "C" int ot_generate_and_trace_tail(const ot_scene* scene, const ot_source
     return OT_OK;
 }
 
+// The living rays of a STORED chunk join a tail storage: `iterative_render` leaves the rays of its last chunk in the tracer
+// (raytracer.py:1235-1267), so that chunk goes through the ray storage -- but its binning need not be a pass of its own (for
+// 2^20 rays the fixed costs of the tile chain are most of it: 0.3-0.4 ms, a seventh of a rank's time when 2e8 rays are sharded
+// over eight GPUs): the last sections of its living rays are appended to the tail of the render-only chunk before it, weights
+// scaled to that chunk's rays (x chunk rays / tail rays, in f64, rounded once), and the two are binned together.
+// Wave k of the range continues the round robin over the pieces behind the `waves_before` waves that filled the tail.
+__global__ __launch_bounds__(256) void tail_append_kernel(ot_rays R, int64_t first, int64_t count, TailOut T, int64_t waves_before,
+                                                          double weight_scale) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool have = q < count;
+    const int64_t r = first + (have ? q : 0), N = R.N;
+    const int nt = R.nt, kq = nt - 2;
+    const float w = have ? R.w[r + N * kq] : 0.f;
+    const bool alive = w > 0.f;
+    const unsigned long long m = __ballot(alive);
+    if (!m) return;
+    const unsigned int n_alive = (unsigned int)__popcll(m);
+    const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    const unsigned int piece = (unsigned int)((waves_before + (q >> 6)) & (OT_TAIL_PIECES - 1));
+    unsigned int q0 = 0;
+    if (rank == 0 && alive) q0 = atomicAdd(&T.fill[piece], n_alive);
+    q0 = __shfl(q0, __ffsll((long long)m) - 1);
+    if (alive) {
+        const unsigned int qs = q0 + rank;
+        const int64_t slot = (((int64_t)(qs >> 6) * OT_TAIL_PIECES + piece) << 6) + (qs & 63u);
+        const int64_t C = T.cap;
+        double* px = T.p + slot;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            px[(2 * c) * C] = R.p[r + N * (kq + (int64_t)nt * c)];
+            px[(2 * c + 1) * C] = R.p[r + N * (kq + 1 + (int64_t)nt * c)];
+        }
+        T.w[slot] = (float)((double)w * weight_scale);
+        T.w[C + slot] = 0.f;
+        T.wl[slot] = R.wl[r];
+    }
+}
+
+extern "C" int ot_tail_append(const ot_rays* rays, int64_t first, int64_t count, double weight_scale, int64_t rays_before,
+                              const ot_rays* tail, uint32_t* fill, int64_t* result2, void* stream) {
+    if (!rays || !tail || !fill || !result2) return fail(OT_ERR_INVALID, "ot_tail_append: null argument");
+    if (!rays->p || !rays->w || !rays->wl || rays->nt < 2) return fail(OT_ERR_INVALID, "ot_tail_append: the ray storage needs p, w, wl and two sections");
+    if (first < 0 || count < 0 || first + count > rays->N || rays_before < 0) return fail(OT_ERR_INVALID, "ot_tail_append: range outside the storage");
+    if (tail->nt != 2 || !tail->p || !tail->w || !tail->wl) return fail(OT_ERR_INVALID, "ot_tail_append: the tail storage has two sections and needs p, w and wl");
+    if (!(weight_scale > 0.0) || !std::isfinite(weight_scale)) return fail(OT_ERR_INVALID, "ot_tail_append: weight_scale must be positive");
+    const int64_t waves_before = (rays_before + 63) / 64, waves = (count + 63) / 64;
+    if (tail->N % 65536 || tail->N < 65536 * std::max<int64_t>(1, (waves_before + waves + OT_TAIL_PIECES - 1) / OT_TAIL_PIECES))
+        return fail(OT_ERR_INVALID, "ot_tail_append: tail storage smaller than ot_tail_capacity(rays_before + count + 64)");
+    if (int rc = require_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    TailOut T;
+    T.p = tail->p;
+    T.w = tail->w;
+    T.wl = tail->wl;
+    T.fill = fill;
+    T.cap = tail->N;
+    if (count) hipLaunchKernelGGL(tail_append_kernel, grid_for(count), dim3(256), 0, st, *rays, first, count, T, waves_before, weight_scale);
+    hipLaunchKernelGGL(tail_seal_kernel, dim3(OT_TAIL_PIECES), dim3(256), 0, st, T, (long long*)result2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return OT_OK;
+}
+
 // ---- leaf entry points -------------------------------------------------------------------------------------
 extern "C" int ot_surface_find_hit(const ot_surface* surf, int64_t n, const double* p, const double* s, double* p_hit,
                                    uint8_t* is_hit, uint8_t* ill, void* stream) {

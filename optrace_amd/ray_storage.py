@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from .base import BaseClass
-from ._device import require_device, stream_ptr, alloc_retry
+from ._device import require_device, stream_ptr, alloc_retry, ptr, mailbox
 from ._warn import warning
 from . import misc
 
@@ -95,6 +95,17 @@ class TailStorage:
             r.s = r.n = r.pol = None
             self._rays_c = r
         return self._rays_c
+
+    def append_living(self, rays: "RayStorage", weight_scale: float) -> None:
+        """The last sections of the living rays of a stored chunk join the tail (`ot_tail_append`), weights times
+        `weight_scale`; `N`, `alive` and `traced` then count both.  The buffers must hold both (`ensure` with
+        ot_tail_capacity(tail rays + chunk rays + 64) before the tail was traced)."""
+        lib = _capi.load_library()
+        mb_t, mb = mailbox()
+        _capi.check(lib.ot_tail_append(C.byref(rays._rays_struct()), 0, int(rays.N), float(weight_scale), int(self.traced),
+                                       C.byref(self._rays_struct()), ptr(self._dev["fill"]), C.c_void_p(mb_t.data_ptr()),
+                                       stream_ptr()))
+        self.N, self.alive, self.traced = int(mb[0]), int(mb[1]), self.traced + int(rays.N)
 
     def release(self) -> None:
         self._dev = self._rays_c = None

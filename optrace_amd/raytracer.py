@@ -66,12 +66,15 @@ class Raytracer(Group):
     ITER_RENDER_ONLY: bool = True
     """`iterative_render`: every chunk but the last is traced render-only -- no section is stored, the last section of
     every ray alive behind the last surface goes to a compact `TailStorage` (56 B per LIVING ray instead of 36-48 B per
-    ray and section), which the detector passes read -- wherever that gives the stored path's images: scenes of flat and
-    no orientation="Function" source, every detector position behind the last tracing surface (every feature level of the
+    ray and section), which the detector passes read -- wherever that gives the stored path's images: no
+    orientation="Function" source, every detector position behind the last tracing surface (every feature level of the
     trace kernel has its render-only form).  False: every chunk through the ray storage."""
     ITER_LAST_RAYS: int = 1 << 20
     """... and the last chunk, whose rays stay in `self.rays` afterwards like those of the reference's last iteration
     (ITER_RAYS_STEP = 1 M there, raytracer.py:40, 1235-1267), then has this many rays."""
+    ITER_MERGE_LAST: bool = True
+    """... and is binned together with the render-only chunk before it: the last sections of its living rays join that chunk's
+    tail (`TailStorage.append_living`), one binning pass less per render.  False: a pass of its own."""
     ITER_GROUP: int = 8
     """Detector positions per pass over a chunk's rays (at most 8: `ot_detector_images`)."""
     ITER_STORAGE_BYTES: int = 16_000_000_000
@@ -303,7 +306,7 @@ class Raytracer(Group):
                 and not self.geometry_error and all(a.tobytes() == b for a, b in fast[5]))
 
     def trace(self, N: int, _initial_rays: tuple = None, _hurb_normals: np.ndarray = None, _N_list=None,
-              _chunk: int = 0, _power_scale: float = 1.0, _tail: TailStorage = None) -> None:
+              _chunk: int = 0, _power_scale: float = 1.0, _tail: TailStorage = None, _tail_room: int = 0) -> None:
         """Trace N rays through the current geometry.
 
         Geometry errors are reported as warnings and set `geometry_error` instead of raising, like the
@@ -313,7 +316,8 @@ class Raytracer(Group):
         `_power_scale`: share of the source powers these rays carry (a rank's shard, distributed.py).
         `_tail`: render-only trace (`iterative_render`, every chunk but the last): no section is stored and `self.rays`
         stays as it is; the last section of every ray still alive behind the last surface goes to that `TailStorage`
-        (`ot_generate_and_trace_tail`).  Counters and warnings as for a stored trace.
+        (`ot_generate_and_trace_tail`).  Counters and warnings as for a stored trace.  `_tail_room`: slots for that many
+        further rays (`TailStorage.append_living`).
 
         The reference re-reads the whole object graph on every call (raytracer.py:246-278).  Here everything
         derived from it -- geometry checks, the compiled scene, the source table, the snapshot -- is kept while
@@ -389,7 +393,7 @@ class Raytracer(Group):
             rng_c = rays_obj._source_ranges()
             # one synchronous call: launch, wait, counters in host memory (no device-to-host copy)
             if _tail is not None:
-                _tail.ensure(int(lib.ot_tail_capacity(N)))
+                _tail.ensure(int(lib.ot_tail_capacity(N + _tail_room)))
                 mb_t, mb = mailbox()
                 _capi.check(lib.ot_generate_and_trace_tail(self._scene_handle, tab.handle, rng_c, len(rng_c), seed, N,
                                                            C.byref(_tail._rays_struct()), ptr(_tail._dev["fill"]),
@@ -1094,11 +1098,13 @@ class Raytracer(Group):
             if all(extentc[j] is not None for j in group):
                 make_plan(gi, specs_of(group))
 
-        for i, n_i in enumerate(chunks):  # one chunk of rays per iteration (raytracer.py:1235-1267)
-            src = tail if (tail is not None and i < len(chunks) - 1) else None
-            with global_options.no_warnings():
-                self.trace(N=n_i, _chunk=i, _power_scale=_power_scale, _tail=src)
-                msgs_cum += self._msgs
+        # The LAST chunk goes through the ray storage (its rays stay in the tracer), but not through a binning pass of its
+        # own: it is traced before the render-only chunk in front of it, the last sections of its living rays join that
+        # chunk's tail (weights scaled to that chunk's rays: x n_last / n_i), and the two are binned together -- for 2^20
+        # rays the fixed costs of the tile chain were most of the pass (0.3-0.4 ms per render)
+        merged = tail is not None and self.ITER_MERGE_LAST
+
+        def bin_chunk(i, n_i, src):
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
                 for gi, group in enumerate(groups):
@@ -1108,6 +1114,24 @@ class Raytracer(Group):
                     self._launch_renders(plans[gi], rays=src, weight_scale=n_i / N)
             finally:
                 self._rays_known_current = False
+
+        for i, n_i in enumerate(chunks):  # one chunk of rays per iteration (raytracer.py:1235-1267)
+            last = i == len(chunks) - 1
+            src = tail if (tail is not None and not last) else None
+            if merged and last:
+                break  # (traced and binned with the chunk before it)
+            with global_options.no_warnings():
+                if merged and i == len(chunks) - 2:
+                    n_last = chunks[-1]
+                    self.trace(N=n_last, _chunk=i + 1, _power_scale=_power_scale)
+                    msgs_cum += self._msgs
+                    self.trace(N=n_i, _chunk=i, _power_scale=_power_scale, _tail=src, _tail_room=n_last + 64)
+                    msgs_cum += self._msgs
+                    src.append_living(self.rays, n_last / n_i)
+                else:
+                    self.trace(N=n_i, _chunk=i, _power_scale=_power_scale, _tail=src)
+                    msgs_cum += self._msgs
+            bin_chunk(i, n_i, src)
         if tail is not None:
             tail.release()
 

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version(lib):
     lib.ot_abi_version.restype = C.c_int
-    assert lib.ot_abi_version() == _capi.ABI_VERSION == 8
+    assert lib.ot_abi_version() == _capi.ABI_VERSION == 9
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -103,3 +103,40 @@ def test_automatic_extent_entry_points_check_their_arguments_before_anything_els
     ext = (C.c_double * 4)()
     assert lib.ot_detector_extent_sample(C.byref(rays), 0, 1, C.byref(sd), 0, 128, ext, st) == -1
     assert b"null buffers" in lib.ot_last_error()
+
+
+def test_tail_append_checks_its_arguments_before_anything_else():
+    """`ot_tail_append` (include/optrace_amd.h, ABI 9): null arguments, storages without buffers, ranges outside the storage,
+    a tail that cannot hold both chunks and a weight scale that is not a positive number are refused with OT_ERR_INVALID
+    before a device is looked for."""
+    lib = _capi.load_library()
+    st = C.c_void_p()
+    assert lib.ot_tail_append(None, 0, 1, 1.0, 0, None, None, None, st) == -1
+    assert b"null argument" in lib.ot_last_error()
+    buf = (C.c_double * 8)()
+    fill = (C.c_uint32 * 1024)()
+    res = (C.c_int64 * 2)()
+    addr = C.addressof(buf)
+
+    def storage(N, nt, with_buffers=True):
+        r = _capi.Rays()
+        r.N, r.nt = N, nt
+        if with_buffers:  # (never dereferenced: every call below fails in the checks)
+            r.p = r.w = r.wl = addr
+        return r
+
+    rays, tail = storage(1000, 4), storage(65536, 2)
+    call = lambda rays, first, count, scale, before, tail: lib.ot_tail_append(
+        C.byref(rays), first, count, scale, before, C.byref(tail), fill, res, st)
+    assert call(storage(1000, 4, False), 0, 10, 1.0, 0, tail) == -1 and b"needs p, w, wl" in lib.ot_last_error()
+    assert call(storage(1000, 1), 0, 10, 1.0, 0, tail) == -1
+    assert call(rays, 0, 1001, 1.0, 0, tail) == -1 and b"range outside" in lib.ot_last_error()
+    assert call(rays, -1, 10, 1.0, 0, tail) == -1
+    assert call(rays, 0, 10, 1.0, -5, tail) == -1
+    assert call(rays, 0, 10, 1.0, 0, storage(65536, 3)) == -1 and b"two sections" in lib.ot_last_error()
+    assert call(rays, 0, 10, 1.0, 0, storage(65536, 2, False)) == -1
+    for bad in (0.0, -1.0, float("nan"), float("inf")):
+        assert call(rays, 0, 10, bad, 0, tail) == -1 and b"weight_scale" in lib.ot_last_error()
+    # 1024 pieces of 64 slots hold 1024 waves: one wave more (before + appended) does not fit 65536 slots
+    assert call(storage(70000, 4), 0, 64, 1.0, 65536, tail) == -1 and b"smaller than" in lib.ot_last_error()
+    assert call(rays, 0, 10, 1.0, 0, storage(65537, 2)) == -1

@@ -7,12 +7,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 "$R/tools/bench_c4_sharded.py" --steps 3 > "$OUT/log.txt" 2>&1
 grep "^{" "$OUT/log.txt"
 F=$(ls "$OUT"/*/*_kernel_trace.csv | head -1)
-python3 - "$F" <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the renders are separated by the large trace_tail kernels: take everything from the last render's first kernel on
-tails = [i for i, r in enumerate(rows) if "trace_tail_kernel" in r["Kernel_Name"]]
-print("kernels", len(rows), "tail launches", len(tails))
-PY
-python3 "$R/tools/host_gaps.py" "$F" 60
+python3 "$R/tools/timeline.py" "$F" trace_tail_kernel 14 34
