@@ -1,0 +1,284 @@
+"""Behavioural tests of the reference for the traced path that the rest of this suite had not taken over yet, restated
+(tests/test_tracer_special.py, tests/test_tracer.py of the reference; each test names the one it follows).  They pin
+behaviour the fixtures do not reach: detectors in front of the source, beyond the outline and inside a lens stack, lens
+cylinder edges, blocked systems, ill-conditioned detector hits, sources without rays, ideal-lens imaging pixel for pixel."""
+import numpy as np
+import pytest
+
+import optrace_amd as ot
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sphere_detector_in_front_of_behind_and_inside_the_beam():
+    """tests/test_tracer_special.py:18-59 (test_sphere_detector_range_hits): rays that start behind the detector, end before
+    it, start inside its z-range; the projected extent of a collimated beam on a spherical detector."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -100, 100])
+        RS = ot.RaySource(ot.CircularSurface(r=0.5), pos=[0, 0, 0], divergence="None")
+        RT.add(RS)
+        ap = ot.Aperture(ot.RingSurface(r=2, ri=1), pos=[0, 0, 3])
+        RT.add(ap)
+        det = ot.Detector(ot.SphericalSurface(r=5, R=-6), pos=[0, 0, -10])
+        RT.add(det)
+        half = np.arcsin(RS.surface.r / abs(det.surface.R))  # angular half extent, Equidistant projection
+        want = half * np.array([-1, 1, -1, 1])
+        RT.trace(400_000)
+        for z in [RT.outline[4], RS.pos[2] + 1, ap.pos[2] - 1, ap.pos[2] + 1, RS.pos[2] + 1 + det.surface.R,
+                  RT.outline[5] - RT.N_EPS, RT.outline[5] + 1]:
+            det.move_to([0, 0, z])
+            img = RT.detector_image(projection_method="Equidistant")
+            if RT.outline[5] > z > RS.surface.pos[2]:
+                assert img.power() == pytest.approx(RS.power, abs=1e-7), f"detector at z = {z}"
+                assert np.allclose(img.extent, want, atol=1e-2, rtol=0)
+            else:
+                assert img.power() == pytest.approx(0, abs=1e-7), f"detector at z = {z}"
+
+
+def test_numeric_surface_hits_from_outside_above_and_along_the_edge():
+    """tests/test_tracer_special.py:126-170 (test_numeric_tracing_surface_hit_special_cases): single rays that start above /
+    outside a data surface, fly over it, hit it, hit only the cylinder edge."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -10, 60])
+        for x, sx in zip([0, -4, -8, -8, 0, -8, -8, 2.5], [0, 0, 8, 16, 4.5, 13, 6, 0.65]):
+            RT.add(ot.RaySource(ot.Point(), divergence="None", spectrum=ot.presets.light_spectrum.FDC, pos=[x, 0, 0],
+                                s=[sx, 0, 10]))
+        Y, X = np.mgrid[-3:3:200j, -3:3:200j]
+        Z = -(X ** 2 + Y ** 2) / 5
+        L = ot.Lens(ot.DataSurface2D(r=3, data=Z), ot.DataSurface2D(r=3, data=Z), d=1.5, pos=[0, 0, 10],
+                    n=ot.RefractionIndex("Constant", n=1))
+        RT.add(L)
+        RT.trace(len(RT.ray_sources))  # one ray per source
+    w, p = RT.rays.w_list, RT.rays.p_list
+    assert not w[[1, 3, 4, 6], 2].any(), "rays that miss are absorbed"
+    assert np.all(L.front.mask(p[[0, 2, 5, 7], 1, 0], p[[0, 2, 5, 7], 1, 1])), "the others hit the front"
+    assert w[[0, 2, 5, 7], 1].all()
+
+
+def test_rays_meeting_the_lens_cylinder_are_absorbed():
+    """tests/test_tracer_special.py:251-277 (test_abnormal_rays): front hit but not back, back but not front."""
+    N = 10_000
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 50])
+        RT.add(ot.RaySource(ot.CircularSurface(r=2), spectrum=ot.LightSpectrum("Monochromatic", wl=555), divergence="None",
+                            pos=[0, 0, -3]))
+        wide, tiny = ot.CircularSurface(r=3), ot.CircularSurface(r=1e-6)
+        n = ot.RefractionIndex("Constant", n=1.5)
+        RT.add(ot.Lens(tiny, wide, n=n, pos=[0, 0, 0], d=0.1))
+        RT.trace(N)
+        assert RT._msgs[RT.INFOS.ABSORB_MISSING, 1] / N == pytest.approx(1, abs=5e-4)
+        RT.lenses[0] = ot.Lens(wide, tiny, n=n, pos=[0, 0, 0], d=0.1)
+        RT.trace(N)
+        assert RT._msgs[RT.INFOS.ABSORB_MISSING, 2] / N == pytest.approx(1, abs=5e-4)
+
+
+def test_a_blocked_system_traces_to_the_end():
+    """tests/test_tracer_special.py:279-287 (test_ray_reach): an aperture that takes every ray."""
+    with ot.global_options.no_warnings():
+        RT = scenes.mixed_geometry(ot)
+        RT.apertures[0] = ot.Aperture(ot.CircularSurface(r=5), pos=RT.apertures[0].pos)
+        RT.trace(10_000)
+        assert not RT.geometry_error and RT.rays.N == 10_000
+        assert not RT.rays.w_list[:, -2].any(), "nothing is left behind it"
+
+
+def test_ill_conditioned_detector_hits_are_counted():
+    """tests/test_tracer_special.py:289-316 (test_detector_ill_conditioned): a tilted detector whose z_max has been made
+    wrong has no root inside the search bracket for rays that miss its disc."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -8, 12])
+        RT.add(ot.RaySource(ot.CircularSurface(r=0.05), divergence="None", pos=[0, 0.5, -4]))
+        surf = ot.TiltedSurface(r=0.2, normal=[0, -np.sin(1.0), np.cos(1.0)])
+        surf._lock = False
+        surf.z_max = 0.1
+        RT.add(ot.Detector(surf, pos=[0, 0, 12]))
+        RT.trace(1000)
+        ill_count = RT._hit_detector("Detector Image", 0, None, None, "Equidistant")[5]
+        assert ill_count == RT.rays.N
+    with pytest.warns(ot.OptraceWarning):
+        RT.detector_image()
+    with pytest.warns(ot.OptraceWarning):
+        RT.detector_spectrum()
+
+
+def front_focal_distance(surfaces, wl=555.):
+    """Paraxial distance of the front focal point in front of the first vertex.  surfaces: (R or inf, index behind the surface,
+    distance to the next vertex); the system stands in air."""
+    M = np.eye(2)
+    n_before = 1.0
+    for R, n_after, gap in surfaces:
+        power = 0.0 if np.isinf(R) else (n_after - n_before) / R
+        M = np.array([[1, 0], [-power / n_after, n_before / n_after]]) @ M
+        M = np.array([[1, gap], [0, 1]]) @ M
+        n_before = n_after
+    return -M[1, 1] / M[1, 0]  # a ray (s t, t) at the first vertex leaves with angle t (C s + D) = 0
+
+
+def test_detectors_of_every_kind_around_and_inside_an_objective():
+    """tests/test_tracer_special.py:459-526 (test_hit_dector_many_surfaces_different_detector_surfaces): a strongly tilted
+    detector that cuts through all four surfaces of a doublet (the hit lies in different sections for different rays), then a
+    ring, a disc and a conic detector inside its second lens.  (The glasses of the reference's preset catalogue are stood in for by Abbe
+    models of their n_d / V_d; the object is a synthetic picture.)"""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -10, 300])
+        RS = ot.RaySource(ot.RGBImage(scenes.synthetic_rgb_image(), [0.2, 0.2]), divergence="Lambertian", pos=[0, 0, 0],
+                          s=[0, 0, 1], div_angle=27)
+        RT.add(RS)
+        flint, crown = ot.RefractionIndex("Abbe", n=1.72825, V=28.41), ot.RefractionIndex("Abbe", n=1.713, V=53.83)
+        R1, R2 = 7.74, -7.29
+        s = front_focal_distance([(np.inf, float(flint(555.)), 0.5), (-R2, float(flint(555.)), 0.0001),
+                                  (-R2, float(crown(555.)), 5.3), (-R1, 1.0, 0.0)])
+        z1 = 0.6 + s + 0.5  # the front focal point 0.6 mm behind the object
+        L01 = ot.Lens(ot.CircularSurface(r=5.5), ot.SphericalSurface(r=5.5, R=-R2), d1=0.5, d2=0, pos=[0, 0, z1], n=flint, n2=flint)
+        L02 = ot.Lens(ot.SphericalSurface(r=5.5, R=-R2), ot.ConicSurface(r=5.5, R=-R1, k=-0.55), d1=0, d2=5.3,
+                      pos=[0, 0, z1 + 0.0001], n=crown)
+        RT.add(L01)
+        RT.add(L02)
+        z_mid = 0.5 * (L01.extent[4] + L02.extent[5])
+        det = ot.Detector(ot.TiltedSurface(r=3.5, normal=[2, 0, 1]), pos=[0, 0, z_mid])
+        RT.add(det)
+        assert det.extent[5] > L02.extent[5] and det.extent[4] < L01.extent[4], "the detector reaches beyond the objective"
+        RT.trace(200_000)
+        assert not RT.geometry_error
+        assert RT.detector_image().power() > 0.55
+        z_after = 12.0  # (as in the reference: INSIDE the second lens, between its faces)
+        assert L02.front.pos[2] < z_after < L02.back.pos[2]
+        RT.add(ot.Detector(ot.RingSurface(r=3.5, ri=0.3), pos=[0, 0, z_after]))
+        img = RT.detector_image(detector_index=1)
+        assert img.power() > 0.4
+        ny, nx = img._data.shape[:2]
+        assert img._data[ny // 2, nx // 2, 3] == 0, "nothing is seen through the hole of the ring"
+        RT.add(ot.Detector(ot.CircularSurface(r=3.5), pos=[0, 0, z_after]))
+        assert RT.detector_image(detector_index=2).power() > 0.4
+        RT.add(ot.Detector(ot.ConicSurface(r=3.5, R=-10, k=2), pos=[0, 0, z_after]))
+        assert RT.detector_image(detector_index=3).power() > 0.4
+
+
+def test_a_source_too_weak_for_a_single_ray():
+    """tests/test_tracer_special.py:528-535 (test_ray_storage_misc): the split leaves a source without rays (a warning)."""
+    RT = scenes.mixed_geometry(ot)
+    RT.ray_sources[0].power = 0.000001
+    RT.ray_sources[1].power = 1
+    with pytest.warns(ot.OptraceWarning):
+        RT.trace(10_000)
+    assert RT.rays.N == 10_000 and RT.rays.N_list[0] == 0 and RT.rays.N_list[1] == 10_000
+
+
+def test_every_action_and_every_message():
+    """tests/test_tracer_special.py:537-568 (test_raytracer_output_threading_nopol): every action once with its messages on,
+    every tracing message on its own, the same system without polarisation."""
+    RT = scenes.mixed_geometry(ot)
+    with ot.global_options.no_warnings():
+        RT.trace(10_000)
+        RT.focus_search(RT.focus_search_methods[0], 12)
+        RT.source_image()
+        RT.detector_image()
+        RT.source_spectrum()
+        RT.detector_spectrum()
+        imgs = RT.iterative_render(100_000)
+    assert len(imgs) == 1 and imgs[0].power() > 0
+    for i in range(len(RT.INFOS)):
+        RT._msgs = np.zeros((len(RT.INFOS), 2), dtype=int)
+        RT._msgs[i, 0] = 1
+        try:
+            with ot.global_options.no_warnings():
+                RT._show_messages(1000)
+        except Exception as err:  # (some of them raise)
+            assert str(err)
+    with ot.global_options.no_warnings():
+        RT.no_pol = True
+        RT.trace(10_000)
+    assert np.isnan(RT.rays.pol_list).all() and RT.rays.w_list[:, 0].all()
+
+
+def test_colliding_elements_are_not_traced():
+    """tests/test_tracer_special.py:701-720 (test_object_collision)."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, -10, 60])
+        RT.add(ot.RaySource(ot.Point(), divergence="Isotropic", pos=[0, 0, 0], s=[0, 0, 1], div_angle=75))
+        geom = ot.presets.geometry.arizona_eye()
+        geom.elements[2].move_to([0, 0, 0.15])
+        RT.add(geom)
+        RT.trace(1000)
+    assert RT.geometry_error and RT.rays.N == 0
+
+
+def test_focus_search_at_the_ends_of_its_range():
+    """tests/test_tracer.py:420-444 (test_focus_additional): a focus beyond the outline ends at the outline; a lens, a filter
+    or an aperture behind the start position ends the search region."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 40])
+        disc = ot.CircularSurface(r=0.5)
+        RT.add(ot.RaySource(disc, pos=[0, 0, -3], orientation="Converging", conv_pos=[0, 0, 60]))
+        RT.trace(10_000)
+        res, _ = RT.focus_search("RMS Spot Size", z_start=10)
+        assert res.x == pytest.approx(RT.extent[5], abs=0.05)
+        for el in [ot.Lens(disc, disc, d=5, pos=[0, 0, 20], n=ot.RefractionIndex("Abbe", n=1.72825, V=28.41)),
+                   ot.Filter(disc, pos=[0, 0, 20], spectrum=ot.TransmissionSpectrum("Constant", val=0.1)),
+                   ot.Aperture(disc, pos=[0, 0, 20])]:
+            RT.add(el)
+            RT.trace(100_000)
+            res, _ = RT.focus_search("RMS Spot Size", z_start=10)
+            assert res.x == pytest.approx(el.extent[4], abs=1e-7)
+            RT.remove(el)
+
+
+def test_a_sphere_given_as_data_focuses_like_a_sphere():
+    """tests/test_tracer.py:888-917 (test_numeric_tracing): a biconvex lens whose faces are DataSurface2D samples of a sphere;
+    the focus against the lensmaker's equation for a thick lens."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-3, 3, -3, 3, -10, 50])
+        x = np.linspace(-2, 2, 100)
+        X, Y = np.meshgrid(x, x)
+        R = 12
+        Z = R * (1 - np.sqrt(1 - (X ** 2 + Y ** 2) / R ** 2))
+        n = ot.RefractionIndex("Constant", n=1.5)
+        L = ot.Lens(ot.DataSurface2D(data=Z, r=2), ot.DataSurface2D(data=-Z, r=2), n, pos=[0, 0, 0], d=0.4)
+        RT.add(L)
+        RT.add(ot.RaySource(ot.CircularSurface(r=0.5), spectrum=ot.LightSpectrum("Monochromatic", wl=555), divergence="None",
+                            pos=[0, 0, -3]))
+        RT.trace(100_000)
+        res, _ = RT.focus_search(RT.focus_search_methods[0], 5)
+    nl = float(n(555.))
+    f = 1 / ((nl - 1) * (1 / R - 1 / -R + (nl - 1) * L.d / (nl * R * -R)))
+    assert res.x == pytest.approx(f, abs=0.2)
+
+
+def test_an_ideal_lens_maps_pixels_onto_pixels():
+    """tests/test_tracer.py:1087-1135 (test_ideal_lens_imaging): all rays of a source pixel meet in one image pixel, so the
+    image behind an ideal lens IS the (flipped) picture of the source, to rounding."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-5, 5, -5, 5, 0, 40])
+        pic = ot.RGBImage(scenes.synthetic_rgb_image(), [4, 4])
+        RT.add(ot.RaySource(pic, divergence="Lambertian", div_angle=8, s=[0, 0, 1], pos=[0, 0, 0]))
+        g, D = 12.0, 120.0
+        RT.add(ot.IdealLens(r=5, D=D, pos=[0, 0, g]))
+        b = 1 / (D / 1000 - 1 / g)  # thin-lens equation
+        zi, beta = g + b, b / g
+        RT.add(ot.Detector(ot.RectangularSurface(dim=[10, 10]), pos=[0, 0, zi]))
+        RT.trace(1_000_000)
+        simg = RT.source_image()
+        dimg = RT.detector_image(extent=np.array(pic.extent[:4]) * beta)
+    join = lambda a: a.reshape(315, 3, 315, 3).mean(axis=(1, 3))  # 945 -> 315 pixels: things average out
+    sw, dw = join(simg._data[:, :, 3]), join(dimg._data[:, :, 3])
+    assert sw.max() > 0
+    assert np.abs(sw - dw[::-1, ::-1]).max() / sw.max() < 1e-8
+
+
+def test_a_negative_and_a_positive_ideal_lens():
+    """tests/test_tracer.py:1137-1161 (test_ideal_lens_negative): the rays of a collimated beam meet on the axis where the
+    two thin lenses put the focus."""
+    with ot.global_options.no_warnings():
+        RT = ot.Raytracer(outline=[-10, 10, -10, 10, 0, 100])
+        RT.add(ot.RaySource(ot.CircularSurface(r=3)))
+        RT.add(ot.IdealLens(r=5, D=-20, pos=[0, 0, 12]))
+        RT.add(ot.IdealLens(r=5, D=50, pos=[0, 0, 15]))
+        f1, f2, gap = -50.0, 20.0, 3.0
+        g2 = gap - f1                      # the virtual focus of the first lens seen from the second
+        zf = 15 + 1 / (1 / f2 - 1 / g2)
+        power = 1000 * (1 / f1 + 1 / f2 - gap / (f1 * f2))
+        assert power == pytest.approx(33)
+        RT.add(ot.Aperture(ot.CircularSurface(r=4), pos=[0, 0, zf]))
+        RT.trace(10_000)
+    assert np.allclose(RT.rays.p_list[:, -1, :2], 0, atol=1e-8)
