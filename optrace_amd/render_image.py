@@ -44,7 +44,10 @@ class RenderImage(BaseClass):
         """(Ny, Nx, 4) float64 XYZW image as the reference exposes it (render_image.py:80); the histogram lives in
         HBM (`_dev`) and is copied to the host when this attribute is first read."""
         if self._host is None and self._dev is not None:
-            self._host = self._dev.cpu().numpy()
+            # from here on the host copy IS the image: the reference's users (and its tests) edit `_data` in place, which no
+            # device copy could notice -- whatever needs the image on the device next uploads this array again
+            self.__dict__["_host"] = self._dev.cpu().numpy()
+            self.__dict__["_dev"] = None
         return self._host
 
     def has_image(self) -> bool:
@@ -203,7 +206,8 @@ class RenderImage(BaseClass):
 
     def _sync_host(self) -> None:
         """The device histogram changed: the host copy is made again when `_data` is next read."""
-        self._host = None
+        if self._dev is not None:
+            self._host = None
 
     # ---- on-disk format (render_image.py:298-328): same keys, files are interchangeable with the reference ----
     def save(self, path: str) -> None:
