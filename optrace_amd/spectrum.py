@@ -224,6 +224,18 @@ class LightSpectrum(Spectrum):
             return np.where(inside, heights[np.clip(bin_, 0, len(heights) - 1)], 0.)
         return super()._eval_host(wl)
 
+    def random_wavelengths(self, N: int) -> np.ndarray:
+        """N wavelengths distributed like this spectrum (light_spectrum.py:81-138) -- drawn where the tracer draws them: by
+        the generation kernel (stratified inverse-CDF sampling on the device, `ot_generate.hpp`), for a point source that
+        carries this spectrum.  -> float64 host array (values of float32 resolution, like `RayStorage.wl_list`)."""
+        from .geometry import Point
+        from .geometry.ray_source import RaySource
+        from . import ops
+        N = int(N)
+        if N < 1:
+            return np.zeros(0, dtype=np.float64)
+        return ops.create_rays(RaySource(Point(), spectrum=self), N, no_pol=True)[4]
+
     # ---- figures of a spectrum (light_spectrum.py:232-400): host arithmetic on the spectrum's own description ----
     _DENSE = 100000   # samples over the visible range where a figure has no closed form
 
