@@ -1099,39 +1099,46 @@ class Raytracer(Group):
                 make_plan(gi, specs_of(group))
 
         # The LAST chunk goes through the ray storage (its rays stay in the tracer), but not through a binning pass of its
-        # own: it is traced before the render-only chunk in front of it, the last sections of its living rays join that
-        # chunk's tail (weights scaled to that chunk's rays: x n_last / n_i), and the two are binned together -- for 2^20
-        # rays the fixed costs of the tile chain were most of the pass (0.3-0.4 ms per render)
+        # own: it is traced FIRST, the last sections of its living rays later join the tail of the final render-only chunk
+        # (weights scaled to that chunk's rays: x n_last / n_i), and the two are binned together -- for 2^20 rays the fixed
+        # costs of the tile chain were most of the pass (0.3-0.4 ms per render).  Automatic extents are those of this
+        # stored chunk's hits (the reference takes its first iteration's, 1 M rays as well, raytracer.py:1262): its rays
+        # have the order of generation, so a seeded render finds the same extents every time -- the slots of a tail
+        # storage are filled in the order the waves happen to finish
         merged = tail is not None and self.ITER_MERGE_LAST
 
-        def bin_chunk(i, n_i, src):
+        def bin_chunk(n_i, src):
             self._rays_known_current = True  # traced a moment ago: skip the snapshot comparison per image
             try:
                 for gi, group in enumerate(groups):
                     if plans[gi] is None:  # automatic extents: those of this, the first chunk (an extent-only pass or a sample)
                         make_plan(gi, self._auto_extents(specs_of(group), agree=_agree_extents,
                                                          sample_rays=self.ITER_EXTENT_RAYS, rays=src))
-                    self._launch_renders(plans[gi], rays=src, weight_scale=n_i / N)
+                    if n_i:
+                        self._launch_renders(plans[gi], rays=src, weight_scale=n_i / N)
             finally:
                 self._rays_known_current = False
 
+        if merged:
+            n_last = chunks[-1]
+            with global_options.no_warnings():
+                self.trace(N=n_last, _chunk=len(chunks) - 1, _power_scale=_power_scale)
+                msgs_cum += self._msgs
+            bin_chunk(0, None)  # (plans with automatic extents only; nothing is binned yet)
         for i, n_i in enumerate(chunks):  # one chunk of rays per iteration (raytracer.py:1235-1267)
             last = i == len(chunks) - 1
-            src = tail if (tail is not None and not last) else None
             if merged and last:
-                break  # (traced and binned with the chunk before it)
+                break  # (traced at the start, binned with the chunk before it)
+            src = tail if (tail is not None and not last) else None
             with global_options.no_warnings():
                 if merged and i == len(chunks) - 2:
-                    n_last = chunks[-1]
-                    self.trace(N=n_last, _chunk=i + 1, _power_scale=_power_scale)
-                    msgs_cum += self._msgs
                     self.trace(N=n_i, _chunk=i, _power_scale=_power_scale, _tail=src, _tail_room=n_last + 64)
                     msgs_cum += self._msgs
                     src.append_living(self.rays, n_last / n_i)
                 else:
                     self.trace(N=n_i, _chunk=i, _power_scale=_power_scale, _tail=src)
                     msgs_cum += self._msgs
-            bin_chunk(i, n_i, src)
+            bin_chunk(n_i, src)
         if tail is not None:
             tail.release()
 

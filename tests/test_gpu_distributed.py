@@ -166,7 +166,7 @@ dist.destroy_process_group()
 
 def _single_process_iter(world, extent):
     """The shards rendered one after the other in this process (same seeds, same chunks), images added.  The common
-    automatic extents come from the two-step hit lists of every shard's first chunk."""
+    automatic extents come from the two-step hit lists of every shard's last chunk (the stored one, traced first)."""
     import optrace_amd as ot
     from optrace_amd import distributed as D
     import scenes
@@ -182,7 +182,9 @@ def _single_process_iter(world, extent):
             hi = -lo
             for r, (a, b) in enumerate(shards):
                 RT.seed = BASE_SEED + r
-                RT.trace(30_000, _chunk=0, _power_scale=(b - a) / N_RAYS)
+                # (the extents are those of the shard's stored LAST chunk, which a render with render-only chunks traces first)
+                plan = RT._chunk_plan(b - a, len(RT.tracing_surfaces) + 2, True)
+                RT.trace(plan[-1], _chunk=len(plan) - 1, _power_scale=(b - a) / N_RAYS)
                 for k, p in enumerate(pos):
                     e = RT._hit_detectors("Detector Image", [dict(detector_index=0, extent=None, pos=p,
                                                                   projection_method="Equidistant")])[0][3]

@@ -282,3 +282,22 @@ def test_a_negative_and_a_positive_ideal_lens():
         RT.add(ot.Aperture(ot.CircularSurface(r=4), pos=[0, 0, zf]))
         RT.trace(10_000)
     assert np.allclose(RT.rays.p_list[:, -1, :2], 0, atol=1e-8)
+
+
+def test_binning_keeps_hits_on_the_edges_and_drops_those_outside():
+    """tests/test_misc.py:139-169 (test_hist2_bin_coords), through `RenderImage.render`: hits exactly on the extent's edges
+    and corners lie inside the image; with a smaller extent exactly the hits outside lose their power."""
+    ext = np.array([-1.5, 1.2, 3, 5])
+    X, Y = np.meshgrid(np.linspace(ext[0], ext[1], 100), np.linspace(ext[2], ext[3], 100))
+    p = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1)
+    assert p[0, 0] == ext[0] and p[-1, 0] == ext[1] and p[0, 1] == ext[2] and p[-1, 1] == ext[3]
+    w = np.ones(len(p), dtype=np.float32)
+    wl = np.full(len(p), 550., dtype=np.float32)
+    img = ot.RenderImage(ext)
+    img.render(p, w, wl)
+    assert img.power() == pytest.approx(w.sum(), rel=1e-12)
+    ext2 = 0.93 * ext
+    img = ot.RenderImage(ext2)
+    img.render(p, w, wl)
+    inside = (p[:, 0] >= ext2[0]) & (p[:, 0] <= ext2[1]) & (p[:, 1] >= ext2[2]) & (p[:, 1] <= ext2[3])
+    assert img.power() == pytest.approx(w[inside].sum(), rel=1e-12)

@@ -186,11 +186,15 @@ def test_iterative_render_render_only_equals_stored_path(name, merge):
                 return orig(N, **kw)
 
             RT.trace = spy
+            if merge and not mode:
+                # (the merged form takes automatic extents from its stored LAST chunk, which it traces first; every other form
+                # from the first chunk: the stored form gets the merged form's extents to bin into)
+                exts = [e if e is not None else list(out[True][0][k]._extent0) for k, e in enumerate(exts)]
             with settings(ITER_RAYS_STEP=n, ITER_RENDER_ONLY=mode, ITER_EXTENT_RAYS=1 << 60, ITER_MERGE_LAST=merge):
                 imgs = RT.iterative_render(3 * n + 77, detector_index=di, pos=pos, extent=exts)
             del RT.trace
             if mode and merge:
-                assert traced == [(n, True), (n + 77, False), (n, True)], "the last chunk goes through the storage, first"
+                assert traced == [(n + 77, False), (n, True), (n, True)], "the last chunk goes through the storage, first"
             else:
                 assert traced == [(n, mode), (n, mode), (n + 77, False)], "the last chunk always goes through the storage"
             assert RT.rays.N == n + 77, "... and its rays stay in the tracer"
@@ -220,8 +224,8 @@ def test_chunk_plan_and_speed_path_of_a_long_render():
             imgs = RT.iterative_render(N, pos=scenes.C4_POSITIONS[:2], extent=[[-8., 8., -8., 8.]] * 2)
         del RT.trace
         last = 1 << 19
-        # (the stored last chunk is traced before the render-only chunk it is binned with, ITER_MERGE_LAST)
-        assert traced[-2] == (last, False) and all(t for k, (_, t) in enumerate(traced) if k != len(traced) - 2)
+        # (the stored last chunk is traced first and binned with the final render-only chunk, ITER_MERGE_LAST)
+        assert traced[0] == (last, False) and all(t for _, t in traced[1:])
         assert sum(n for n, _ in traced) == N and all(n <= 1 << 20 for n, t in traced if t)
         assert len(traced) == 4
         with settings(ITER_RENDER_ONLY=False):
@@ -325,8 +329,10 @@ def test_render_only_with_a_spherical_detector(proj):
             RT = scenes.c4_image_render(ot, seed=8)
             RT.add(ot.Detector(ot.SphericalSurface(r=7.5, R=-30), pos=[0, 0, 34]))
             pos = [[0, 0, 33.], [0, 0, 35.5], [0, 0, 39.2]]  # the last one: the outline (z = 40) cuts through the sphere's sag
+            exts = [[-6., 6., -6., 6.], None, None] if proj == "Orthographic" else [None] * 3
+            if not mode:  # (automatic extents: those the render-only form took from its stored last chunk)
+                exts = [e if e is not None else list(out[True][k]._extent0) for k, e in enumerate(exts)]
             with settings(ITER_RAYS_STEP=500_000, ITER_RENDER_ONLY=mode, ITER_EXTENT_RAYS=1 << 60):
-                out[mode] = RT.iterative_render(1_500_000, detector_index=1, pos=pos, projection_method=proj,
-                                                extent=[[-6., 6., -6., 6.], None, None] if proj == "Orthographic" else None)
+                out[mode] = RT.iterative_render(1_500_000, detector_index=1, pos=pos, projection_method=proj, extent=exts)
     for x, y in zip(out[True], out[False]):
-        same_image(x, y)
+        same_image(x, y, tol=1e-7)
