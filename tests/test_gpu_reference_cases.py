@@ -301,3 +301,21 @@ def test_binning_keeps_hits_on_the_edges_and_drops_those_outside():
     img.render(p, w, wl)
     inside = (p[:, 0] >= ext2[0]) & (p[:, 0] <= ext2[1]) & (p[:, 1] >= ext2[2]) & (p[:, 1] <= ext2[3])
     assert img.power() == pytest.approx(w[inside].sum(), rel=1e-12)
+
+
+@pytest.mark.parametrize("centre", [(0, 0, 0), (5, -3, 2), (-1, 2, -10)])
+@pytest.mark.parametrize("R", [0.01, 1, 100])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_sphere_projections_keep_the_quadrant(centre, R, sign):
+    """tests/test_surface.py:409-440 (test_surface_sphere_projection_quadrants): whatever the position, the curvature and its
+    sign, a point keeps its quadrant relative to the sphere's centre under every projection, and the centre stays the centre."""
+    surf = ot.SphericalSurface(r=0.999 * R, R=R * sign)
+    surf.move_to(list(centre))
+    rel = 0.9 * R * np.array([[0, 0, 0], [+1, +1, 0], [+1, -1, 0], [-1, +1, 0], [-1, -1, 0]], dtype=float)
+    p = np.tile(surf.pos, (5, 1)) + rel
+    p[:, 2] = surf.values(p[:, 0], p[:, 1])
+    for method in ot.SphericalSurface.sphere_projection_methods:
+        want = rel if method != "Orthographic" else rel + np.array(centre, dtype=float)  # (absolute coordinates there)
+        got = surf.sphere_projection(p, method)
+        assert np.all(np.sign(got[1:, :2]) == np.sign(want[1:, :2])), method
+        assert np.allclose(got[0, :2], want[0, :2], atol=1e-9, rtol=0), method
