@@ -119,22 +119,22 @@ def _as_one_block(hists: list):
 
 
 def lit_window(block: torch.Tensor) -> torch.Tensor:
-    """[y0, -y1, x0, -x1] (int64, on the block's device) of the pixel window [y0, y1) x [x0, x1) outside of which every
-    histogram of the (K, Ny, Nx, 4) block is zero; an all-dark block gives [Ny, 0, Nx, 0].  (The negated upper ends let
-    ONE MIN all-reduce form the union of the ranks' windows.)"""
+    """Per histogram of the (K, Ny, Nx, 4) block: [y0, -y1, x0, -x1] (int64 (K, 4), on the block's device) of the pixel window
+    [y0, y1) x [x0, x1) outside of which the histogram is zero; an all-dark one gives [Ny, 0, Nx, 0].  (The negated upper ends
+    let ONE MIN all-reduce form the union of the ranks' windows.)"""
     K, Ny, Nx, _ = block.shape
     lit = (block != 0).any(dim=3)
-    rows, cols = lit.any(dim=2).any(dim=0), lit.any(dim=1).any(dim=0)
-    iy = torch.arange(Ny, device=block.device)
-    ix = torch.arange(Nx, device=block.device)
-    return torch.stack([torch.where(rows, iy, Ny).min(), -(torch.where(rows, iy, -1).max() + 1),
-                        torch.where(cols, ix, Nx).min(), -(torch.where(cols, ix, -1).max() + 1)])
+    rows, cols = lit.any(dim=2), lit.any(dim=1)  # (K, Ny), (K, Nx)
+    iy = torch.arange(Ny, device=block.device).expand(K, Ny)
+    ix = torch.arange(Nx, device=block.device).expand(K, Nx)
+    return torch.stack([torch.where(rows, iy, Ny).amin(dim=1), -(torch.where(rows, iy, -1).amax(dim=1) + 1),
+                        torch.where(cols, ix, Nx).amin(dim=1), -(torch.where(cols, ix, -1).amax(dim=1) + 1)], dim=1)
 
 
 #: what the last `allreduce_images` of this process sent (bench.py reports it)
 last_exchange: dict = dict(bytes=0, window=None)
 
-#: the lit window is exchanged instead of the whole histograms when it holds at most this share of their pixels
+#: the lit windows are exchanged instead of the whole histograms when they hold at most this share of their pixels
 WINDOW_EXCHANGE_BELOW = 0.7
 
 
@@ -145,11 +145,12 @@ def _sent(n_bytes: int, window) -> dict:
 
 def allreduce_images(hists: list) -> dict:
     """Sum K detector histograms ((Ny, Nx, 4) float64 device tensors) over all ranks in place -- the one data exchange of
-    a sharded render.  Equally shaped histograms go as ONE message; and only the window of pixels that any rank has lit
-    travels (four integers are agreed first): an image that fills a fifth of its extent (BASELINE config 4: 6 x 28.6 MB of
-    histograms, a picture of 4 x 3 mm on a 16 x 16 mm detector) costs a fifth of the ring's time, a point-spread image
-    next to nothing.  Outside the window every rank holds zeros, so the result is the sum of the whole histograms.
-    -> {"bytes": what travelled, "window": [y0, y1, x0, x1] or None}."""
+    a sharded render.  Equally shaped histograms go as ONE message; and of every histogram only the WINDOW of pixels that
+    any rank has lit travels (four integers per image are agreed first): BASELINE config 4 renders a 4 x 3 mm picture onto
+    a 16 x 16 mm detector at six positions behind the focus -- the windows around its pictures are 21 to 80 % of their
+    histograms, half of the 6 x 28.6 MB together --, a point-spread image sends next to nothing.  Outside its window every rank holds zeros, so
+    the result is the sum of the whole histograms.
+    -> {"bytes": what travelled, "window": per image [y0, y1, x0, x1], or None where the histograms travelled whole}."""
     if any(h.dtype != torch.float64 or h.dim() != 3 or h.shape[2] != 4 for h in hists):
         raise TypeError("detector histograms are (Ny, Nx, 4) float64")
     full = int(sum(h.numel() * 8 for h in hists))
@@ -167,18 +168,24 @@ def allreduce_images(hists: list) -> dict:
     if not _device_collectives():
         win = win.cpu()
     dist.all_reduce(win, op=dist.ReduceOp.MIN)
-    y0, y1, x0, x1 = (int(v) for v in (win * win.new_tensor([1, -1, 1, -1])).tolist())
     K, Ny, Nx, _ = block.shape
-    if y1 <= y0 or x1 <= x0:  # no rank has a hit anywhere
-        return _sent(0, [0, 0, 0, 0])
-    if (y1 - y0) * (x1 - x0) > WINDOW_EXCHANGE_BELOW * Ny * Nx:
+    wins = [[int(w[0]), -int(w[1]), int(w[2]), -int(w[3])] for w in win.tolist()]  # [y0, y1, x0, x1]
+    wins = [[0, 0, 0, 0] if (y1 <= y0 or x1 <= x0) else [y0, y1, x0, x1] for y0, y1, x0, x1 in wins]  # (no hit anywhere)
+    pixels = sum((y1 - y0) * (x1 - x0) for y0, y1, x0, x1 in wins)
+    if pixels == 0:
+        return _sent(0, wins)
+    if pixels > WINDOW_EXCHANGE_BELOW * K * Ny * Nx:
         allreduce_sum_(block)
         window, sent = None, full
     else:
-        part = block[:, y0:y1, x0:x1, :].contiguous()
+        part = torch.cat([block[k, y0:y1, x0:x1, :].reshape(-1) for k, (y0, y1, x0, x1) in enumerate(wins)])
         allreduce_sum_(part)
-        block[:, y0:y1, x0:x1, :] = part
-        window, sent = [y0, y1, x0, x1], int(part.numel() * 8)
+        off = 0
+        for k, (y0, y1, x0, x1) in enumerate(wins):
+            n = (y1 - y0) * (x1 - x0) * 4
+            block[k, y0:y1, x0:x1, :] = part[off:off + n].view(y1 - y0, x1 - x0, 4)
+            off += n
+        window, sent = wins, int(part.numel() * 8)
     if stacked:
         for k, h in enumerate(hists):
             h.copy_(block[k])

@@ -148,12 +148,13 @@ def test_lit_window_and_block_view():
     assert block is not None and block.shape == (3, 6, 7, 4) and block.data_ptr() == pool.data_ptr()
     assert D._as_one_block([hists[0], hists[2]]) is None                    # a gap
     assert D._as_one_block([hists[0], torch.zeros(6, 7, 4, dtype=torch.float64)]) is None  # another allocation
-    assert D.lit_window(block).tolist() == [6, 0, 7, 0]                     # all dark: an empty window
+    assert D.lit_window(block).tolist() == [[6, 0, 7, 0]] * 3                # all dark: empty windows
     hists[0][2, 3, 3] = 1.0
     hists[2][4, 1, 0] = -2.0                                                # (any channel counts)
-    assert D.lit_window(block).tolist() == [2, -5, 1, -4]
+    assert D.lit_window(block).tolist() == [[2, -3, 3, -4], [6, 0, 7, 0], [4, -5, 1, -2]]
     block[1, 0, 6, 1] = 5.0
-    assert D.lit_window(block).tolist() == [0, -5, 1, -7]
+    hists[0][5, 0, 2] = 1.0
+    assert D.lit_window(block).tolist() == [[2, -6, 0, -4], [0, -1, 6, -7], [4, -5, 1, -2]]
     # without a process group: nothing to exchange
     assert D.allreduce_images(hists) == dict(bytes=0, window=None)
     with pytest.raises(TypeError):
@@ -177,8 +178,11 @@ def _worker_img(rank, world, port, out):
             h[y0:y1, x0:x1] = torch.from_numpy(rng.random((y1 - y0, x1 - x0, 4)))
         return hs
 
-    # 1) a picture in a part of the extent, the ranks' windows differ: the union travels
+    # 1) pictures in a part of the extent, the ranks' windows differ: per image the union travels
     hs = images(3, 40, 50, 10 + rank, 20 + rank, 5, 15 + 2 * rank)
+    hs[1][:] = 0
+    hs[1][30:33, 40 - rank:45] = 1.5 + rank                                # the second image: another place
+    hs[2][:] = 0                                                            # the third: dark on both ranks
     mine = [h.clone() for h in hs]
     info = D.allreduce_images(hs)
     res["win"], res["win_bytes"] = np.array(info["window"]), info["bytes"]
@@ -214,11 +218,12 @@ def test_histogram_exchange_sends_the_lit_window_only(tmp_path):
     out = str(tmp_path / "img")
     mp.spawn(_worker_img, args=(2, _free_port(), out), nprocs=2, join=True)
     r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
-    np.testing.assert_array_equal(r0["win"], [10, 21, 5, 17])               # the union of rows 10-19 / 11-20, columns 5-14 / 5-16
-    assert int(r0["win_bytes"]) == 3 * 11 * 12 * 32 < 3 * 40 * 50 * 32
+    # image 0: the union of rows 10-19 / 11-20, columns 5-14 / 5-16; image 1: rows 30-32, columns 39-44; image 2: nothing
+    np.testing.assert_array_equal(r0["win"], [[10, 21, 5, 17], [30, 33, 39, 45], [0, 0, 0, 0]])
+    assert int(r0["win_bytes"]) == (11 * 12 + 3 * 6) * 32 < 3 * 40 * 50 * 32
     assert int(r0["b_bytes"]) == 2 * 6 * 4 * 32
     assert bool(r0["c_window_is_none"]) and int(r0["c_bytes"]) == 2 * 16 * 16 * 32
-    assert int(r0["d_bytes"]) == 0 and not r0["d_window"].any()
+    assert int(r0["d_bytes"]) == 0 and not r0["d_window"].any() and r0["d_window"].shape == (2, 4)
     assert int(r0["e_bytes"]) == (8 * 9 + 9 * 8) * 32
     for key in ("a", "b", "c"):
         want = r0[key + "_mine"] + r1[key + "_mine"]
