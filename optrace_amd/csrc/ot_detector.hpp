@@ -76,6 +76,50 @@ OT_DEV double wave_max(double v) {
     return v;
 }
 
+// Sum over the wave, delivered in lane 63 (row-wise DPP steps: no LDS traffic, unlike the shuffles above).
+#define OT_DPP_ADD(x, CTRL, ROWS)                                                                  \
+    do {                                                                                           \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xF, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xF, false); \
+        x += __hiloint2double(hi_, lo_);                                                           \
+    } while (0)
+OT_DEV double wave_sum_in_last_lane(double x) {
+    OT_DPP_ADD(x, 0xB1, 0xF);   // quad_perm [1, 0, 3, 2]
+    OT_DPP_ADD(x, 0x4E, 0xF);   // quad_perm [2, 3, 0, 1]
+    OT_DPP_ADD(x, 0x141, 0xF);  // row_half_mirror
+    OT_DPP_ADD(x, 0x140, 0xF);  // row_mirror: every lane holds its row's sum
+    OT_DPP_ADD(x, 0x142, 0xA);  // row_bcast15 into rows 1 and 3
+    OT_DPP_ADD(x, 0x143, 0xC);  // row_bcast31 into rows 2 and 3
+    return x;
+}
+
+// Four values per lane, to be added under a key (a pixel): lanes of the wave that share a key are summed first and ONE lane
+// adds for them.  Images of point-like objects -- the point spread functions this path serves -- send the 64 hits of a wave
+// into one or two pixels: as LDS atomics on one address they are carried out one after the other, and the LDS pipe of the CU
+// was what the binning of such images waited for (BASELINE config 2, 1e7 rays into five spots: 0.23 ms, 2.4 TB/s).  Up to
+// three keys per call are treated this way, a key with fewer than eight lanes is not worth the 72 vector instructions of the
+// four sums; whoever is left adds for himself.  All lanes of the wave must call (valid = false: nothing to add).
+template <class ADD>
+OT_DEV void wave_add4_by_key(bool valid, int key, double v0, double v1, double v2, double v3, ADD add) {
+    const int lane = __lane_id();
+    unsigned long long todo = __ballot(valid), self = 0ull;
+    for (int round = 0; round < 3 && todo; round++) {
+        const int leader = (int)__ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long m = __ballot(valid && key == k) & todo;
+        todo &= ~m;
+        if (__popcll(m) < 8) {
+            self |= m;
+            continue;
+        }
+        const bool in = (m >> lane) & 1ull;
+        const double a0 = wave_sum_in_last_lane(in ? v0 : 0.0), a1 = wave_sum_in_last_lane(in ? v1 : 0.0);
+        const double a2 = wave_sum_in_last_lane(in ? v2 : 0.0), a3 = wave_sum_in_last_lane(in ? v3 : 0.0);
+        if (lane == 63) add(k, a0, a1, a2, a3);
+    }
+    if (((todo | self) >> lane) & 1ull) add(key, v0, v1, v2, v3);
+}
+
 // SphericalSurface.sphere_projection spherical_surface.py:36-97
 OT_DEV void sphere_project(double x0, double y0, double z0, double R, int projection, V3& p) {
     if (projection == OT_PROJ_NONE || projection == OT_PROJ_ORTHOGRAPHIC) return;
@@ -373,8 +417,8 @@ template <bool NUMERIC, class DET>
 OT_DEV void detector_one(const ot_rays& R, int64_t q, int64_t r, bool active, int64_t count, DET& D, const SectionPair& sp,
                          const V3& sdir, double (*sext)[4][4], int di) {
     V3 ph;
-    float w;
-    bool valid, any_ill = false, timeout = false;
+    float w = 0.f;
+    bool valid = false, any_ill = false, timeout = false;
     // detector with a closed-form hit behind the last surface (the usual case): settled from the prefetched pair of
     // sections; the section search only if a lane of the wave needs it.  Sphere projection and user extent follow either
     // way (ONE copy of the projections' polynomials, outside of the search's loop: with them inside, every ray of a
@@ -594,15 +638,8 @@ __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* _
     for (int64_t c = blockIdx.x; fill ? c < OT_HIT_PIECES_N : c * chunk < n; c += fill ? gridDim.x : n) {
     int64_t i_end = ((c + 1) * chunk < n) ? (c + 1) * chunk : n;
     if (fill) i_end = c * chunk + (int64_t)fill[c];
-    for (int64_t i = c * chunk + threadIdx.x; i < i_end; i += blockDim.x) {
-        float wi = w[i];
-        if (!(wi > 0.f || wi < 0.f)) continue;  // w == 0: adds nothing (and NaN weights are dropped)
-        int32_t ix, iy;
-        const int pix = hit_pixel(a, px[i], py[i], ix, iy);
-        if (pix < 0) continue;
-        double xo, yo, zo;
-        observer_xyz_at(obs, (double)wl[i], xo, yo, zo);
-        double wm = (double)wi * a.ws;
+    // (every lane of a wave takes part in every round: the sums over lanes with a common pixel need them all)
+    auto add = [&](int pix, double a0, double a1, double a2, double a3) {
         // LDS hash insert: claim or match one of OT_HASH_PROBES consecutive entries
         unsigned int h = ((unsigned int)pix * 2654435761u) >> (32 - 11);  // OT_HASH_N = 2^11
         int slot = -1;
@@ -616,19 +653,25 @@ __global__ __launch_bounds__(1024) void render_kernel(int64_t n, const double* _
                 break;
             }
         }
-        if (slot >= 0) {
-            double* hv = &hval[slot * 4];
-            unsafeAtomicAdd(hv + 0, xo * wm);
-            unsafeAtomicAdd(hv + 1, yo * wm);
-            unsafeAtomicAdd(hv + 2, zo * wm);
-            unsafeAtomicAdd(hv + 3, 1.0 * wm);
-        } else {
-            double* hg = hist + (int64_t)pix * 4;
-            unsafeAtomicAdd(hg + 0, xo * wm);
-            unsafeAtomicAdd(hg + 1, yo * wm);
-            unsafeAtomicAdd(hg + 2, zo * wm);
-            unsafeAtomicAdd(hg + 3, 1.0 * wm);
-        }
+        double* hv = (slot >= 0) ? &hval[slot * 4] : hist + (int64_t)pix * 4;
+        unsafeAtomicAdd(hv + 0, a0);
+        unsafeAtomicAdd(hv + 1, a1);
+        unsafeAtomicAdd(hv + 2, a2);
+        unsafeAtomicAdd(hv + 3, a3);
+    };
+    const int64_t i_first = c * chunk;
+    for (int64_t base = i_first; base < i_end; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        bool valid = i < i_end;
+        float wi = valid ? w[i] : 0.f;
+        valid = valid && (wi > 0.f || wi < 0.f);  // w == 0: adds nothing (and NaN weights are dropped)
+        int32_t ix, iy;
+        int pix = valid ? hit_pixel(a, px[i], py[i], ix, iy) : -1;
+        valid = valid && pix >= 0;
+        double xo = 0.0, yo = 0.0, zo = 0.0;
+        if (valid) observer_xyz_at(obs, (double)wl[i], xo, yo, zo);
+        const double wm = (double)wi * a.ws;
+        wave_add4_by_key(valid, pix, xo * wm, yo * wm, zo * wm, 1.0 * wm, add);
     }
     }
     __syncthreads();
