@@ -148,8 +148,8 @@ def allreduce_images(hists: list) -> dict:
     a sharded render.  Equally shaped histograms go as ONE message; and of every histogram only the WINDOW of pixels that
     any rank has lit travels (four integers per image are agreed first): BASELINE config 4 renders a 4 x 3 mm picture onto
     a 16 x 16 mm detector at six positions behind the focus -- the windows around its pictures are 21 to 80 % of their
-    histograms, half of the 6 x 28.6 MB together --, a point-spread image sends next to nothing.  Outside its window every rank holds zeros, so
-    the result is the sum of the whole histograms.
+    histograms, half of the 6 x 28.6 MB together --, a point-spread image sends next to nothing.  Outside its window every
+    rank holds zeros, so the result is the sum of the whole histograms.
     -> {"bytes": what travelled, "window": per image [y0, y1, x0, x1], or None where the histograms travelled whole}."""
     if any(h.dtype != torch.float64 or h.dim() != 3 or h.shape[2] != 4 for h in hists):
         raise TypeError("detector histograms are (Ny, Nx, 4) float64")
